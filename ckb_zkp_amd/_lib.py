@@ -1,0 +1,112 @@
+"""ctypes binding of libzkp_accel.so (include/zkp_accel.h).  There is NO CPU fallback: if the library is
+missing or no gfx950 device is present, every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libzkp_accel.so"
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+
+class ZkpError(RuntimeError):
+    def __init__(self, status: int, where: str, text: str):
+        super().__init__(f"{where}: status {status} ({text})")
+        self.status = status
+
+
+class Csr(C.Structure):
+    _fields_ = [("row_ptr", vp), ("col", vp), ("coeff", vp)]
+
+
+class Groth16PkDesc(C.Structure):
+    _fields_ = [
+        ("curve", C.c_int), ("num_inputs", C.c_uint32), ("num_aux", C.c_uint32), ("num_constraints", C.c_uint32),
+        ("at", Csr), ("bt", Csr), ("ct", Csr),
+        ("alpha_g1", vp), ("beta_g1", vp), ("delta_g1", vp), ("beta_g2", vp), ("delta_g2", vp),
+        ("a_query", vp), ("a_inf", vp), ("a_len", C.c_size_t),
+        ("b_g1_query", vp), ("b_g1_inf", vp), ("b_g1_len", C.c_size_t),
+        ("b_g2_query", vp), ("b_g2_inf", vp), ("b_g2_len", C.c_size_t),
+        ("h_query", vp), ("h_inf", vp), ("h_len", C.c_size_t),
+        ("l_query", vp), ("l_inf", vp), ("l_len", C.c_size_t),
+    ]
+
+
+class Groth16Timing(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_witness_map", C.c_float), ("ms_msm", C.c_float * 5),
+                ("ms_assemble", C.c_float), ("ms_msm_accumulate", C.c_float),
+                ("msm_accumulate_launches", C.c_uint64), ("msm_points", C.c_uint64)]
+
+
+# name -> (restype, argtypes).  Must list every symbol declared in include/zkp_accel.h
+# (tests/test_abi.py parses the header and checks both directions).
+SIGNATURES = {
+    "zkp_status_string": (C.c_char_p, [C.c_int32]),
+    "zkp_version": (C.c_char_p, []),
+    "zkp_ctx_create": (C.c_int32, [C.POINTER(vp), C.c_int]),
+    "zkp_ctx_destroy": (C.c_int32, [vp]),
+    "zkp_ctx_set_stream": (C.c_int32, [vp, vp]),
+    "zkp_ctx_sync": (C.c_int32, [vp]),
+    "zkp_dev_alloc": (C.c_int32, [vp, C.c_size_t, C.POINTER(vp)]),
+    "zkp_dev_free": (C.c_int32, [vp, vp]),
+    "zkp_h2d": (C.c_int32, [vp, vp, vp, C.c_size_t]),
+    "zkp_d2h": (C.c_int32, [vp, vp, vp, C.c_size_t]),
+    "zkp_timer_start": (C.c_int32, [vp]),
+    "zkp_timer_stop_ms": (C.c_int32, [vp, C.POINTER(C.c_float)]),
+    "zkp_ntt": (C.c_int32, [vp, C.c_int, vp, C.c_uint32, C.c_int32]),
+    "zkp_ntt_dev": (C.c_int32, [vp, C.c_int, vp, C.c_uint32, C.c_int32]),
+    "zkp_bases_upload_g1": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "zkp_bases_upload_g2": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "zkp_bases_free": (C.c_int32, [vp, C.c_uint64]),
+    "zkp_bases_len": (C.c_int32, [vp, C.c_uint64, C.POINTER(C.c_size_t)]),
+    "zkp_msm_g1": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
+    "zkp_msm_g2": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
+    "zkp_msm_g1_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
+    "zkp_msm_g2_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
+    "zkp_vartime_multiscalar_mul_g1": (C.c_int32, [vp, C.c_uint64, vp, C.c_size_t, vp]),
+    "zkp_g1_fold": (C.c_int32, [vp, C.c_int, vp, C.c_size_t, vp]),
+    "zkp_g2_fold": (C.c_int32, [vp, C.c_int, vp, C.c_size_t, vp]),
+    "zkp_g1_into_affine": (C.c_int32, [vp, C.c_int, vp, vp, vp]),
+    "zkp_g2_into_affine": (C.c_int32, [vp, C.c_int, vp, vp, vp]),
+    "zkp_fixed_base_mul_g1": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, vp, vp]),
+    "zkp_fixed_base_mul_g2": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, vp, vp]),
+    "zkp_groth16_pk_upload": (C.c_int32, [vp, C.POINTER(Groth16PkDesc), C.POINTER(vp)]),
+    "zkp_groth16_pk_free": (C.c_int32, [vp, vp]),
+    "zkp_groth16_witness_map": (C.c_int32, [vp, vp, vp, vp]),
+    "zkp_groth16_witness_map_dev": (C.c_int32, [vp, vp, vp, vp]),
+    "zkp_groth16_domain_size": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
+    "zkp_groth16_prove": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp]),
+    "zkp_groth16_prove_dev": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp]),
+    "zkp_groth16_last_timing": (C.c_int32, [vp, C.POINTER(Groth16Timing)]),
+    "zkp_set_profiling": (C.c_int32, [vp, C.c_int32]),
+}
+
+_lib = None
+
+
+def load(path: os.PathLike | None = None) -> C.CDLL:
+    """dlopen the in-tree library and attach signatures.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise ImportError(f"{p} not found — build it with `python -m ckb_zkp_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(str(p))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status: int, where: str) -> None:
+    if status != 0:
+        raise ZkpError(status, where, load().zkp_status_string(status).decode())

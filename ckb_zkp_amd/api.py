@@ -1,0 +1,188 @@
+"""Thin object layer over the C ABI (numpy in / numpy out).  One `Context` per GPU / process."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .params import CurveParams, get_curve
+
+NTT_FFT, NTT_IFFT, NTT_COSET_FFT, NTT_COSET_IFFT = 0, 1, 2, 3
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return C.c_void_p(a.ctypes.data)
+
+
+def _c64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class Context:
+    """zkp_ctx: device, stream, twiddle tables, scratch, resident bases."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.zkp_ctx_create(C.byref(h), device), "zkp_ctx_create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zkp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- plumbing
+    def set_stream(self, hip_stream: int | None):
+        _lib.check(self.lib.zkp_ctx_set_stream(self.h, C.c_void_p(hip_stream or 0)), "zkp_ctx_set_stream")
+
+    def sync(self):
+        _lib.check(self.lib.zkp_ctx_sync(self.h), "zkp_ctx_sync")
+
+    def set_profiling(self, on: bool):
+        _lib.check(self.lib.zkp_set_profiling(self.h, 1 if on else 0), "zkp_set_profiling")
+
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        _lib.check(self.lib.zkp_dev_alloc(self.h, nbytes, C.byref(p)), "zkp_dev_alloc")
+        return p.value
+
+    def dev_free(self, dptr: int):
+        _lib.check(self.lib.zkp_dev_free(self.h, C.c_void_p(dptr)), "zkp_dev_free")
+
+    def h2d(self, dptr: int, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        _lib.check(self.lib.zkp_h2d(self.h, C.c_void_p(dptr), _ptr(a), a.nbytes), "zkp_h2d")
+
+    def d2h(self, a: np.ndarray, dptr: int):
+        assert a.flags["C_CONTIGUOUS"]
+        _lib.check(self.lib.zkp_d2h(self.h, _ptr(a), C.c_void_p(dptr), a.nbytes), "zkp_d2h")
+
+    def to_device(self, a: np.ndarray) -> int:
+        a = np.ascontiguousarray(a)
+        d = self.dev_alloc(a.nbytes)
+        self.h2d(d, a)
+        return d
+
+    def timer_start(self):
+        _lib.check(self.lib.zkp_timer_start(self.h), "zkp_timer_start")
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        _lib.check(self.lib.zkp_timer_stop_ms(self.h, C.byref(ms)), "zkp_timer_stop_ms")
+        return ms.value
+
+    # ---- NTT (ark-poly EvaluationDomain ops)
+    def ntt(self, curve, data: np.ndarray, op: int) -> np.ndarray:
+        """data: (2^k, 4) uint64 Montgomery Fr; returns the transformed copy."""
+        c = get_curve(curve)
+        a = _c64(data).copy()
+        n = a.shape[0]
+        assert n & (n - 1) == 0 and a.shape[1] == 4
+        _lib.check(self.lib.zkp_ntt(self.h, c.cid, _ptr(a), n.bit_length() - 1, op), "zkp_ntt")
+        return a
+
+    def ntt_dev(self, curve, dptr: int, log_n: int, op: int):
+        _lib.check(self.lib.zkp_ntt_dev(self.h, get_curve(curve).cid, C.c_void_p(dptr), log_n, op), "zkp_ntt_dev")
+
+    # ---- bases / MSM (ark-ec VariableBaseMSM)
+    def upload_bases(self, curve, group: int, xy: np.ndarray, inf: np.ndarray | None = None) -> "Bases":
+        c = get_curve(curve)
+        xy = _c64(xy)
+        n = xy.shape[0] if xy.ndim == 2 else 0
+        if inf is not None:
+            inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        hnd = C.c_uint64()
+        fn = self.lib.zkp_bases_upload_g1 if group == 1 else self.lib.zkp_bases_upload_g2
+        _lib.check(fn(self.h, c.cid, _ptr(xy), _ptr(inf), n, C.byref(hnd)), "zkp_bases_upload")
+        return Bases(self, c, group, hnd.value, n)
+
+    def fold(self, curve, group: int, xyz: np.ndarray) -> np.ndarray:
+        c = get_curve(curve)
+        xyz = _c64(xyz)
+        w = 3 * c.fq_limbs * (1 if group == 1 else 2)
+        out = np.zeros(w, dtype=np.uint64)
+        fn = self.lib.zkp_g1_fold if group == 1 else self.lib.zkp_g2_fold
+        _lib.check(fn(self.h, c.cid, _ptr(xyz), xyz.size // w, _ptr(out)), "zkp_fold")
+        return out
+
+    def into_affine(self, curve, group: int, xyz: np.ndarray):
+        c = get_curve(curve)
+        w = 2 * c.fq_limbs * (1 if group == 1 else 2)
+        xy = np.zeros(w, dtype=np.uint64)
+        inf = np.zeros(1, dtype=np.uint8)
+        fn = self.lib.zkp_g1_into_affine if group == 1 else self.lib.zkp_g2_into_affine
+        _lib.check(fn(self.h, c.cid, _ptr(_c64(xyz)), _ptr(xy), _ptr(inf)), "zkp_into_affine")
+        return xy, bool(inf[0])
+
+    def fixed_base_mul(self, curve, group: int, base_xy: np.ndarray, scalars: np.ndarray):
+        """k_i * P for canonical scalars (n,4) -> ((n, w) uint64 affine Montgomery, (n,) uint8 identity flags)."""
+        c = get_curve(curve)
+        scalars = _c64(scalars)
+        n = scalars.shape[0]
+        w = 2 * c.fq_limbs * (1 if group == 1 else 2)
+        out = np.zeros((n, w), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        fn = self.lib.zkp_fixed_base_mul_g1 if group == 1 else self.lib.zkp_fixed_base_mul_g2
+        _lib.check(fn(self.h, c.cid, _ptr(_c64(base_xy)), _ptr(scalars), n, _ptr(out), _ptr(inf)), "zkp_fixed_base_mul")
+        return out, inf
+
+
+class Bases:
+    """Device-resident query / SRS (zkp_bases_upload_*)."""
+
+    def __init__(self, ctx: Context, curve: CurveParams, group: int, handle: int, n: int):
+        self.ctx, self.curve, self.group, self.handle, self.n = ctx, curve, group, handle, n
+
+    def free(self):
+        if self.handle:
+            _lib.check(self.ctx.lib.zkp_bases_free(self.ctx.h, self.handle), "zkp_bases_free")
+            self.handle = 0
+
+    def _out(self):
+        return np.zeros(3 * self.curve.fq_limbs * (1 if self.group == 1 else 2), dtype=np.uint64)
+
+    def msm(self, scalars: np.ndarray, offset: int = 0) -> np.ndarray:
+        """VariableBaseMSM::multi_scalar_mul(bases[offset..], scalars) -> Jacobian (X,Y,Z) Montgomery limbs."""
+        s = _c64(scalars)
+        n = s.shape[0] if s.ndim == 2 else 0
+        out = self._out()
+        fn = self.ctx.lib.zkp_msm_g1 if self.group == 1 else self.ctx.lib.zkp_msm_g2
+        _lib.check(fn(self.ctx.h, self.handle, offset, _ptr(s), n, _ptr(out)), "zkp_msm")
+        return out
+
+    def msm_dev(self, scalars_dev: int, n: int, offset: int = 0) -> np.ndarray:
+        out = self._out()
+        fn = self.ctx.lib.zkp_msm_g1_dev if self.group == 1 else self.ctx.lib.zkp_msm_g2_dev
+        _lib.check(fn(self.ctx.h, self.handle, offset, C.c_void_p(scalars_dev), n, _ptr(out)), "zkp_msm_dev")
+        return out
+
+    def vartime_multiscalar_mul(self, fr_scalars_mont: np.ndarray) -> np.ndarray:
+        """zkp_curve::Curve::vartime_multiscalar_mul (curve/src/lib.rs:38-45): Montgomery Fr scalars."""
+        assert self.group == 1
+        s = _c64(fr_scalars_mont)
+        out = self._out()
+        _lib.check(self.ctx.lib.zkp_vartime_multiscalar_mul_g1(self.ctx.h, self.handle, _ptr(s), s.shape[0], _ptr(out)),
+                   "zkp_vartime_multiscalar_mul_g1")
+        return out
+
+    def msm_affine(self, scalars: np.ndarray, offset: int = 0):
+        return self.ctx.into_affine(self.curve, self.group, self.msm(scalars, offset))

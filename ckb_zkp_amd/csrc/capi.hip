@@ -1,0 +1,295 @@
+// extern "C" boundary (include/zkp_accel.h): argument checking, exception -> status mapping, host<->device
+// staging for the host-pointer variants.  No arithmetic lives here.
+#include <cstring>
+
+#include "ctx.hpp"
+#include "internal.hpp"
+
+using namespace zkp;
+
+namespace {
+
+template <class Fn>
+int32_t guarded(zkp_ctx* ctx, Fn&& fn) {
+  if (!ctx) return ZKP_ERR_BAD_ARG;
+  try {
+    ZKP_HIP(hipSetDevice(ctx->device));
+    fn();
+    return ZKP_OK;
+  } catch (const StatusError& e) {
+    return e.status;
+  } catch (const HipError& e) {
+    ctx->last_error = std::string(e.what) + ": " + hipGetErrorString(e.e);
+    fprintf(stderr, "[zkp_accel] HIP error %s at line %d: %s\n", hipGetErrorString(e.e), e.line, e.what);
+    return e.e == hipErrorOutOfMemory ? ZKP_ERR_OOM : ZKP_ERR_DEVICE;
+  } catch (const std::bad_alloc&) {
+    return ZKP_ERR_OOM;
+  } catch (...) {
+    return ZKP_ERR_DEVICE;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* zkp_status_string(int32_t s) {
+  switch (s) {
+    case ZKP_OK: return "ok";
+    case ZKP_ERR_BAD_ARG: return "bad argument";
+    case ZKP_ERR_UNSUPPORTED_CURVE: return "unsupported curve";
+    case ZKP_ERR_DOMAIN_TOO_LARGE: return "domain too large (PolynomialDegreeTooLarge)";
+    case ZKP_ERR_OOM: return "out of device memory";
+    case ZKP_ERR_DEVICE: return "HIP device error / no gfx950 device (there is no CPU fallback)";
+    case ZKP_ERR_BAD_HANDLE: return "bad handle";
+    default: return "unknown status";
+  }
+}
+
+const char* zkp_version(void) { return "zkp_accel 0.1 (gfx950)"; }
+
+int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
+  if (!out) return ZKP_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) {
+    fprintf(stderr, "[zkp_accel] no usable HIP device (count=%d, requested %d); there is no CPU fallback\n", count,
+            device_id);
+    return ZKP_ERR_DEVICE;
+  }
+  zkp_ctx* ctx = new (std::nothrow) zkp_ctx();
+  if (!ctx) return ZKP_ERR_OOM;
+  ctx->device = device_id;
+  int32_t st = guarded(ctx, [&] {
+    ZKP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ZKP_HIP(hipEventCreate(&ctx->ev0));
+    ZKP_HIP(hipEventCreate(&ctx->ev1));
+    ZKP_HIP(hipEventCreate(&ctx->ev2));
+    ZKP_HIP(hipEventCreate(&ctx->ev3));
+  });
+  if (st != ZKP_OK) {
+    delete ctx;
+    return st;
+  }
+  *out = ctx;
+  return ZKP_OK;
+}
+
+int32_t zkp_ctx_destroy(zkp_ctx* ctx) {
+  if (!ctx) return ZKP_ERR_BAD_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ntt_free_tables(ctx);
+  msm_free_all(ctx);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+  if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return ZKP_OK;
+}
+
+int32_t zkp_ctx_set_stream(zkp_ctx* ctx, void* s) {
+  return guarded(ctx, [&] {
+    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+    if (s) {
+      if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+      ctx->stream = reinterpret_cast<hipStream_t>(s);
+      ctx->own_stream = false;
+    } else if (!ctx->own_stream) {
+      ZKP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+  });
+}
+
+int32_t zkp_ctx_sync(zkp_ctx* ctx) {
+  return guarded(ctx, [&] { ZKP_HIP(hipStreamSynchronize(ctx->stream)); });
+}
+
+int32_t zkp_dev_alloc(zkp_ctx* ctx, size_t bytes, void** dptr) {
+  if (!dptr) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    *dptr = nullptr;
+    if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+  });
+}
+int32_t zkp_dev_free(zkp_ctx* ctx, void* dptr) {
+  return guarded(ctx, [&] {
+    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+    if (dptr) ZKP_HIP(hipFree(dptr));
+  });
+}
+int32_t zkp_h2d(zkp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes && (!dst || !src)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    if (bytes) ZKP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+int32_t zkp_d2h(zkp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes && (!dst || !src)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    if (bytes) ZKP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+int32_t zkp_timer_start(zkp_ctx* ctx) {
+  return guarded(ctx, [&] { ZKP_HIP(hipEventRecord(ctx->ev0, ctx->stream)); });
+}
+int32_t zkp_timer_stop_ms(zkp_ctx* ctx, float* ms) {
+  if (!ms) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    ZKP_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ZKP_HIP(hipEventSynchronize(ctx->ev1));
+    ZKP_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  });
+}
+int32_t zkp_set_profiling(zkp_ctx* ctx, int32_t enable) {
+  if (!ctx) return ZKP_ERR_BAD_ARG;
+  ctx->profiling = enable != 0;
+  return ZKP_OK;
+}
+
+// ------------------------------------------------------------------------------------------- NTT
+int32_t zkp_ntt_dev(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* data, uint32_t log_n, int32_t op) {
+  if (!data) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    ZKP_REQUIRE(log_n <= 30, ZKP_ERR_DOMAIN_TOO_LARGE);
+    ntt_run(ctx, curve, reinterpret_cast<uint32_t*>(data), (int)log_n, op);
+  });
+}
+int32_t zkp_ntt(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* data, uint32_t log_n, int32_t op) {
+  if (!data) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    ZKP_REQUIRE(log_n <= 30, ZKP_ERR_DOMAIN_TOO_LARGE);
+    ZKP_REQUIRE(curve == ZKP_BN254 || curve == ZKP_BLS12_381, ZKP_ERR_UNSUPPORTED_CURVE);
+    ZKP_REQUIRE((int)log_n <= (curve == ZKP_BN254 ? 28 : 32), ZKP_ERR_DOMAIN_TOO_LARGE);
+    size_t bytes = ((size_t)1 << log_n) * 32;
+    uint32_t* d = ctx->ntt_io.as<uint32_t>(bytes / 4);
+    ZKP_HIP(hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ntt_run(ctx, curve, d, (int)log_n, op);
+    ZKP_HIP(hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+// ------------------------------------------------------------------------------------------- bases / MSM
+int32_t zkp_bases_upload_g1(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n,
+                            uint64_t* handle) {
+  if (!handle || (n && !xy)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { *handle = bases_upload(ctx, curve, 1, xy, inf, n); });
+}
+int32_t zkp_bases_upload_g2(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n,
+                            uint64_t* handle) {
+  if (!handle || (n && !xy)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { *handle = bases_upload(ctx, curve, 2, xy, inf, n); });
+}
+int32_t zkp_bases_free(zkp_ctx* ctx, uint64_t handle) {
+  return guarded(ctx, [&] { bases_free(ctx, handle); });
+}
+int32_t zkp_bases_len(zkp_ctx* ctx, uint64_t handle, size_t* n) {
+  if (!n) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { *n = bases_len(ctx, handle); });
+}
+
+static int32_t msm_common(zkp_ctx* ctx, int group, uint64_t handle, size_t offset, const uint64_t* scalars, size_t n,
+                          uint64_t* out, bool scalars_on_device, bool montgomery) {
+  if (!out || (n && !scalars)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    size_t avail = bases_len(ctx, handle);
+    ZKP_REQUIRE(bases_group(ctx, handle) == group, ZKP_ERR_BAD_HANDLE);
+    ZKP_REQUIRE(offset <= avail, ZKP_ERR_BAD_ARG);
+    if (n > avail - offset) n = avail - offset;      // ark min(len) truncation
+    const uint64_t* sdev = scalars;
+    if (!scalars_on_device && n) {
+      uint64_t* d = ctx->msm_scalars.as<uint64_t>(n * 4);
+      ZKP_HIP(hipMemcpyAsync(d, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+      sdev = d;
+    }
+    msm_run(ctx, handle, offset, sdev, n, montgomery, out);
+  });
+}
+int32_t zkp_msm_g1(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t* s, size_t n, uint64_t* out) {
+  return msm_common(ctx, 1, h, off, s, n, out, false, false);
+}
+int32_t zkp_msm_g2(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t* s, size_t n, uint64_t* out) {
+  return msm_common(ctx, 2, h, off, s, n, out, false, false);
+}
+int32_t zkp_msm_g1_dev(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t* s, size_t n, uint64_t* out) {
+  return msm_common(ctx, 1, h, off, s, n, out, true, false);
+}
+int32_t zkp_msm_g2_dev(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t* s, size_t n, uint64_t* out) {
+  return msm_common(ctx, 2, h, off, s, n, out, true, false);
+}
+int32_t zkp_vartime_multiscalar_mul_g1(zkp_ctx* ctx, uint64_t h, const uint64_t* s, size_t n, uint64_t* out) {
+  return msm_common(ctx, 1, h, 0, s, n, out, false, true);
+}
+
+int32_t zkp_g1_fold(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz, size_t k, uint64_t* out) {
+  if (!out || (k && !xyz)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { point_fold(ctx, curve, 1, xyz, k, out); });
+}
+int32_t zkp_g2_fold(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz, size_t k, uint64_t* out) {
+  if (!out || (k && !xyz)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { point_fold(ctx, curve, 2, xyz, k, out); });
+}
+int32_t zkp_g1_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz, uint64_t* xy, uint8_t* inf) {
+  if (!xyz || !xy || !inf) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { point_into_affine(ctx, curve, 1, xyz, xy, inf); });
+}
+int32_t zkp_g2_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz, uint64_t* xy, uint8_t* inf) {
+  if (!xyz || !xy || !inf) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { point_into_affine(ctx, curve, 2, xyz, xy, inf); });
+}
+int32_t zkp_fixed_base_mul_g1(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* base, const uint64_t* scalars, size_t n,
+                              uint64_t* out_xy, uint8_t* out_inf) {
+  if (!base || (n && (!scalars || !out_xy || !out_inf))) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { fixed_base_mul(ctx, curve, 1, base, scalars, n, out_xy, out_inf); });
+}
+int32_t zkp_fixed_base_mul_g2(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* base, const uint64_t* scalars, size_t n,
+                              uint64_t* out_xy, uint8_t* out_inf) {
+  if (!base || (n && (!scalars || !out_xy || !out_inf))) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { fixed_base_mul(ctx, curve, 2, base, scalars, n, out_xy, out_inf); });
+}
+
+// ------------------------------------------------------------------------------------------- Groth16
+int32_t zkp_groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, zkp_groth16_pk** out) {
+  if (!desc || !out) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { *out = groth16_pk_upload(ctx, desc); });
+}
+int32_t zkp_groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk) {
+  if (!pk) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_pk_free(ctx, pk); });
+}
+int32_t zkp_groth16_domain_size(zkp_groth16_pk* pk, uint64_t* n) {
+  if (!pk || !n) return ZKP_ERR_BAD_ARG;
+  *n = groth16_domain_size(pk);
+  return ZKP_OK;
+}
+int32_t zkp_groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, uint64_t* h) {
+  if (!pk || !z || !h) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_witness_map(ctx, pk, z, h, false); });
+}
+int32_t zkp_groth16_witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, uint64_t* h) {
+  if (!pk || !z || !h) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_witness_map(ctx, pk, z, h, true); });
+}
+int32_t zkp_groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, const uint64_t* r, const uint64_t* s,
+                          uint64_t* proof, uint8_t* inf) {
+  if (!pk || !z || !r || !s || !proof || !inf) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_prove(ctx, pk, z, false, r, s, proof, inf); });
+}
+int32_t zkp_groth16_prove_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, const uint64_t* r,
+                              const uint64_t* s, uint64_t* proof, uint8_t* inf) {
+  if (!pk || !z || !r || !s || !proof || !inf) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_prove(ctx, pk, z, true, r, s, proof, inf); });
+}
+int32_t zkp_groth16_last_timing(zkp_ctx* ctx, zkp_groth16_timing* out) {
+  if (!ctx || !out) return ZKP_ERR_BAD_ARG;
+  *out = ctx->last_timing;
+  return ZKP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// Library context: device, stream, cached twiddle tables, grow-only scratch arena, resident bases.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/zkp_accel.h"
+
+namespace zkp {
+
+struct HipError {
+  hipError_t e;
+  const char* what;
+  int line;
+};
+
+#define ZKP_HIP(call)                                                   \
+  do {                                                                  \
+    hipError_t _e = (call);                                             \
+    if (_e != hipSuccess) throw ::zkp::HipError{_e, #call, __LINE__};   \
+  } while (0)
+
+struct StatusError {
+  int32_t status;
+};
+#define ZKP_REQUIRE(cond, status) \
+  do {                            \
+    if (!(cond)) throw ::zkp::StatusError{(status)}; \
+  } while (0)
+
+// Device buffer that grows on demand (never shrinks): scratch is sized once for the largest job.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void* get(size_t bytes) {
+    if (bytes > cap) {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+      cap = 0;
+      size_t want = bytes + (bytes >> 3) + 256;
+      hipError_t e = hipMalloc(&p, want);
+      if (e != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+      cap = want;
+    }
+    return p;
+  }
+  template <class T>
+  T* as(size_t count) { return reinterpret_cast<T*>(get(count * sizeof(T))); }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// Twiddle tables for one (curve, log_n): two-level powers of w_N, w_N^-1, and coset-shift powers.
+struct NttTables {
+  int log_n = 0, h = 0;           // e = hi << h | lo
+  uint32_t* w_lo = nullptr;       // w^i, i < 2^h            (forward)
+  uint32_t* w_hi = nullptr;       // w^(i << h), i < 2^(log_n-h)
+  uint32_t* wi_lo = nullptr;      // inverse root
+  uint32_t* wi_hi = nullptr;
+  uint32_t* g_lo = nullptr;       // g^i  (coset shift)
+  uint32_t* g_hi = nullptr;
+  uint32_t* gi_lo = nullptr;      // g^-i
+  uint32_t* gi_hi = nullptr;      // g^-(i<<h) / N   (1/N folded in)
+  uint32_t* sub_fwd = nullptr;    // w_R^k, k < R/2, R = 2^SMAX_TABLE (sub-FFT butterflies)
+  uint32_t* sub_inv = nullptr;
+  uint32_t* n_inv = nullptr;      // 1/N (one element)
+  void* block = nullptr;
+};
+
+struct BasesEntry;   // msm.hip
+struct Groth16Timing {
+  zkp_groth16_timing t{};
+};
+
+}  // namespace zkp
+
+struct zkp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // zkp_timer_*
+  hipEvent_t ev2 = nullptr, ev3 = nullptr;   // internal per-kernel timing
+  bool profiling = false;
+  std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)
+  zkp::DevBuf ntt_scratch, ntt_io;
+  // MSM scratch
+  zkp::DevBuf msm_scalars, msm_keys, msm_vals, msm_keys2, msm_vals2, msm_sort_tmp, msm_offsets, msm_buckets,
+      msm_tmp, msm_out, msm_misc;
+  std::unordered_map<uint64_t, std::shared_ptr<zkp::BasesEntry>> bases;
+  uint64_t next_handle = 1;
+  zkp_groth16_timing last_timing{};
+  std::string last_error;
+};

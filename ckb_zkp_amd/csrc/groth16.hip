@@ -1,0 +1,330 @@
+// Groth16 prover orchestration on the device: the host-side mirror of
+// /root/reference/groth16/src/prover.rs:124-211 (`create_proof`) and
+// /root/reference/groth16/src/r1cs_to_qap.rs:113-172 (`R1CStoQAP::witness_map`).
+//
+// What stays on the caller's side: circuit synthesis (Rust closures filling `ProvingAssignment`,
+// prover.rs:16-95).  What crosses the boundary: the three sparse matrices at/bt/ct (fixed per circuit,
+// uploaded with the key) and the full assignment z = input_assignment ++ aux_assignment (Montgomery Fr).
+//
+// Device pipeline for one proof (everything resident in HBM, one stream, no host round trips until the
+// 3 proof points come back):
+//   1. a,b,c = A z, B z, C z (CSR, one lane per constraint row)            r1cs_to_qap.rs:131-142,154-159
+//   2. ifft, coset_fft on a,b,c; ab = (a*b - c) / Z(g); coset_ifft -> h     r1cs_to_qap.rs:144-169
+//   3. five MSMs; `into_repr()` (prover.rs:150-161) is fused into the MSM digit scan
+//   4. assemble A, B, C                                                      prover.rs:164-210
+//
+// Restructuring that keeps the result identical (a proof is three group elements, so any evaluation order
+// is bit-exact): the small fixed-point terms of prover.rs:165-177,183,213-228 are folded INTO the MSMs by
+// extending each query with a few key points and the scalar vector with (1, r, s, -rs):
+//     S      = z ++ [1, r, s, -r*s]
+//     A_ext  = a_query    ++ [alpha_g1, delta_g1, inf,      inf     ]   -> g_a  = <A_ext , S>
+//     B1_ext = b_g1_query ++ [beta_g1 , inf,      delta_g1, inf     ]   -> g1_b = <B1_ext, S>
+//     B2_ext = b_g2_query ++ [beta_g2 , inf,      delta_g2, inf     ]   -> g2_b = <B2_ext, S>
+//     L_ext  = l_query    ++ [inf,      inf,      inf,      delta_g1]   -> l'   = <L_ext , S[num_inputs..]>
+// (z[0] = 1 so query[0] needs no special case; r == 0 makes r*g1_b the identity exactly as the reference's
+// `if r != 0` branch does).  What remains is  C = s*g_a + r*g1_b + l' + h_acc  and three `into_affine()`.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "field.cuh"
+#include "internal.hpp"
+#include "msm_vtbl.hpp"
+
+using namespace zkp;
+
+struct DevCsr {
+  uint32_t* row_ptr = nullptr;
+  uint32_t* col = nullptr;
+  uint32_t* coeff = nullptr;
+  size_t nnz = 0;
+};
+
+struct zkp_groth16_pk {
+  int curve = 0;
+  uint32_t num_inputs = 0, num_aux = 0, num_constraints = 0;
+  int log_n = 0;
+  size_t N = 0, nz = 0;
+  DevCsr m[3];
+  uint64_t hA = 0, hB1 = 0, hB2 = 0, hH = 0, hL = 0;
+  DevBuf abc;        // 3 * N Fr
+  DevBuf S;          // nz + 4 Fr
+  DevBuf results;    // 5 XYZZ (G2-sized slots)
+  DevBuf consts;     // zinv etc.
+  DevBuf proof;      // device proof + flags
+};
+
+namespace zkp {
+
+// a[row] = sum coeff * z[col] ; rows >= num_constraints: a gets z[row - nc] for the next num_inputs rows, 0 after
+template <class P>
+__global__ __launch_bounds__(256) void csr_eval_kernel(const uint32_t* __restrict__ row_ptr,
+                                                       const uint32_t* __restrict__ col,
+                                                       const uint32_t* __restrict__ coeff,
+                                                       const uint32_t* __restrict__ z, uint32_t nc, uint32_t N,
+                                                       uint32_t num_inputs, int is_a, uint32_t* __restrict__ out) {
+  using F = Fp<P>;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  F acc = F::zero();
+  if (i < nc) {
+    const F one = F::one();
+    for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; k++) {
+      F v = F::load(z + (size_t)col[k] * 8);
+      F cf = F::load(coeff + (size_t)k * 8);
+      if (cf == one) acc = acc + v;          // evaluate_constraint's is_one fast path (r1cs_to_qap.rs:39-43)
+      else acc = acc + v * cf;
+    }
+  } else if (is_a && i - nc < num_inputs) {
+    acc = F::load(z + (size_t)(i - nc) * 8); // r1cs_to_qap.rs:140-142
+  }
+  acc.store(out + (size_t)i * 8);
+}
+
+// ab[i] = (a[i]*b[i] - c[i]) * zinv      (r1cs_to_qap.rs:150,164-168)
+template <class P>
+__global__ __launch_bounds__(256) void qap_pointwise_kernel(uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                            const uint32_t* __restrict__ c,
+                                                            const uint32_t* __restrict__ zinv, uint32_t N) {
+  using F = Fp<P>;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  F x = F::load(a + (size_t)i * 8) * F::load(b + (size_t)i * 8) - F::load(c + (size_t)i * 8);
+  (x * F::load(zinv)).store(a + (size_t)i * 8);
+}
+
+// consts[0] = (g^N - 1)^-1
+template <class P>
+__global__ void qap_consts_kernel(uint32_t* consts, int log_n) {
+  if (threadIdx.x || blockIdx.x) return;
+  using F = Fp<P>;
+  F g;
+#pragma unroll
+  for (int i = 0; i < 8; i++) g.v[i] = P::GEN[i];
+  for (int i = 0; i < log_n; i++) g = g.sqr();
+  (g - F::one()).inv().store(consts);
+}
+
+// S tail: [1, r, s, -r*s]
+template <class P>
+__global__ void scalar_tail_kernel(uint32_t* tail, const uint32_t* rs) {
+  if (threadIdx.x || blockIdx.x) return;
+  using F = Fp<P>;
+  F r = F::load(rs), s = F::load(rs + 8);
+  F::one().store(tail);
+  r.store(tail + 8);
+  s.store(tail + 16);
+  (r * s).neg().store(tail + 24);
+}
+
+static DevCsr upload_csr(zkp_ctx* ctx, const zkp_csr& m, uint32_t rows) {
+  DevCsr d;
+  ZKP_REQUIRE(m.row_ptr != nullptr, ZKP_ERR_BAD_ARG);
+  d.nnz = m.row_ptr[rows];
+  ZKP_REQUIRE(d.nnz == 0 || (m.col && m.coeff), ZKP_ERR_BAD_ARG);
+  if (hipMalloc(&d.row_ptr, ((size_t)rows + 1) * 4) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+  if (hipMalloc(&d.col, std::max<size_t>(d.nnz, 1) * 4) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+  if (hipMalloc(&d.coeff, std::max<size_t>(d.nnz, 1) * 32) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+  ZKP_HIP(hipMemcpyAsync(d.row_ptr, m.row_ptr, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (d.nnz) {
+    ZKP_HIP(hipMemcpyAsync(d.col, m.col, d.nnz * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZKP_HIP(hipMemcpyAsync(d.coeff, m.coeff, d.nnz * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return d;
+}
+
+// query ++ tail points (tail entry nullptr = identity)
+static uint64_t upload_ext(zkp_ctx* ctx, int curve, int group, const uint64_t* q, const uint8_t* inf, size_t n,
+                           size_t limbs_per_point, const uint64_t* const tail[4]) {
+  std::vector<uint64_t> xy((n + 4) * limbs_per_point, 0);
+  std::vector<uint8_t> fl(n + 4, 0);
+  if (n) memcpy(xy.data(), q, n * limbs_per_point * 8);
+  if (inf && n) memcpy(fl.data(), inf, n);
+  for (int k = 0; k < 4; k++) {
+    if (tail[k]) memcpy(xy.data() + (n + k) * limbs_per_point, tail[k], limbs_per_point * 8);
+    else fl[n + k] = 1;
+  }
+  return bases_upload(ctx, curve, group, xy.data(), fl.data(), n + 4);
+}
+
+zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d) {
+  ZKP_REQUIRE(d->curve == ZKP_BN254 || d->curve == ZKP_BLS12_381, ZKP_ERR_UNSUPPORTED_CURVE);
+  ZKP_REQUIRE(d->num_inputs >= 1, ZKP_ERR_BAD_ARG);
+  std::unique_ptr<zkp_groth16_pk> pk(new zkp_groth16_pk());
+  pk->curve = d->curve;
+  pk->num_inputs = d->num_inputs;
+  pk->num_aux = d->num_aux;
+  pk->num_constraints = d->num_constraints;
+  pk->nz = (size_t)d->num_inputs + d->num_aux;
+  size_t dom = (size_t)d->num_constraints + d->num_inputs;       // r1cs_to_qap.rs:123-126
+  int lg = 0;
+  while (((size_t)1 << lg) < dom) lg++;
+  ZKP_REQUIRE(lg <= (d->curve == ZKP_BN254 ? 28 : 32) && lg <= 30, ZKP_ERR_DOMAIN_TOO_LARGE);
+  pk->log_n = lg;
+  pk->N = (size_t)1 << lg;
+  ZKP_REQUIRE(d->a_len == pk->nz && d->b_g1_len == pk->nz && d->b_g2_len == pk->nz, ZKP_ERR_BAD_ARG);
+  ZKP_REQUIRE(d->l_len == d->num_aux, ZKP_ERR_BAD_ARG);
+  const size_t fq = d->curve == ZKP_BN254 ? 4 : 6;
+  const uint64_t* tA[4] = {d->alpha_g1, d->delta_g1, nullptr, nullptr};
+  const uint64_t* tB1[4] = {d->beta_g1, nullptr, d->delta_g1, nullptr};
+  const uint64_t* tB2[4] = {d->beta_g2, nullptr, d->delta_g2, nullptr};
+  const uint64_t* tL[4] = {nullptr, nullptr, nullptr, d->delta_g1};
+  for (auto p : {d->alpha_g1, d->beta_g1, d->delta_g1, d->beta_g2, d->delta_g2}) ZKP_REQUIRE(p, ZKP_ERR_BAD_ARG);
+  pk->m[0] = upload_csr(ctx, d->at, d->num_constraints);
+  pk->m[1] = upload_csr(ctx, d->bt, d->num_constraints);
+  pk->m[2] = upload_csr(ctx, d->ct, d->num_constraints);
+  pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA);
+  pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1);
+  pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2);
+  pk->hH = bases_upload(ctx, d->curve, 1, d->h_query, d->h_inf, d->h_len);
+  pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL);
+  uint32_t* consts = pk->consts.as<uint32_t>(64);
+  if (d->curve == ZKP_BN254) hipLaunchKernelGGL(qap_consts_kernel<Bn254Fr>, dim3(1), dim3(64), 0, ctx->stream, consts, lg);
+  else hipLaunchKernelGGL(qap_consts_kernel<Bls381Fr>, dim3(1), dim3(64), 0, ctx->stream, consts, lg);
+  ZKP_HIP(hipGetLastError());
+  pk->abc.get(3 * pk->N * 32);
+  pk->S.get((pk->nz + 4) * 32);
+  pk->results.get(5 * 16 * 24 * 4 + 64);
+  pk->proof.get(4096);
+  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  return pk.release();
+}
+
+void groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk) {
+  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  for (uint64_t h : {pk->hA, pk->hB1, pk->hB2, pk->hH, pk->hL})
+    if (h) ctx->bases.erase(h);
+  for (auto& m : pk->m) {
+    if (m.row_ptr) (void)hipFree(m.row_ptr);
+    if (m.col) (void)hipFree(m.col);
+    if (m.coeff) (void)hipFree(m.coeff);
+  }
+  delete pk;
+}
+
+uint64_t groth16_domain_size(zkp_groth16_pk* pk) { return pk->N; }
+
+// z_dev: nz Fr (device).  Leaves h (N Fr, Montgomery) in pk->abc[0..N)
+template <class P>
+static uint32_t* witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint32_t* z_dev) {
+  const uint32_t N = (uint32_t)pk->N;
+  uint32_t* a = pk->abc.as<uint32_t>(3 * pk->N * 8);
+  uint32_t* b = a + pk->N * 8;
+  uint32_t* c = b + pk->N * 8;
+  uint32_t* bufs[3] = {a, b, c};
+  hipStream_t st = ctx->stream;
+  for (int k = 0; k < 3; k++)
+    hipLaunchKernelGGL(csr_eval_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, st, pk->m[k].row_ptr, pk->m[k].col,
+                       pk->m[k].coeff, z_dev, pk->num_constraints, N, pk->num_inputs, k == 0 ? 1 : 0, bufs[k]);
+  for (int k = 0; k < 3; k++) {
+    ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_IFFT);
+    ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_COSET_FFT);
+  }
+  hipLaunchKernelGGL(qap_pointwise_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, st, a, b, c,
+                     pk->consts.as<uint32_t>(64), N);
+  ntt_run(ctx, pk->curve, a, pk->log_n, ZKP_NTT_COSET_IFFT);
+  ZKP_HIP(hipGetLastError());
+  return a;
+}
+
+void groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, uint64_t* h, bool on_device) {
+  const uint32_t* zd = reinterpret_cast<const uint32_t*>(z);
+  if (!on_device) {
+    uint32_t* s = pk->S.as<uint32_t>((pk->nz + 4) * 8);
+    ZKP_HIP(hipMemcpyAsync(s, z, pk->nz * 32, hipMemcpyHostToDevice, ctx->stream));
+    zd = s;
+  }
+  uint32_t* hd = pk->curve == ZKP_BN254 ? witness_map_dev<Bn254Fr>(ctx, pk, zd) : witness_map_dev<Bls381Fr>(ctx, pk, zd);
+  ZKP_HIP(hipMemcpyAsync(h, hd, pk->N * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+  if (!on_device) ZKP_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+template <class FrP>
+static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
+                    const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out) {
+  hipStream_t st = ctx->stream;
+  const bool prof = ctx->profiling;
+  zkp_groth16_timing tm{};
+  hipEvent_t e0 = nullptr, e1 = nullptr, eT0 = nullptr, eT1 = nullptr;
+  ZKP_HIP(hipEventCreate(&eT0));
+  ZKP_HIP(hipEventCreate(&eT1));
+  if (prof) {
+    ZKP_HIP(hipEventCreate(&e0));
+    ZKP_HIP(hipEventCreate(&e1));
+  }
+  auto tic = [&] { if (prof) ZKP_HIP(hipEventRecord(e0, st)); };
+  auto toc = [&](float* dst) {
+    if (!prof) return;
+    ZKP_HIP(hipEventRecord(e1, st));
+    ZKP_HIP(hipEventSynchronize(e1));
+    ZKP_HIP(hipEventElapsedTime(dst, e0, e1));
+  };
+  ZKP_HIP(hipEventRecord(eT0, st));
+  uint32_t* S = pk->S.as<uint32_t>((pk->nz + 4) * 8);
+  ZKP_HIP(hipMemcpyAsync(S, z, pk->nz * 32, z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  uint32_t* rs = pk->proof.as<uint32_t>(1024);         // [r, s] then proof words then flags
+  uint32_t* proof_dev = rs + 16;
+  uint32_t* flags_dev = proof_dev + 256;
+  ZKP_HIP(hipMemcpyAsync(rs, r, 32, hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipMemcpyAsync(rs + 8, s, 32, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(scalar_tail_kernel<FrP>, dim3(1), dim3(64), 0, st, S + pk->nz * 8, rs);
+
+  tic();
+  uint32_t* h = witness_map_dev<FrP>(ctx, pk, S);
+  toc(&tm.ms_witness_map);
+
+  const MsmVtbl* v1 = msm_vtbl(pk->curve, 1);
+  const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
+  const size_t slot = v2->xyzz_bytes;                  // uniform slot size
+  char* res = reinterpret_cast<char*>(pk->results.get(5 * slot));
+  const uint64_t* Sd = reinterpret_cast<const uint64_t*>(S);
+  float acc_ms = 0.f;
+  uint64_t ent = 0;
+  auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n) {
+    float ms = 0.f;
+    uint64_t e = 0;
+    tic();
+    msm_run(ctx, handle, 0, sc, n, true, nullptr, res + idx * slot, prof ? &ms : nullptr, &e);
+    toc(&tm.ms_msm[idx]);
+    acc_ms += ms;
+    ent += e;
+    tm.msm_accumulate_launches += 1;
+  };
+  run(0, pk->hA, Sd, pk->nz + 4);                                                  // prover.rs:164-167
+  run(1, pk->hB1, Sd, pk->nz + 4);                                                 // prover.rs:170-177
+  run(2, pk->hB2, Sd, pk->nz + 4);                                                 // prover.rs:182-184
+  run(3, pk->hH, reinterpret_cast<const uint64_t*>(h), std::min(pk->N, bases_len(ctx, pk->hH)));  // :186-187
+  run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4);        // prover.rs:189-190
+  tm.ms_msm_accumulate = acc_ms;
+  tm.msm_points = ent;
+
+  tic();
+  // proof layout (32-bit words): A = 2*fN1 | B = 2*fN2 | C = 2*fN1
+  v1->assemble_g1(st, res, slot, rs, proof_dev, flags_dev, 2 * v1->fN + 2 * v2->fN);
+  v2->assemble_g2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN);
+  ZKP_HIP(hipGetLastError());
+  toc(&tm.ms_assemble);
+  const size_t proof_words = 4 * (size_t)v1->fN + 2 * (size_t)v2->fN;
+  uint32_t flags_host[4] = {0, 0, 0, 0};
+  ZKP_HIP(hipMemcpyAsync(proof_out, proof_dev, proof_words * 4, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(flags_host, flags_dev, 12, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipEventRecord(eT1, st));
+  ZKP_HIP(hipStreamSynchronize(st));
+  ZKP_HIP(hipEventElapsedTime(&tm.ms_total, eT0, eT1));
+  for (int i = 0; i < 3; i++) inf_out[i] = (uint8_t)flags_host[i];
+  ctx->last_timing = tm;
+  (void)hipEventDestroy(eT0);
+  (void)hipEventDestroy(eT1);
+  if (prof) {
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+}
+
+void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
+                   const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out) {
+  if (pk->curve == ZKP_BN254) prove_t<Bn254Fr>(ctx, pk, z, z_on_device, r, s, proof_out, inf_out);
+  else prove_t<Bls381Fr>(ctx, pk, z, z_on_device, r, s, proof_out, inf_out);
+}
+
+}  // namespace zkp

@@ -1,0 +1,34 @@
+// Internal (non-ABI) entry points shared between translation units.
+#pragma once
+#include "ctx.hpp"
+
+namespace zkp {
+
+// ntt.hip
+void ntt_run(zkp_ctx* ctx, int curve, uint32_t* data_dev, int log_n, int op);
+void ntt_free_tables(zkp_ctx* ctx);
+
+// msm.hip
+uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, const uint8_t* inf_host, size_t n);
+void bases_free(zkp_ctx* ctx, uint64_t handle);
+size_t bases_len(zkp_ctx* ctx, uint64_t handle);
+int bases_group(zkp_ctx* ctx, uint64_t handle);
+// result -> host Jacobian (out_xyz_host) ; if out_dev_xyzz != nullptr the XYZZ result is also left on device
+void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
+             uint64_t* out_xyz_host, void* out_dev_xyzz = nullptr, float* ms_accumulate = nullptr,
+             uint64_t* n_entries = nullptr);
+void msm_free_all(zkp_ctx* ctx);
+void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz_host);
+void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, uint64_t* xy_out, uint8_t* inf_out);
+void fixed_base_mul(zkp_ctx* ctx, int curve, int group, const uint64_t* base_xy, const uint64_t* scalars_host, size_t n,
+                    uint64_t* out_xy, uint8_t* out_inf);
+
+// groth16.hip
+zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d);
+void groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk);
+uint64_t groth16_domain_size(zkp_groth16_pk* pk);
+void groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, uint64_t* h, bool on_device);
+void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
+                   const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
+
+}  // namespace zkp

@@ -1,0 +1,300 @@
+// Multi-scalar multiplication over G1/G2 for gfx950: fixed-base-precomputed, single-window, sort-based
+// Pippenger.
+//
+// Replaces ark-ec 0.2 `VariableBaseMSM::multi_scalar_mul(bases, scalars)` (reference call sites:
+// /root/reference/groth16/src/prover.rs:187,190,220; /root/reference/marlin/src/pc/kzg10.rs:109,118,137,146;
+// /root/reference/curve/src/lib.rs:44).  ark's CPU algorithm is W = ceil(bits/c) independent windows of
+// 2^c-1 buckets each, one rayon task per window, then a Horner combine with c doublings per window.
+// A GPU lane is ~1000x slower than the chip in aggregate, so every serial tail (running sums, the Horner
+// chain of ~250 doublings) is poison here; and MI355X has 288 GB of HBM.  Design, MI355X-first:
+//
+//   upload (once per key):  T[w][i] = 2^(c*w) * P_i  for w < W, affine, resident in HBM (W ~ 13 copies).
+//   per MSM:
+//     K5  digit scan      scalar i -> W signed c-bit digits d_w in [-2^(c-1), 2^(c-1)];  entry
+//                         (bucket |d_w|-1, point w*n+i, sign) — all windows share ONE bucket set because
+//                         the window weight already lives in T.  Coalesced 32 B/scalar read, 8 B/entry
+//                         written.  Identity bases / zero digits emit a sentinel key.
+//     K6  sort by bucket  radix sort of (key, val) on c bits (rocPRIM device radix sort as scaffolding).
+//     K7  accumulate      one lane per bucket walks its run of the sorted list: gather T[val] (64 B,
+//                         negate y on sign) and mixed-add into an XYZZ accumulator held in VGPRs.
+//     K8  reduce          sum_b (b+1) B_b  with log-depth kernels only: pairwise-sum pyramid A^(l+1)_k =
+//                         A^l_2k + A^l_2k+1; O_l = sum of odd entries of level l;  result =
+//                         sum_l 2^l O_l + root.  No running sums, no Horner over windows.
+//
+// The result is a group element: any correct schedule is bit-identical after `into_affine()`.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "field.cuh"
+#include "internal.hpp"
+#include "msm_vtbl.hpp"
+
+namespace zkp {
+
+const MsmVtbl* msm_vtbl_c01();
+const MsmVtbl* msm_vtbl_c02();
+const MsmVtbl* msm_vtbl_c11();
+const MsmVtbl* msm_vtbl_c12();
+
+const MsmVtbl* msm_vtbl(int curve, int group) {
+  if (curve == ZKP_BN254 && group == 1) return msm_vtbl_c01();
+  if (curve == ZKP_BN254 && group == 2) return msm_vtbl_c02();
+  if (curve == ZKP_BLS12_381 && group == 1) return msm_vtbl_c11();
+  if (curve == ZKP_BLS12_381 && group == 2) return msm_vtbl_c12();
+  throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+}
+
+struct BasesEntry {
+  int curve = 0, group = 1;
+  const MsmVtbl* vt = nullptr;
+  size_t n = 0;
+  int c = 0, W = 0;
+  char* table = nullptr;       // W * n affine points: T[w][i] = 2^(c*w) * P_i
+  uint8_t* inf = nullptr;      // n identity flags (device) or nullptr
+  ~BasesEntry() {
+    if (table) (void)hipFree(table);
+    if (inf) (void)hipFree(inf);
+  }
+};
+
+static int pick_window_bits(size_t n) {
+  if (const char* e = getenv("ZKP_MSM_C")) {
+    int c = atoi(e);
+    if (c >= 2 && c <= 22) return c;
+  }
+  int lg = 0;
+  while (((size_t)2 << lg) <= n) lg++;          // floor(log2 n)
+  return std::min(20, std::max(4, lg));
+}
+
+uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n) {
+  auto e = std::make_shared<BasesEntry>();
+  e->curve = curve;
+  e->group = group;
+  e->vt = msm_vtbl(curve, group);
+  e->n = n;
+  e->c = pick_window_bits(n);
+  e->W = (e->vt->scalar_bits + 1 + e->c - 1) / e->c;
+  ZKP_REQUIRE((double)n * e->W < 2147483000.0, ZKP_ERR_BAD_ARG);
+  const size_t ab = e->vt->aff_bytes;
+  size_t bytes = std::max<size_t>(1, n) * e->W * ab;
+  if (hipMalloc(&e->table, bytes) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+  if (n) {
+    ZKP_HIP(hipMemcpyAsync(e->table, xy, n * ab, hipMemcpyHostToDevice, ctx->stream));
+    if (inf) {
+      if (hipMalloc(&e->inf, n) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+      ZKP_HIP(hipMemcpyAsync(e->inf, inf, n, hipMemcpyHostToDevice, ctx->stream));
+      e->vt->ingest(ctx->stream, e->table, e->inf, n);
+    }
+    e->vt->precompute(ctx->stream, e->table, n, e->c, e->W);
+    ZKP_HIP(hipGetLastError());
+    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  uint64_t h = ctx->next_handle++;
+  ctx->bases[h] = e;
+  return h;
+}
+
+static std::shared_ptr<BasesEntry> get_bases(zkp_ctx* ctx, uint64_t handle) {
+  auto it = ctx->bases.find(handle);
+  if (it == ctx->bases.end()) throw StatusError{ZKP_ERR_BAD_HANDLE};
+  return it->second;
+}
+void bases_free(zkp_ctx* ctx, uint64_t handle) {
+  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->bases.erase(handle) == 0) throw StatusError{ZKP_ERR_BAD_HANDLE};
+}
+size_t bases_len(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->n; }
+int bases_group(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->group; }
+void msm_free_all(zkp_ctx* ctx) { ctx->bases.clear(); }
+
+// ------------------------------------------------------------------------------------------- K5 digit scan
+template <class FrP>
+__global__ __launch_bounds__(256) void digits_kernel(const uint32_t* __restrict__ scalars, size_t n, size_t offset,
+                                                     const uint8_t* __restrict__ inf, size_t ntab, int c, int W,
+                                                     uint32_t nb, uint32_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ vals, int montgomery) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp<FrP> s = Fp<FrP>::load(scalars + i * 8);
+  if (montgomery) s = s.from_mont();            // ark into_repr(), fused (prover.rs:150-161)
+  const bool skip = inf && inf[offset + i];
+  uint32_t carry = 0;
+  const uint32_t cmask = (1u << c) - 1;
+  for (int w = 0; w < W; w++) {
+    int bit = w * c;
+    int limb = bit >> 5, sh = bit & 31;
+    uint32_t d = 0;
+    if (limb < 8) {
+      uint64_t two = s.v[limb];
+      if (limb + 1 < 8) two |= (uint64_t)s.v[limb + 1] << 32;
+      d = (uint32_t)(two >> sh) & cmask;
+    }
+    d += carry;
+    uint32_t neg = 0;
+    if (d > nb) {
+      d = (1u << c) - d;
+      neg = 1;
+      carry = 1;
+    } else {
+      carry = 0;
+    }
+    uint32_t key = (d == 0 || skip) ? nb : d - 1;
+    uint32_t val = (uint32_t)((size_t)w * ntab + offset + i) | (neg << 31);
+    keys[(size_t)w * n + i] = key;
+    vals[(size_t)w * n + i] = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- bucket bounds
+__global__ void bounds_kernel(const uint32_t* __restrict__ keys, size_t E, uint32_t nb, uint32_t* __restrict__ start,
+                              uint32_t* __restrict__ end) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  uint32_t k = keys[e];
+  if (k >= nb) return;
+  if (e == 0 || keys[e - 1] != k) start[k] = (uint32_t)e;
+  if (e + 1 == E || keys[e + 1] != k) end[k] = (uint32_t)(e + 1);
+}
+
+
+void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
+             uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries) {
+  auto be = get_bases(ctx, handle);
+  const MsmVtbl* vt = be->vt;
+  hipStream_t st = ctx->stream;
+  const size_t XB = vt->xyzz_bytes;
+  const size_t jac_words = 3 * (size_t)vt->fN;
+  uint32_t* out_jac = ctx->msm_out.as<uint32_t>(64 * 4);
+  if (ms_accumulate) *ms_accumulate = 0.f;
+  if (n_entries) *n_entries = 0;
+  if (n == 0) {
+    vt->write_identity(st, (char*)out_dev_xyzz, out_jac);
+  } else {
+    const int c = be->c, W = be->W;
+    const uint32_t nb = 1u << (c - 1);
+    const size_t E = n * (size_t)W;
+    ZKP_REQUIRE(E < 2147483000ull, ZKP_ERR_BAD_ARG);
+    uint32_t* keys = ctx->msm_keys.as<uint32_t>(E);
+    uint32_t* vals = ctx->msm_vals.as<uint32_t>(E);
+    uint32_t* keys2 = ctx->msm_keys2.as<uint32_t>(E);
+    uint32_t* vals2 = ctx->msm_vals2.as<uint32_t>(E);
+    const uint32_t* sc = reinterpret_cast<const uint32_t*>(scalars_dev);
+    if (be->curve == ZKP_BN254)
+      hipLaunchKernelGGL(digits_kernel<Bn254Fr>, dim3((n + 255) / 256), dim3(256), 0, st, sc, n, offset, be->inf, be->n,
+                         c, W, nb, keys, vals, montgomery ? 1 : 0);
+    else
+      hipLaunchKernelGGL(digits_kernel<Bls381Fr>, dim3((n + 255) / 256), dim3(256), 0, st, sc, n, offset, be->inf,
+                         be->n, c, W, nb, keys, vals, montgomery ? 1 : 0);
+    // K6: sort (key bits 0..c; key nb == sentinel sorts last)
+    size_t tmp_bytes = 0;
+    ZKP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)E, 0, c, st));
+    void* tmp = ctx->msm_sort_tmp.get(tmp_bytes);
+    ZKP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)E, 0, c, st));
+    uint32_t* start = ctx->msm_offsets.as<uint32_t>(2 * (size_t)nb);
+    uint32_t* end = start + nb;
+    ZKP_HIP(hipMemsetAsync(start, 0, 2 * (size_t)nb * 4, st));
+    hipLaunchKernelGGL(bounds_kernel, dim3((E + 255) / 256), dim3(256), 0, st, keys2, E, nb, start, end);
+    // K7 — level l of the reduction pyramid lives at element offset lvl_off[l] of `buckets` (level 0 = buckets)
+    char* buckets = reinterpret_cast<char*>(ctx->msm_buckets.get((size_t)2 * nb * XB + XB));
+    const bool timed = ms_accumulate && ctx->profiling;
+    if (timed) ZKP_HIP(hipEventRecord(ctx->ev2, st));
+    vt->accumulate(st, be->table, vals2, start, end, nb, buckets);
+    if (timed) {
+      ZKP_HIP(hipEventRecord(ctx->ev3, st));
+      ZKP_HIP(hipEventSynchronize(ctx->ev3));
+      ZKP_HIP(hipEventElapsedTime(ms_accumulate, ctx->ev2, ctx->ev3));
+    }
+    if (n_entries) *n_entries = E;
+    // K8: pyramid
+    const int L = c - 1;                           // levels with odd entries: 0..L-1 ; root = level L
+    SegPlan plan{};
+    plan.L = L;
+    uint32_t lvl_off = 0, cnt = nb, blocks = 0;
+    for (int l = 0; l < L; l++) {
+      uint32_t next_off = lvl_off + cnt;
+      vt->pair(st, buckets + (size_t)lvl_off * XB, buckets + (size_t)next_off * XB, cnt / 2);
+      plan.first_block[l] = blocks;
+      plan.off[l] = lvl_off + 1;
+      plan.stride[l] = 2;
+      plan.count[l] = cnt / 2;
+      blocks += (cnt / 2 + SEG_CHUNK - 1) / SEG_CHUNK;
+      lvl_off = next_off;
+      cnt /= 2;
+    }
+    plan.first_block[L] = blocks;
+    const char* root = buckets + (size_t)lvl_off * XB;      // cnt == 1
+    char* partial = reinterpret_cast<char*>(ctx->msm_tmp.get(((size_t)blocks + 64) * XB));
+    char* Obuf = partial + (size_t)blocks * XB;
+    if (L > 0) {
+      vt->segsum(st, buckets, &plan, partial, blocks);
+      SegPlan p2{};
+      p2.L = L;
+      for (int l = 0; l < L; l++) {
+        p2.first_block[l] = l;
+        p2.off[l] = plan.first_block[l];
+        p2.stride[l] = 1;
+        p2.count[l] = plan.first_block[l + 1] - plan.first_block[l];
+        ZKP_REQUIRE(p2.count[l] <= (uint32_t)SEG_CHUNK, ZKP_ERR_BAD_ARG);
+      }
+      p2.first_block[L] = L;
+      vt->segsum(st, partial, &p2, Obuf, L);
+    }
+    vt->final(st, Obuf, L, root, (char*)out_dev_xyzz, out_jac);
+  }
+  ZKP_HIP(hipGetLastError());
+  if (out_xyz_host) {
+    ZKP_HIP(hipMemcpyAsync(out_xyz_host, out_jac, jac_words * 4, hipMemcpyDeviceToHost, st));
+    ZKP_HIP(hipStreamSynchronize(st));
+  }
+}
+
+void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz, size_t k, uint64_t* out) {
+  const MsmVtbl* vt = msm_vtbl(curve, group);
+  size_t words = 3 * (size_t)vt->fN;
+  uint32_t* d = ctx->msm_misc.as<uint32_t>((k + 1) * words);
+  if (k) ZKP_HIP(hipMemcpyAsync(d + words, xyz, k * words * 4, hipMemcpyHostToDevice, ctx->stream));
+  vt->fold(ctx->stream, d + words, (int)k, d);
+  ZKP_HIP(hipGetLastError());
+  ZKP_HIP(hipMemcpyAsync(out, d, words * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz, uint64_t* xy_out, uint8_t* inf_out) {
+  const MsmVtbl* vt = msm_vtbl(curve, group);
+  size_t jw = 3 * (size_t)vt->fN, aw = 2 * (size_t)vt->fN;
+  uint32_t* d = ctx->msm_misc.as<uint32_t>(jw + aw + 4);
+  ZKP_HIP(hipMemcpyAsync(d, xyz, jw * 4, hipMemcpyHostToDevice, ctx->stream));
+  vt->into_affine(ctx->stream, d, d + jw, d + jw + aw);
+  ZKP_HIP(hipGetLastError());
+  uint32_t flag = 0;
+  ZKP_HIP(hipMemcpyAsync(xy_out, d + jw, aw * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZKP_HIP(hipMemcpyAsync(&flag, d + jw + aw, 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  *inf_out = (uint8_t)flag;
+}
+
+void fixed_base_mul(zkp_ctx* ctx, int curve, int group, const uint64_t* base_xy, const uint64_t* scalars, size_t n,
+                    uint64_t* out_xy, uint8_t* out_inf) {
+  if (n == 0) return;
+  const MsmVtbl* vt = msm_vtbl(curve, group);
+  size_t ab = vt->aff_bytes;
+  char* buf = reinterpret_cast<char*>(ctx->msm_misc.get(ab + n * 32 + n * ab + n + 64));
+  char* d_base = buf;
+  char* d_sc = d_base + ab;
+  char* d_out = d_sc + n * 32;
+  uint8_t* d_inf = reinterpret_cast<uint8_t*>(d_out + n * ab);
+  ZKP_HIP(hipMemcpyAsync(d_base, base_xy, ab, hipMemcpyHostToDevice, ctx->stream));
+  ZKP_HIP(hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  vt->fixed_base(ctx->stream, reinterpret_cast<const uint32_t*>(d_base), reinterpret_cast<const uint32_t*>(d_sc), n,
+                 d_out, d_inf);
+  ZKP_HIP(hipGetLastError());
+  ZKP_HIP(hipMemcpyAsync(out_xy, d_out, n * ab, hipMemcpyDeviceToHost, ctx->stream));
+  ZKP_HIP(hipMemcpyAsync(out_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+}  // namespace zkp

@@ -1,0 +1,59 @@
+// K7 — bucket accumulation: the dominant kernel of the whole prover (>= 85 % of the field multiplications of
+// a Groth16 proof).  One lane owns one bucket: it walks the bucket's run of the sorted (bucket, point) list,
+// gathers the pre-multiplied affine base T[w][i] (64 B for BN254 G1; random access, served mostly from the
+// 256 MiB Infinity Cache / HBM), negates y for negative signed digits, and mixed-adds (madd-2008-s, 8M+2S)
+// into an XYZZ accumulator that stays in VGPRs for the whole run.  Buckets are written once, coalesced by
+// bucket index.  Compiled per configuration; the BN254 configurations inline the Montgomery multiplier.
+//
+// Replaces the bucket loop of ark-ec 0.2 `VariableBaseMSM::multi_scalar_mul`
+// (reference call sites: /root/reference/groth16/src/prover.rs:187,190,220).
+#include "ec.cuh"
+#include "msm_vtbl.hpp"
+
+namespace zkp {
+
+#if ZKP_CFG_CURVE == 0
+using CfgFq = Bn254Fq;
+#else
+using CfgFq = Bls381Fq;
+#endif
+#if ZKP_CFG_GROUP == 1
+using CfgF = Fp<CfgFq>;
+#else
+using CfgF = Fp2<CfgFq>;
+#endif
+#define ZKP_CAT3(a, b, c) a##b##c
+#define ZKP_SYM(name, cu, gr) ZKP_CAT3(name, cu, gr)
+#define ZKP_CFG_SYM(name) ZKP_SYM(name##_c, ZKP_CFG_CURVE, ZKP_CFG_GROUP)
+
+// non-template kernels get a per-configuration namespace (the same source is compiled four times)
+namespace ZKP_CFG_SYM(cfg) {}
+using namespace ZKP_CFG_SYM(cfg);
+
+namespace ZKP_CFG_SYM(cfg) {
+__global__ __launch_bounds__(256) void accumulate_kernel(const char* __restrict__ table,
+                                                         const uint32_t* __restrict__ vals,
+                                                         const uint32_t* __restrict__ start,
+                                                         const uint32_t* __restrict__ end, uint32_t nb,
+                                                         char* __restrict__ buckets) {
+  using F = CfgF;
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  uint32_t e0 = start[b], e1 = end[b];
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t e = e0; e < e1; e++) {
+    uint32_t v = vals[e];
+    Affine<F> p = Affine<F>::load(table + (size_t)(v & 0x7fffffffu) * Affine<F>::BYTES);
+    if (v >> 31) p.y = p.y.neg();
+    acc.madd(p);
+  }
+  acc.store(buckets + (size_t)b * XYZZ<F>::BYTES);
+}
+}  // namespace ZKP_CFG_SYM(cfg)
+
+void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint32_t* start,
+                                        const uint32_t* end, uint32_t nb, char* buckets) {
+  hipLaunchKernelGGL(accumulate_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, table, vals, start, end, nb, buckets);
+}
+
+}  // namespace zkp

@@ -1,0 +1,295 @@
+// Per-configuration MSM kernels (everything except the hot bucket-accumulate loop, which lives in
+// msm_acc.hip): table pre-computation, log-depth bucket reduction, point utilities, Groth16 assembly.
+// Compiled once per (curve, group): -DZKP_CFG_CURVE={0,1} -DZKP_CFG_GROUP={1,2}.  See msm.hip for the design.
+#include "ec.cuh"
+#include "msm_vtbl.hpp"
+
+#ifndef ZKP_CFG_CURVE
+#error "compile with -DZKP_CFG_CURVE=0|1 -DZKP_CFG_GROUP=1|2"
+#endif
+
+namespace zkp {
+
+#if ZKP_CFG_CURVE == 0
+using CfgFq = Bn254Fq;
+using CfgFr = Bn254Fr;
+constexpr int CFG_BITS = 254;
+#else
+using CfgFq = Bls381Fq;
+using CfgFr = Bls381Fr;
+constexpr int CFG_BITS = 255;
+#endif
+#if ZKP_CFG_GROUP == 1
+using CfgF = Fp<CfgFq>;
+#else
+using CfgF = Fp2<CfgFq>;
+#endif
+#define ZKP_CAT3(a, b, c) a##b##c
+#define ZKP_SYM(name, cu, gr) ZKP_CAT3(name, cu, gr)
+#define ZKP_CFG_SYM(name) ZKP_SYM(name##_c, ZKP_CFG_CURVE, ZKP_CFG_GROUP)
+
+// non-template kernels get a per-configuration namespace (the same source is compiled four times)
+namespace ZKP_CFG_SYM(cfg) {}
+using namespace ZKP_CFG_SYM(cfg);
+
+template <class F>
+__global__ void ingest_kernel(char* table, const uint8_t* inf, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (inf && inf[i]) Affine<F>::inf().store(table + i * Affine<F>::BYTES);
+}
+
+template <class F>
+__global__ __launch_bounds__(128) void precompute_kernel(char* table, size_t n, int c, int W) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p = Affine<F>::load(table + i * Affine<F>::BYTES);
+  XYZZ<F> acc = XYZZ<F>::from_affine(p);
+  for (int w = 1; w < W; w++) {
+    for (int k = 0; k < c; k++) acc = acc.dbl();
+    Affine<F> a = acc.to_affine();
+    a.store(table + ((size_t)w * n + i) * Affine<F>::BYTES);
+    acc = XYZZ<F>::from_affine(a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- K8 reduce
+template <class F>
+__global__ __launch_bounds__(256) void pair_kernel(const char* __restrict__ in, char* __restrict__ out,
+                                                   uint32_t count) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  XYZZ<F> a = XYZZ<F>::load(in + (size_t)(2 * k) * XYZZ<F>::BYTES);
+  a.add(XYZZ<F>::load(in + (size_t)(2 * k + 1) * XYZZ<F>::BYTES));
+  a.store(out + (size_t)k * XYZZ<F>::BYTES);
+}
+
+
+// block -> (segment l, chunk): sums <= SEG_CHUNK entries into partial[block]
+template <class F>
+__global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ base, SegPlan plan,
+                                                     char* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int l = 0;
+  while (l + 1 < plan.L && blockIdx.x >= plan.first_block[l + 1]) l++;
+  uint32_t chunk = blockIdx.x - plan.first_block[l];
+  uint32_t lo = chunk * SEG_CHUNK;
+  uint32_t hi = min(plan.count[l], lo + SEG_CHUNK);
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
+    acc.add(XYZZ<F>::load(base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * XYZZ<F>::BYTES));
+  // LDS tree
+  acc.store(smem + threadIdx.x * XYZZ<F>::BYTES);
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      XYZZ<F> o = XYZZ<F>::load(smem + (threadIdx.x + s) * XYZZ<F>::BYTES);
+      if (!o.is_inf() || !acc.is_inf()) {
+        acc.add(o);
+        acc.store(smem + threadIdx.x * XYZZ<F>::BYTES);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc.store(partial + (size_t)blockIdx.x * XYZZ<F>::BYTES);
+}
+
+// out = sum_l 2^l * O[l] + root ; one wave
+template <class F>
+__global__ __launch_bounds__(64) void final_kernel(const char* __restrict__ O, int L, const char* __restrict__ root,
+                                                   char* __restrict__ out_xyzz, uint32_t* __restrict__ out_jac) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int t = threadIdx.x;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  if (t < L) {
+    acc = XYZZ<F>::load(O + (size_t)t * XYZZ<F>::BYTES);
+    for (int k = 0; k < t; k++) acc = acc.dbl();
+  } else if (t == L) {
+    acc = XYZZ<F>::load(root);
+  }
+  acc.store(smem + t * XYZZ<F>::BYTES);
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (t < s) {
+      XYZZ<F> o = XYZZ<F>::load(smem + (t + s) * XYZZ<F>::BYTES);
+      if (!o.is_inf() || !acc.is_inf()) {
+        acc.add(o);
+        acc.store(smem + t * XYZZ<F>::BYTES);
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (out_xyzz) acc.store(out_xyzz);
+    if (out_jac) acc.store_jacobian(out_jac);
+  }
+}
+
+template <class F>
+__global__ void write_identity_kernel(char* out_xyzz, uint32_t* out_jac) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    XYZZ<F> z = XYZZ<F>::inf();
+    if (out_xyzz) z.store(out_xyzz);
+    if (out_jac) z.store_jacobian(out_jac);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- small point utilities
+template <class F>
+__device__ XYZZ<F> jac_to_xyzz(const uint32_t* p) {
+  F X = F::load(p), Y = F::load(p + F::N), Z = F::load(p + 2 * F::N);
+  if (Z.is_zero()) return XYZZ<F>::inf();
+  F zz = Z.sqr();
+  return {X, Y, zz, zz * Z};
+}
+
+template <class F>
+__global__ void fold_kernel(const uint32_t* pts, int k, uint32_t* out_jac) {
+  if (threadIdx.x || blockIdx.x) return;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int i = 0; i < k; i++) acc.add(jac_to_xyzz<F>(pts + (size_t)i * 3 * F::N));
+  acc.store_jacobian(out_jac);
+}
+
+template <class F>
+__global__ void into_affine_kernel(const uint32_t* jac, uint32_t* xy, uint32_t* inf) {
+  if (threadIdx.x || blockIdx.x) return;
+  XYZZ<F> p = jac_to_xyzz<F>(jac);
+  Affine<F> a = p.to_affine();
+  a.store(xy);
+  *inf = p.is_inf() ? 1 : 0;
+}
+
+// k_i * P, one lane per scalar (setup-side helper; double-and-add, MSB first)
+template <class F, int BITS>
+__global__ __launch_bounds__(128) void fixed_base_kernel(const uint32_t* base, const uint32_t* scalars, size_t n,
+                                                         char* out_xy, uint8_t* out_inf) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p = Affine<F>::load(base);
+  uint32_t s[8];
+#pragma unroll
+  for (int l = 0; l < 8; l++) s[l] = scalars[i * 8 + l];
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int bit = BITS; bit >= 0; bit--) {
+    acc = acc.dbl();
+    if ((s[bit >> 5] >> (bit & 31)) & 1) acc.madd(p);
+  }
+  Affine<F> a = acc.to_affine();
+  a.store(out_xy + i * Affine<F>::BYTES);
+  out_inf[i] = acc.is_inf() ? 1 : 0;
+}
+
+
+// ------------------------------------------------------------------------------------------- Groth16 assembly
+// (prover.rs:192-210 after the folding described in groth16.hip)
+namespace ZKP_CFG_SYM(cfg) {
+#if ZKP_CFG_GROUP == 1
+// lanes 0/1: s*g_a and r*g1_b (double-and-add on the affine-normalised point); lane 0 then sums C.
+__global__ __launch_bounds__(64) void assemble_g1_kernel(const char* __restrict__ res, size_t slot,
+                                                         const uint32_t* __restrict__ rs, uint32_t* __restrict__ out,
+                                                         uint32_t* __restrict__ flags, int c_off_words) {
+  using F = CfgF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  if (t < 2) {
+    // t = 0: g_a (slot 0) times s ; t = 1: g1_b (slot 1) times r
+    XYZZ<F> p = XYZZ<F>::load(res + (size_t)t * slot);
+    Affine<F> a = p.to_affine();
+    if (t == 0) {
+      a.store(out);                              // proof.a
+      flags[0] = p.is_inf() ? 1 : 0;
+    }
+    Fp<CfgFr> k = Fp<CfgFr>::load(rs + (t == 0 ? 8 : 0)).from_mont();
+    for (int bit = CFG_BITS; bit >= 0; bit--) {
+      acc = acc.dbl();
+      if ((k.v[bit >> 5] >> (bit & 31)) & 1) acc.madd(a);
+    }
+  }
+  acc.store(smem + t * XYZZ<F>::BYTES);
+  __syncthreads();
+  if (t == 0) {
+    acc.add(XYZZ<F>::load(smem + XYZZ<F>::BYTES));
+    acc.add(XYZZ<F>::load(res + 3 * slot));      // h_acc
+    acc.add(XYZZ<F>::load(res + 4 * slot));      // l' (includes -rs*delta)
+    Affine<F> c = acc.to_affine();
+    c.store(out + c_off_words);
+    flags[2] = acc.is_inf() ? 1 : 0;
+  }
+}
+#else
+__global__ __launch_bounds__(64) void assemble_g2_kernel(const char* __restrict__ res, size_t slot,
+                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ flags,
+                                                         int out_off_words) {
+  if (threadIdx.x || blockIdx.x) return;
+  XYZZ<CfgF> p = XYZZ<CfgF>::load(res + 2 * slot);
+  p.to_affine().store(out + out_off_words);
+  flags[1] = p.is_inf() ? 1 : 0;
+}
+#endif
+}  // namespace ZKP_CFG_SYM(cfg)
+
+// ------------------------------------------------------------------------------------------- launch table
+void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t, const char*, const uint32_t*, const uint32_t*, const uint32_t*,
+                                        uint32_t, char*);   // msm_acc.hip
+
+namespace {
+using F = CfgF;
+constexpr size_t XB = XYZZ<F>::BYTES;
+void l_ingest(hipStream_t s, char* table, const uint8_t* inf, size_t n) {
+  hipLaunchKernelGGL(ingest_kernel<F>, dim3((n + 255) / 256), dim3(256), 0, s, table, inf, n);
+}
+void l_precompute(hipStream_t s, char* table, size_t n, int c, int W) {
+  hipLaunchKernelGGL(precompute_kernel<F>, dim3((n + 127) / 128), dim3(128), 0, s, table, n, c, W);
+}
+void l_pair(hipStream_t s, const char* in, char* out, uint32_t count) {
+  hipLaunchKernelGGL(pair_kernel<F>, dim3((count + 255) / 256), dim3(256), 0, s, in, out, count);
+}
+void l_segsum(hipStream_t s, const char* base, const SegPlan* plan, char* partial, uint32_t blocks) {
+  hipLaunchKernelGGL(segsum_kernel<F>, dim3(blocks), dim3(256), 256 * XB, s, base, *plan, partial);
+}
+void l_final(hipStream_t s, const char* O, int L, const char* root, char* out_xyzz, uint32_t* out_jac) {
+  hipLaunchKernelGGL(final_kernel<F>, dim3(1), dim3(64), 64 * XB, s, O, L, root, out_xyzz, out_jac);
+}
+void l_identity(hipStream_t s, char* out_xyzz, uint32_t* out_jac) {
+  hipLaunchKernelGGL(write_identity_kernel<F>, dim3(1), dim3(64), 0, s, out_xyzz, out_jac);
+}
+void l_fold(hipStream_t s, const uint32_t* pts, int k, uint32_t* out_jac) {
+  hipLaunchKernelGGL(fold_kernel<F>, dim3(1), dim3(64), 0, s, pts, k, out_jac);
+}
+void l_into_affine(hipStream_t s, const uint32_t* jac, uint32_t* xy, uint32_t* inf) {
+  hipLaunchKernelGGL(into_affine_kernel<F>, dim3(1), dim3(64), 0, s, jac, xy, inf);
+}
+void l_fixed_base(hipStream_t s, const uint32_t* base, const uint32_t* scalars, size_t n, char* out_xy,
+                  uint8_t* out_inf) {
+  hipLaunchKernelGGL((fixed_base_kernel<F, CFG_BITS>), dim3((n + 127) / 128), dim3(128), 0, s, base, scalars, n,
+                     out_xy, out_inf);
+}
+#if ZKP_CFG_GROUP == 1
+void l_assemble_g1(hipStream_t s, const char* res, size_t slot, const uint32_t* rs, uint32_t* out, uint32_t* flags,
+                   int c_off_words) {
+  hipLaunchKernelGGL(assemble_g1_kernel, dim3(1), dim3(64), 64 * XB, s, res, slot, rs, out, flags, c_off_words);
+}
+#else
+void l_assemble_g2(hipStream_t s, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int off) {
+  hipLaunchKernelGGL(assemble_g2_kernel, dim3(1), dim3(64), 0, s, res, slot, out, flags, off);
+}
+#endif
+}  // namespace
+
+const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
+  static const MsmVtbl v = {
+      F::N, Affine<F>::BYTES, XYZZ<F>::BYTES, CFG_BITS,
+      l_ingest, l_precompute, ZKP_CFG_SYM(msm_accumulate_launch), l_pair, l_segsum, l_final, l_identity, l_fold,
+      l_into_affine, l_fixed_base,
+#if ZKP_CFG_GROUP == 1
+      l_assemble_g1, nullptr,
+#else
+      nullptr, l_assemble_g2,
+#endif
+  };
+  return &v;
+}
+
+}  // namespace zkp

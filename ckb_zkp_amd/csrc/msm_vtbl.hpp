@@ -1,0 +1,44 @@
+// Per-(curve, group) kernel launch table.  Each configuration is compiled in its own translation unit
+// (msm_group.hip / msm_acc.hip with -DZKP_CFG_CURVE=.. -DZKP_CFG_GROUP=..) so the four configurations build in
+// parallel and the hot accumulate kernel can be rebuilt alone.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace zkp {
+
+constexpr int SEG_CHUNK = 1024;
+struct SegPlan {
+  int L;                       // number of segments
+  uint32_t first_block[26];    // blocks of segment l: first_block[l] .. first_block[l+1]
+  uint32_t off[25];            // element offset of segment l's first entry
+  uint32_t stride[25];         // element stride
+  uint32_t count[25];          // entries in segment l
+};
+
+struct MsmVtbl {
+  int fN;                      // 32-bit words per coordinate (8 / 16 / 12 / 24)
+  size_t aff_bytes, xyzz_bytes;
+  int scalar_bits;
+  void (*ingest)(hipStream_t, char* table, const uint8_t* inf, size_t n);
+  void (*precompute)(hipStream_t, char* table, size_t n, int c, int W);
+  void (*accumulate)(hipStream_t, const char* table, const uint32_t* vals, const uint32_t* start, const uint32_t* end,
+                     uint32_t nb, char* buckets);
+  void (*pair)(hipStream_t, const char* in, char* out, uint32_t count);
+  void (*segsum)(hipStream_t, const char* base, const SegPlan* plan, char* partial, uint32_t blocks);
+  void (*final)(hipStream_t, const char* O, int L, const char* root, char* out_xyzz, uint32_t* out_jac);
+  void (*write_identity)(hipStream_t, char* out_xyzz, uint32_t* out_jac);
+  void (*fold)(hipStream_t, const uint32_t* pts, int k, uint32_t* out_jac);
+  void (*into_affine)(hipStream_t, const uint32_t* jac, uint32_t* xy, uint32_t* inf);
+  void (*fixed_base)(hipStream_t, const uint32_t* base, const uint32_t* scalars, size_t n, char* out_xy,
+                     uint8_t* out_inf);
+  // Groth16 assembly (groth16.hip): G1 tables implement assemble_g1, G2 tables assemble_g2
+  void (*assemble_g1)(hipStream_t, const char* res, size_t slot, const uint32_t* rs, uint32_t* out, uint32_t* flags,
+                      int c_off_words);
+  void (*assemble_g2)(hipStream_t, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int out_off_words);
+};
+
+const MsmVtbl* msm_vtbl(int curve, int group);     // msm.hip; throws StatusError on unknown config
+
+}  // namespace zkp

@@ -1,0 +1,333 @@
+// Radix-2 NTT over Fr for gfx950: multi-pass Stockham (autosort) with LDS tiles.
+//
+// Replaces ark-poly 0.2 `GeneralEvaluationDomain::<Fr>::{fft,ifft,coset_fft,coset_ifft}_in_place`
+// (call sites: /root/reference/groth16/src/r1cs_to_qap.rs:144-148,161-162,169 and every
+// interpolate/fft/evaluate_over_domain in /root/reference/marlin/src/ahp/prover.rs).
+// Contract: natural order in, natural order out, out[i] = sum_j in[j] w^(ij); inverse uses w^-1 and
+// multiplies by 1/N; coset_fft scales coefficient j by g^j first, coset_ifft scales by g^-j last.
+//
+// Decomposition (derived in DESIGN.md §NTT): log N = S_1 + ... + S_P, S_p <= 7.  State before pass p is
+// "B interleaved sub-transforms of size M" (B*M = N, B = 2^(S_1+..+S_{p-1})):  in[b + B*j].
+// Pass p with R = 2^S:   j = j1*(M/R) + j',   k = k1 + R*k'
+//     Y_b[k1][j'] = w_M^(j' k1) * sum_{j1} in[b + B*(j1*(M/R) + j')] * w_R^(j1 k1)
+// stored at  b + B*k1 + B*R*j'   (new batch index b + B*k1, new B' = B*R).  Reads are runs of C
+// consecutive elements (the element index b + B*j' is a *contiguous* range [0, N/R) for every j1),
+// writes are runs of >= min(C, B) consecutive elements -> every pass is coalesced in both directions and
+// the last pass lands in natural order: no bit-reversal pass, no transposes.
+//
+// One workgroup = one LDS tile of R rows x C columns (R*C = 1024 elements, 32 KiB, limb-major SoA so that
+// ds_read/ds_write_b32 of consecutive columns hit consecutive banks).  The R-point column transforms are
+// S radix-2 DIF stages in LDS with the w_R twiddle tile in LDS; the inter-pass twiddle w_N^(B j' k1) comes
+// from a two-level table (w^lo, w^(hi<<h)), both L2-resident (<= 256 KiB at 2^24).
+//
+// Arithmetic is 256-bit Montgomery on the integer VALU (v_mad_u64_u32); there is no MFMA in this path.
+#include <algorithm>
+
+#include "ctx.hpp"
+#include "field.cuh"
+
+namespace zkp {
+
+constexpr int NTT_SMAX = 7;            // max radix bits per pass
+constexpr int NTT_TILE_LOG = 10;       // elements per LDS tile (1024 * 32 B = 32 KiB)
+constexpr int NTT_THREADS = 256;
+constexpr int NTT_SUB_LOG = 7;         // sub-FFT twiddle table covers R <= 2^7
+
+// ------------------------------------------------------------------------------------------- tables
+template <class P>
+__global__ void ntt_setup_kernel(uint32_t* consts, int log_n, int h) {
+  // consts[k*8..]: 0 w, 1 w^-1, 2 w^(2^h), 3 w^-(2^h), 4 g^(2^h), 5 g^-(2^h), 6 1/N, 7 w_sub, 8 w_sub^-1
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  using F = Fp<P>;
+  F w, wi, g, gi;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    w.v[i] = P::ROOT[i];
+    wi.v[i] = P::ROOT_INV[i];
+    g.v[i] = P::GEN[i];
+    gi.v[i] = P::GEN_INV[i];
+  }
+  F wsub = w, wsubi = wi;
+  for (int i = 0; i < P::TWO_ADICITY - log_n; i++) {
+    w = w.sqr();
+    wi = wi.sqr();
+  }
+  int sub = log_n < NTT_SUB_LOG ? log_n : NTT_SUB_LOG;
+  for (int i = 0; i < P::TWO_ADICITY - sub; i++) {
+    wsub = wsub.sqr();
+    wsubi = wsubi.sqr();
+  }
+  F wh = w, wih = wi, gh = g, gih = gi;
+  for (int i = 0; i < h; i++) {
+    wh = wh.sqr();
+    wih = wih.sqr();
+    gh = gh.sqr();
+    gih = gih.sqr();
+  }
+  F n = F::zero();
+  n.v[log_n / 32] = 1u << (log_n % 32);
+  F ninv = n.to_mont().inv();
+  w.store(consts + 0 * 8);
+  wi.store(consts + 1 * 8);
+  wh.store(consts + 2 * 8);
+  wih.store(consts + 3 * 8);
+  gh.store(consts + 4 * 8);
+  gih.store(consts + 5 * 8);
+  ninv.store(consts + 6 * 8);
+  wsub.store(consts + 7 * 8);
+  wsubi.store(consts + 8 * 8);
+  g.store(consts + 9 * 8);
+  gi.store(consts + 10 * 8);
+}
+
+// out[i] = base^i * (mult ? *mult : 1)
+template <class P>
+__global__ void pow_table_kernel(uint32_t* out, const uint32_t* base, const uint32_t* mult, uint32_t count) {
+  using F = Fp<P>;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  F b = F::load(base);
+  F r = b.pow_u64(i);
+  if (mult) r = r * F::load(mult);
+  r.store(out + (size_t)i * 8);
+}
+
+template <class P>
+static NttTables& get_tables(zkp_ctx* ctx, int curve, int log_n) {
+  auto key = std::make_pair(curve, log_n);
+  auto it = ctx->ntt_tables.find(key);
+  if (it != ctx->ntt_tables.end()) return it->second;
+  NttTables t;
+  t.log_n = log_n;
+  t.h = (log_n + 1) / 2;
+  size_t lo = (size_t)1 << t.h, hi = (size_t)1 << (log_n - t.h);
+  int sub = std::min(log_n, NTT_SUB_LOG);
+  size_t subn = sub > 0 ? ((size_t)1 << sub) / 2 : 1;
+  if (subn == 0) subn = 1;
+  size_t words = (4 * (lo + hi) + 2 * subn + 16) * 8;
+  uint32_t* blk;
+  if (hipMalloc(&blk, words * 4) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+  t.block = blk;
+  uint32_t* p = blk;
+  uint32_t* consts = p; p += 16 * 8;
+  t.w_lo = p; p += lo * 8;
+  t.w_hi = p; p += hi * 8;
+  t.wi_lo = p; p += lo * 8;
+  t.wi_hi = p; p += hi * 8;
+  t.g_lo = p; p += lo * 8;
+  t.g_hi = p; p += hi * 8;
+  t.gi_lo = p; p += lo * 8;
+  t.gi_hi = p; p += hi * 8;
+  t.sub_fwd = p; p += subn * 8;
+  t.sub_inv = p; p += subn * 8;
+  t.n_inv = consts + 6 * 8;
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(ntt_setup_kernel<P>, dim3(1), dim3(64), 0, s, consts, log_n, t.h);
+  auto gen = [&](uint32_t* out, uint32_t* base, uint32_t* mult, size_t cnt) {
+    hipLaunchKernelGGL(pow_table_kernel<P>, dim3((cnt + 255) / 256), dim3(256), 0, s, out, base, mult, (uint32_t)cnt);
+  };
+  gen(t.w_lo, consts + 0 * 8, nullptr, lo);
+  gen(t.w_hi, consts + 2 * 8, nullptr, hi);
+  gen(t.wi_lo, consts + 1 * 8, nullptr, lo);
+  gen(t.wi_hi, consts + 3 * 8, nullptr, hi);
+  gen(t.g_lo, consts + 9 * 8, nullptr, lo);
+  gen(t.g_hi, consts + 4 * 8, nullptr, hi);
+  gen(t.gi_lo, consts + 10 * 8, nullptr, lo);
+  gen(t.gi_hi, consts + 5 * 8, consts + 6 * 8, hi);   // g^-(i<<h) / N
+  gen(t.sub_fwd, consts + 7 * 8, nullptr, subn);
+  gen(t.sub_inv, consts + 8 * 8, nullptr, subn);
+  ZKP_HIP(hipGetLastError());
+  ctx->ntt_tables[key] = t;
+  return ctx->ntt_tables[key];
+}
+
+// ------------------------------------------------------------------------------------------- pass
+struct NttPassArgs {
+  int log_n, S, logB, logC, sub_log;
+  int last;                 // M == R: no inter-pass twiddle
+  int h;
+  const uint32_t* tw_sub;   // w_Rsub^k (Rsub = 2^sub_log), k < Rsub/2
+  const uint32_t* tw_lo;    // two-level w_N
+  const uint32_t* tw_hi;
+  const uint32_t* pre_lo;   // optional: multiply input j by pre_hi[j>>h]*pre_lo[j&mask]
+  const uint32_t* pre_hi;
+  const uint32_t* post_lo;  // optional: multiply output k likewise
+  const uint32_t* post_hi;
+  const uint32_t* post_const;  // optional: multiply every output by a constant (1/N)
+};
+
+template <class P>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* __restrict__ in,
+                                                               uint32_t* __restrict__ out, NttPassArgs a) {
+  using F = Fp<P>;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int S = a.S, logC = a.logC;
+  const int R = 1 << S, C = 1 << logC;
+  const int TILE = R << logC;
+  uint32_t* tw_l = lds + 8 * TILE;                 // R/2 twiddles, AoS (broadcast reads)
+  const uint32_t ncols = 1u << (a.log_n - S);
+  const uint32_t c0 = blockIdx.x << logC;
+  const int tid = threadIdx.x;
+  const uint32_t hmask = (1u << a.h) - 1;
+
+  // sub-FFT twiddle tile -> LDS
+  {
+    const int shift = a.sub_log - S;               // w_R^k = w_Rsub^(k << shift)
+    for (int k = tid; k < (R >> 1) * 8; k += NTT_THREADS) {
+      int e = k >> 3, l = k & 7;
+      tw_l[k] = a.tw_sub[((size_t)(e << shift)) * 8 + l];
+    }
+  }
+  // load tile (coalesced runs of C elements), optional coset pre-scale
+  for (int e = tid; e < TILE; e += NTT_THREADS) {
+    uint32_t j1 = e >> logC, cc = e & (C - 1);
+    uint32_t gidx = j1 * ncols + c0 + cc;
+    F x = F::load(in + (size_t)gidx * 8);
+    if (a.pre_lo) {
+      F s = F::load(a.pre_hi + (size_t)(gidx >> a.h) * 8) * F::load(a.pre_lo + (size_t)(gidx & hmask) * 8);
+      x = x * s;
+    }
+#pragma unroll
+    for (int l = 0; l < 8; l++) lds[l * TILE + e] = x.v[l];
+  }
+  // S radix-2 DIF stages over rows
+  for (int s = 0; s < S; s++) {
+    __syncthreads();
+    const int half = R >> (s + 1);
+    for (int bf = tid; bf < (TILE >> 1); bf += NTT_THREADS) {
+      int cc = bf & (C - 1);
+      int u = bf >> logC;
+      int pos = u & (half - 1);
+      int grp = u >> (S - 1 - s);
+      int p0 = (((grp * 2 * half) + pos) << logC) + cc;
+      int p1 = p0 + (half << logC);
+      F x0, x1, tw;
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        x0.v[l] = lds[l * TILE + p0];
+        x1.v[l] = lds[l * TILE + p1];
+        tw.v[l] = tw_l[((pos << s) << 3) + l];
+      }
+      F y0 = x0 + x1;
+      F y1 = (x0 - x1) * tw;
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        lds[l * TILE + p0] = y0.v[l];
+        lds[l * TILE + p1] = y1.v[l];
+      }
+    }
+  }
+  __syncthreads();
+  // store: rows come out bit-reversed in LDS; enumerate outputs in global-address order
+  const int logB = a.logB;
+  const int logBc = logB < logC ? logB : logC;
+  for (int o = tid; o < TILE; o += NTT_THREADS) {
+    uint32_t bb = o & ((1u << logBc) - 1);
+    uint32_t k1 = (o >> logBc) & (R - 1);
+    uint32_t jj = o >> (logBc + S);
+    uint32_t cc = bb + (jj << logBc);
+    uint32_t c = c0 + cc;
+    uint32_t b = c & ((1u << logB) - 1);
+    uint32_t bj = c - b;                              // B * j'
+    uint32_t oidx = b + (k1 << logB) + (bj << S);
+    uint32_t row = S ? (__brev(k1) >> (32 - S)) : 0;
+    int pos = (row << logC) + cc;
+    F x;
+#pragma unroll
+    for (int l = 0; l < 8; l++) x.v[l] = lds[l * TILE + pos];
+    if (!a.last) {
+      uint32_t e = bj * k1;                           // < N
+      if (e) {
+        F t = F::load(a.tw_hi + (size_t)(e >> a.h) * 8) * F::load(a.tw_lo + (size_t)(e & hmask) * 8);
+        x = x * t;
+      }
+    }
+    if (a.post_lo) {
+      F t = F::load(a.post_hi + (size_t)(oidx >> a.h) * 8) * F::load(a.post_lo + (size_t)(oidx & hmask) * 8);
+      x = x * t;
+    } else if (a.post_const) {
+      x = x * F::load(a.post_const);
+    }
+    x.store(out + (size_t)oidx * 8);
+  }
+}
+
+static void ntt_plan(int log_n, int* S, int* P) {
+  if (log_n == 0) {
+    *P = 0;
+    return;
+  }
+  int p = (log_n + NTT_SMAX - 1) / NTT_SMAX;
+  int base = log_n / p, rem = log_n % p;
+  for (int i = 0; i < p; i++) S[i] = base + (i < rem ? 1 : 0);
+  *P = p;
+}
+
+// data: N elements (device).  In place from the caller's view; uses ctx->ntt_scratch.
+template <class P>
+void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* data, int log_n, int op) {
+  ZKP_REQUIRE(log_n <= P::TWO_ADICITY, ZKP_ERR_DOMAIN_TOO_LARGE);
+  if (log_n == 0) return;  // size-1 transform is the identity (coset scale by g^0, 1/N = 1)
+  NttTables& t = get_tables<P>(ctx, curve, log_n);
+  const size_t N = (size_t)1 << log_n;
+  uint32_t* scratch = ctx->ntt_scratch.as<uint32_t>(N * 8);
+  int S[8], np;
+  ntt_plan(log_n, S, &np);
+  const bool inverse = (op == ZKP_NTT_IFFT || op == ZKP_NTT_COSET_IFFT);
+  // buffers alternate; pass p (0-based) writes dst if (np-1-p) even else scratch; in-place + odd np -> copy
+  const bool odd = (np & 1);
+  uint32_t* cur = data;
+  int logB = 0;
+  for (int p = 0; p < np; p++) {
+    uint32_t* dst;
+    if (!odd) dst = ((np - 1 - p) & 1) ? scratch : data;
+    else dst = (p & 1) ? data : scratch;              // ends in scratch
+    NttPassArgs a{};
+    a.log_n = log_n;
+    a.S = S[p];
+    a.logB = logB;
+    int logC = std::min(NTT_TILE_LOG - S[p], log_n - S[p]);
+    a.logC = logC;
+    a.sub_log = std::min(log_n, NTT_SUB_LOG);
+    a.last = (p == np - 1);
+    a.h = t.h;
+    a.tw_sub = inverse ? t.sub_inv : t.sub_fwd;
+    a.tw_lo = inverse ? t.wi_lo : t.w_lo;
+    a.tw_hi = inverse ? t.wi_hi : t.w_hi;
+    if (p == 0 && op == ZKP_NTT_COSET_FFT) {
+      a.pre_lo = t.g_lo;
+      a.pre_hi = t.g_hi;
+    }
+    if (p == np - 1) {
+      if (op == ZKP_NTT_COSET_IFFT) {
+        a.post_lo = t.gi_lo;
+        a.post_hi = t.gi_hi;                          // includes 1/N
+      } else if (op == ZKP_NTT_IFFT) {
+        a.post_const = t.n_inv;
+      }
+    }
+    const int tile = 1 << (S[p] + logC);
+    const size_t lds_bytes = (size_t)tile * 32 + ((size_t)1 << S[p]) / 2 * 32 + 32;
+    const uint32_t grid = (uint32_t)(N >> (S[p] + logC));
+    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid), dim3(NTT_THREADS), lds_bytes, ctx->stream, cur, dst, a);
+    cur = dst;
+    logB += S[p];
+  }
+  ZKP_HIP(hipGetLastError());
+  if (cur != data) ZKP_HIP(hipMemcpyAsync(data, cur, N * 32, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+void ntt_run(zkp_ctx* ctx, int curve, uint32_t* data, int log_n, int op) {
+  ZKP_REQUIRE(op >= 0 && op <= 3, ZKP_ERR_BAD_ARG);
+  if (curve == ZKP_BN254) ntt_run_t<Bn254Fr>(ctx, curve, data, log_n, op);
+  else if (curve == ZKP_BLS12_381) ntt_run_t<Bls381Fr>(ctx, curve, data, log_n, op);
+  else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+}
+
+void ntt_free_tables(zkp_ctx* ctx) {
+  for (auto& kv : ctx->ntt_tables)
+    if (kv.second.block) (void)hipFree(kv.second.block);
+  ctx->ntt_tables.clear();
+}
+
+}  // namespace zkp

@@ -1,0 +1,259 @@
+"""Host-side mirror of the reference's Groth16 prover interface, running on the MI355X backend.
+
+Mirrors /root/reference/groth16/src/lib.rs:39-91 (`Parameters`, `Proof`, `create_random_proof`) and
+/root/reference/groth16/src/prover.rs:97-211 (`create_random_proof`, `create_proof`, `create_proof_no_zk`).
+Setup (`generate_parameters`, /root/reference/groth16/src/generator.rs:135-286) is NOT part of the hot path;
+it is provided with an explicit trapdoor so that synthetic keys of 2^20+ constraints can be produced on the
+GPU (zkp_fixed_base_mul_*) for the parity tests and the benchmark.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import secrets
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .api import Context, _ptr
+from .codec import fr_canonical, fr_to_mont, g1_from_mont, g1_to_mont, g2_from_mont, g2_to_mont, ints_to_limbs
+from .params import CurveParams, get_curve
+from .r1cs import ConstraintSystem, PolynomialDegreeTooLarge, R1csInstance
+
+
+@dataclass
+class Proof:
+    """groth16/src/lib.rs:52-57 — affine points as canonical integers; None = identity."""
+    a: tuple
+    b: tuple
+    c: tuple
+
+
+@dataclass
+class Parameters:
+    """groth16/src/lib.rs:79-91 in ABI layout (Montgomery limbs + identity flags)."""
+    curve: CurveParams
+    num_inputs: int
+    num_aux: int
+    num_constraints: int
+    alpha_g1: np.ndarray
+    beta_g1: np.ndarray
+    beta_g2: np.ndarray
+    gamma_g2: np.ndarray
+    delta_g1: np.ndarray
+    delta_g2: np.ndarray
+    gamma_abc_g1: tuple            # (xy, inf)
+    a_query: tuple
+    b_g1_query: tuple
+    b_g2_query: tuple
+    h_query: tuple
+    l_query: tuple
+    toxic: dict = field(default_factory=dict)   # trapdoor exponents (test keys only)
+
+
+def _domain_log(c: CurveParams, n: int) -> int:
+    lg = max(n - 1, 0).bit_length()
+    if lg > c.two_adicity:
+        raise PolynomialDegreeTooLarge()      # r1cs_to_qap.rs:123-125
+    return lg
+
+
+def _as_instance(curve, circuit, assign: bool) -> R1csInstance:
+    if isinstance(circuit, R1csInstance):
+        return circuit
+    cs = ConstraintSystem(curve, assign)
+    circuit.generate_constraints(cs)
+    return R1csInstance.from_cs(cs)
+
+
+def qap_exponents(inst: R1csInstance, tau: int):
+    """R1CStoQAP::instance_map_with_evaluation (r1cs_to_qap.rs:58-110): a_i(tau), b_i(tau), c_i(tau), Z(tau)."""
+    c = inst.curve
+    r = c.r
+    nc, ni = inst.num_constraints(), inst.num_inputs
+    lg = _domain_log(c, nc + (ni - 1) + 1)
+    N = 1 << lg
+    w = pow(pow(c.fr_generator, (r - 1) >> c.two_adicity, r), 1 << (c.two_adicity - lg), r)
+    zt = (pow(tau, N, r) - 1) % r
+    # Lagrange coefficients u_i = Z(tau) w^i / (N (tau - w^i)), batch inversion
+    els, p = [], 1
+    for _ in range(N):
+        els.append(p)
+        p = p * w % r
+    if zt == 0:
+        u = [1 if e == tau % r else 0 for e in els]
+    else:
+        den = [(tau - e) % r for e in els]
+        pref, acc = [], 1
+        for d in den:
+            pref.append(acc)
+            acc = acc * d % r
+        inv = pow(acc, -1, r)
+        zn = zt * pow(N, -1, r) % r
+        u = [0] * N
+        for i in range(N - 1, -1, -1):
+            u[i] = zn * els[i] % r * (inv * pref[i] % r) % r
+            inv = inv * den[i] % r
+    nvars = (ni - 1) + inst.num_aux
+    Ri = pow(1 << (64 * c.fr_limbs), -1, r)
+    out = []
+    for which in "abc":
+        row_ptr, col, coeff = inst.csr(which)
+        from .codec import limbs_to_ints
+        cf = [x * Ri % r for x in limbs_to_ints(coeff)] if len(col) else []
+        acc = [0] * (nvars + 1)
+        rp = row_ptr.tolist()
+        cl = col.tolist()
+        for i in range(nc):
+            ui = u[i]
+            for k in range(rp[i], rp[i + 1]):
+                acc[cl[k]] = (acc[cl[k]] + ui * cf[k]) % r
+        out.append(acc)
+    a, b, cc = out
+    for i in range(ni):
+        a[i] = (a[i] + u[nc + i]) % r
+    return a, b, cc, zt, N
+
+
+def generate_parameters(ctx: Context, curve, circuit, alpha: int, beta: int, gamma: int, delta: int, tau: int,
+                        g1_k: int = 1, g2_k: int = 1) -> Parameters:
+    """generator.rs:135-286 with the toxic waste (and the generator multiples) as explicit inputs."""
+    c = get_curve(curve)
+    r = c.r
+    inst = _as_instance(c, circuit, assign=False)
+    a, b, cc, zt, N = qap_exponents(inst, tau)
+    ni = inst.num_inputs
+    gi, di = pow(gamma, -1, r), pow(delta, -1, r)
+    gamma_abc = [(beta * a[i] + alpha * b[i] + cc[i]) * gi % r for i in range(ni)]
+    l = [(beta * x + alpha * y + z) * di % r for x, y, z in zip(a, b, cc)]
+    h, p, zd = [], 1, zt * di % r
+    for _ in range(N - 1):
+        h.append(zd * p % r)
+        p = p * tau % r
+    g1_base, _ = g1_to_mont([c.g1], c)
+    g2_base, _ = g2_to_mont([c.g2], c)
+
+    def mul1(ks):
+        return ctx.fixed_base_mul(c, 1, g1_base, fr_canonical([k * g1_k % r for k in ks], c))
+
+    def mul2(ks):
+        return ctx.fixed_base_mul(c, 2, g2_base, fr_canonical([k * g2_k % r for k in ks], c))
+
+    singles1, _ = mul1([alpha, beta, delta])
+    singles2, _ = mul2([beta, gamma, delta])
+    return Parameters(
+        curve=c, num_inputs=ni, num_aux=inst.num_aux, num_constraints=inst.num_constraints(),
+        alpha_g1=singles1[0], beta_g1=singles1[1], delta_g1=singles1[2],
+        beta_g2=singles2[0], gamma_g2=singles2[1], delta_g2=singles2[2],
+        gamma_abc_g1=mul1(gamma_abc), a_query=mul1(a), b_g1_query=mul1(b), b_g2_query=mul2(b),
+        h_query=mul1(h), l_query=mul1(l[ni:]),
+        toxic=dict(alpha=alpha, beta=beta, gamma=gamma, delta=delta, tau=tau, g1_k=g1_k, g2_k=g2_k,
+                   a=a, b=b, c=cc, l=l, h=h, zt=zt),
+    )
+
+
+class ProvingKey:
+    """Device-resident proving key + circuit matrices (zkp_groth16_pk_upload)."""
+
+    def __init__(self, ctx: Context, params: Parameters, circuit):
+        self.ctx, self.params, self.curve = ctx, params, params.curve
+        inst = _as_instance(self.curve, circuit, assign=False)
+        assert (inst.num_inputs, inst.num_aux, inst.num_constraints()) == \
+            (params.num_inputs, params.num_aux, params.num_constraints)
+        d = _lib.Groth16PkDesc()
+        d.curve, d.num_inputs, d.num_aux, d.num_constraints = self.curve.cid, inst.num_inputs, inst.num_aux, \
+            inst.num_constraints()
+        keep = []
+
+        def P(a):
+            a = np.ascontiguousarray(a)
+            keep.append(a)
+            return a.ctypes.data
+
+        for name, which in (("at", "a"), ("bt", "b"), ("ct", "c")):
+            rp, col, cf = inst.csr(which)
+            m = getattr(d, name)
+            m.row_ptr, m.col, m.coeff = P(rp.astype(np.uint32)), P(col.astype(np.uint32)), P(cf.astype(np.uint64))
+        for name in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2"):
+            setattr(d, name, P(getattr(params, name).astype(np.uint64)))
+        for name, fld in (("a", "a_query"), ("b_g1", "b_g1_query"), ("b_g2", "b_g2_query"), ("h", "h_query"),
+                          ("l", "l_query")):
+            xy, inf = getattr(params, fld)
+            setattr(d, f"{name}_query", P(xy.astype(np.uint64)))
+            setattr(d, f"{name}_inf", P(inf.astype(np.uint8)) if len(inf) else None)
+            setattr(d, f"{name}_len", len(inf))
+        h = C.c_void_p()
+        _lib.check(ctx.lib.zkp_groth16_pk_upload(ctx.h, C.byref(d), C.byref(h)), "zkp_groth16_pk_upload")
+        self.h = h
+        n = C.c_uint64()
+        _lib.check(ctx.lib.zkp_groth16_domain_size(self.h, C.byref(n)), "zkp_groth16_domain_size")
+        self.domain_size = n.value
+        self.nz = inst.num_inputs + inst.num_aux
+
+    def free(self):
+        if self.h:
+            _lib.check(self.ctx.lib.zkp_groth16_pk_free(self.ctx.h, self.h), "zkp_groth16_pk_free")
+            self.h = None
+
+    # R1CStoQAP::witness_map (r1cs_to_qap.rs:113-172)
+    def witness_map(self, z_mont: np.ndarray) -> np.ndarray:
+        z = np.ascontiguousarray(z_mont, dtype=np.uint64)
+        assert z.shape == (self.nz, 4)
+        h = np.zeros((self.domain_size, 4), dtype=np.uint64)
+        _lib.check(self.ctx.lib.zkp_groth16_witness_map(self.ctx.h, self.h, _ptr(z), _ptr(h)), "zkp_groth16_witness_map")
+        return h
+
+    def prove_raw(self, z, r_mont: np.ndarray, s_mont: np.ndarray, z_on_device: bool = False):
+        """-> (proof limbs uint64, identity flags[3])."""
+        c = self.curve
+        words = 4 * c.fq_limbs + 4 * c.fq_limbs
+        out = np.zeros(words, dtype=np.uint64)
+        inf = np.zeros(3, dtype=np.uint8)
+        r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64)
+        s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
+        if z_on_device:
+            st = self.ctx.lib.zkp_groth16_prove_dev(self.ctx.h, self.h, C.c_void_p(z), _ptr(r_mont), _ptr(s_mont),
+                                                    _ptr(out), _ptr(inf))
+        else:
+            z = np.ascontiguousarray(z, dtype=np.uint64)
+            assert z.shape == (self.nz, 4)
+            st = self.ctx.lib.zkp_groth16_prove(self.ctx.h, self.h, _ptr(z), _ptr(r_mont), _ptr(s_mont), _ptr(out),
+                                                _ptr(inf))
+        _lib.check(st, "zkp_groth16_prove")
+        return out, inf
+
+    def decode_proof(self, out: np.ndarray, inf) -> Proof:
+        c = self.curve
+        f = c.fq_limbs
+        a = g1_from_mont(out[0:2 * f], [inf[0]], c)[0]
+        b = g2_from_mont(out[2 * f:6 * f], [inf[1]], c)[0]
+        cc = g1_from_mont(out[6 * f:8 * f], [inf[2]], c)[0]
+        return Proof(a, b, cc)
+
+    def last_timing(self) -> dict:
+        t = _lib.Groth16Timing()
+        _lib.check(self.ctx.lib.zkp_groth16_last_timing(self.ctx.h, C.byref(t)), "zkp_groth16_last_timing")
+        return dict(ms_total=t.ms_total, ms_witness_map=t.ms_witness_map, ms_msm=list(t.ms_msm),
+                    ms_assemble=t.ms_assemble, ms_msm_accumulate=t.ms_msm_accumulate,
+                    msm_accumulate_launches=t.msm_accumulate_launches, msm_points=t.msm_points)
+
+
+def create_proof(pk: ProvingKey, circuit, r: int, s: int) -> Proof:
+    """prover.rs:124-211: synthesise on the host, prove on the device."""
+    inst = _as_instance(pk.curve, circuit, assign=True)
+    z = fr_to_mont(inst.full_assignment(), pk.curve).reshape(-1, 4)
+    rm = fr_to_mont([r], pk.curve)[0]
+    sm = fr_to_mont([s], pk.curve)[0]
+    out, inf = pk.prove_raw(z, rm, sm)
+    return pk.decode_proof(out, inf)
+
+
+def create_random_proof(pk: ProvingKey, circuit, rng=None) -> Proof:
+    """prover.rs:97-111: r, s <- Fr::rand(rng)."""
+    rnd = (lambda: rng.randrange(pk.curve.r)) if rng is not None else (lambda: secrets.randbelow(pk.curve.r))
+    return create_proof(pk, circuit, rnd(), rnd())
+
+
+def create_proof_no_zk(pk: ProvingKey, circuit) -> Proof:
+    """prover.rs:113-122"""
+    return create_proof(pk, circuit, 0, 0)

@@ -1,0 +1,173 @@
+/* zkp_accel.h — C ABI of the MI355X-native MSM + NTT proving backend for sec-bit/ckb-zkp.
+ *
+ * The reference (Rust) has no FFI for this path; this header *defines* the drop-in
+ * boundary.  Each entry point names the reference call it replaces; INTEGRATION.md shows the Rust
+ * `extern "C"` shim a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int32_t: ZKP_OK (0) or a negative zkp_status; nothing throws across the ABI;
+ *   - field elements: little-endian u64 limbs, MONTGOMERY form (R = 2^256, or 2^384 for BLS12-381 Fq)
+ *     == ark-ff `Fp256/Fp384` in memory;  Fr = 4 limbs; Fq = 4 (BN254) / 6 (BLS12-381) limbs;
+ *   - MSM scalars: 4 x u64 CANONICAL integers < r  == ark `BigInteger256` from `into_repr()`;
+ *   - affine points: AoS (x, y), G2 coordinates (c0, c1); identity = separate u8 flag array (NULL = none);
+ *   - projective results: ark Jacobian (X, Y, Z), identity = (0, 1, 0) — compare after `into_affine()`;
+ *   - `*_dev` variants take DEVICE pointers (hipMalloc / torch tensors) and run on the ctx stream;
+ *     host variants copy in/out and synchronise;
+ *   - one in-flight call per ctx; create one ctx per prover thread / per GPU (one process per GPU).
+ */
+#ifndef ZKP_ACCEL_H
+#define ZKP_ACCEL_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { ZKP_BN254 = 0, ZKP_BLS12_381 = 1 } zkp_curve_t;
+
+typedef enum {
+  ZKP_OK = 0,
+  ZKP_ERR_BAD_ARG = -1,
+  ZKP_ERR_UNSUPPORTED_CURVE = -2,
+  ZKP_ERR_DOMAIN_TOO_LARGE = -3, /* == SynthesisError::PolynomialDegreeTooLarge (groth16/src/r1cs_to_qap.rs:123-125) */
+  ZKP_ERR_OOM = -4,
+  ZKP_ERR_DEVICE = -5,           /* HIP runtime error, or no MI355X/gfx950 device: there is NO CPU fallback */
+  ZKP_ERR_BAD_HANDLE = -6
+} zkp_status;
+
+/* ops of zkp_ntt: ark-poly `EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place`
+ * (groth16/src/r1cs_to_qap.rs:144-148,161-162,169) */
+typedef enum { ZKP_NTT_FFT = 0, ZKP_NTT_IFFT = 1, ZKP_NTT_COSET_FFT = 2, ZKP_NTT_COSET_IFFT = 3 } zkp_ntt_op;
+
+typedef struct zkp_ctx zkp_ctx; /* opaque: device, stream, twiddle tables, scratch, resident bases */
+
+const char* zkp_status_string(int32_t status);
+const char* zkp_version(void);
+
+/* ---- context & device memory ------------------------------------------------------------------ */
+int32_t zkp_ctx_create(zkp_ctx** out, int device_id);
+int32_t zkp_ctx_destroy(zkp_ctx* ctx);
+/* run on an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int32_t zkp_ctx_set_stream(zkp_ctx* ctx, void* hip_stream);
+int32_t zkp_ctx_sync(zkp_ctx* ctx);
+int32_t zkp_dev_alloc(zkp_ctx* ctx, size_t bytes, void** dptr);
+int32_t zkp_dev_free(zkp_ctx* ctx, void* dptr);
+int32_t zkp_h2d(zkp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int32_t zkp_d2h(zkp_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* stream-ordered timing helpers (HIP events on the ctx stream) used by bench.py */
+int32_t zkp_timer_start(zkp_ctx* ctx);
+int32_t zkp_timer_stop_ms(zkp_ctx* ctx, float* ms);
+
+/* ---- NTT: replaces ark-poly GeneralEvaluationDomain::<Fr> ops ----------------------------------
+ * data: 2^log_n Fr elements (Montgomery), natural order in and out, in place.
+ * log_n > TWO_ADICITY (28 BN254 / 32 BLS12-381) -> ZKP_ERR_DOMAIN_TOO_LARGE.
+ * coset generator = Fr::multiplicative_generator() = 5 (BN254) / 7 (BLS12-381). */
+int32_t zkp_ntt(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* data_host, uint32_t log_n, int32_t op);
+int32_t zkp_ntt_dev(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* data_dev, uint32_t log_n, int32_t op);
+
+/* ---- bases (proving-key queries / SRS powers): upload once, prove many -------------------------
+ * xy: n affine points (Montgomery); inf: n flags or NULL.  The library copies (and pre-computes its
+ * window tables in HBM); the caller keeps ownership of the host buffers. */
+int32_t zkp_bases_upload_g1(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n,
+                            uint64_t* handle);
+int32_t zkp_bases_upload_g2(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n,
+                            uint64_t* handle);
+int32_t zkp_bases_free(zkp_ctx* ctx, uint64_t handle);
+int32_t zkp_bases_len(zkp_ctx* ctx, uint64_t handle, size_t* n);
+
+/* ---- MSM: replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul ------------------------------
+ * (groth16/src/prover.rs:187,190,220; marlin/src/pc/kzg10.rs:109,118,137,146; curve/src/lib.rs:44)
+ * result = sum_{i<n} scalars[i] * bases[offset+i]; n is clamped to the bases available (ark's
+ * min(len) truncation, prover.rs:186-187); n == 0 -> identity.
+ * out_xyz: 3 (G1) or 6 (G2) field elements, Jacobian, Montgomery, host memory. */
+int32_t zkp_msm_g1(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_host, size_t n,
+                   uint64_t* out_xyz);
+int32_t zkp_msm_g2(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_host, size_t n,
+                   uint64_t* out_xyz);
+int32_t zkp_msm_g1_dev(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n,
+                       uint64_t* out_xyz_host);
+int32_t zkp_msm_g2_dev(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n,
+                       uint64_t* out_xyz_host);
+/* zkp_curve::Curve::vartime_multiscalar_mul (curve/src/lib.rs:38-45): scalars are Fr in MONTGOMERY form;
+ * the into_repr() map is fused into the digit scan on the device. */
+int32_t zkp_vartime_multiscalar_mul_g1(zkp_ctx* ctx, uint64_t handle, const uint64_t* fr_scalars_host, size_t n,
+                                       uint64_t* out_xyz);
+/* fold k Jacobian points (host) into one: the local step after the multi-GPU all-gather of partial MSM
+ * results (EC addition is not an RCCL reduction op) */
+int32_t zkp_g1_fold(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz);
+int32_t zkp_g2_fold(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz);
+/* Jacobian -> affine (x, y) + identity flag: ark `into_affine()` */
+int32_t zkp_g1_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_host, uint64_t* xy_out,
+                           uint8_t* inf_out);
+int32_t zkp_g2_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_host, uint64_t* xy_out,
+                           uint8_t* inf_out);
+
+/* ---- fixed-base multiples k_i * P (setup side, generator.rs:205-256 `FixedBaseMSM`).
+ * Used to build synthetic proving keys from a known trapdoor at 2^20+ scale.  scalars canonical. */
+int32_t zkp_fixed_base_mul_g1(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* base_xy, const uint64_t* scalars_host,
+                              size_t n, uint64_t* out_xy, uint8_t* out_inf);
+int32_t zkp_fixed_base_mul_g2(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* base_xy, const uint64_t* scalars_host,
+                              size_t n, uint64_t* out_xy, uint8_t* out_inf);
+
+/* ---- Groth16: replaces zkp_groth16::create_proof (groth16/src/prover.rs:124-211) ---------------
+ * The circuit closures stay on the caller's side (Rust); the boundary receives what
+ * `ProvingAssignment` holds after synthesis (prover.rs:16-25): the three sparse matrices and the
+ * assignment.  Matrices are fixed per circuit -> uploaded with the key. */
+typedef struct {
+  /* CSR over constraints; coeffs Fr Montgomery; col = index into z = input_assignment ++ aux_assignment */
+  const uint32_t* row_ptr; /* num_constraints + 1 */
+  const uint32_t* col;     /* nnz */
+  const uint64_t* coeff;   /* nnz x 4 */
+} zkp_csr;
+
+typedef struct {
+  zkp_curve_t curve;
+  uint32_t num_inputs;      /* incl. the constant one */
+  uint32_t num_aux;
+  uint32_t num_constraints;
+  zkp_csr at, bt, ct;       /* prover.rs:17-19 */
+  /* Parameters<E> (groth16/src/lib.rs:79-91), host affine Montgomery + identity flags (NULL = none) */
+  const uint64_t* alpha_g1; const uint64_t* beta_g1; const uint64_t* delta_g1; /* 1 G1 point each */
+  const uint64_t* beta_g2; const uint64_t* delta_g2;                           /* 1 G2 point each */
+  const uint64_t* a_query; const uint8_t* a_inf; size_t a_len;
+  const uint64_t* b_g1_query; const uint8_t* b_g1_inf; size_t b_g1_len;
+  const uint64_t* b_g2_query; const uint8_t* b_g2_inf; size_t b_g2_len;
+  const uint64_t* h_query; const uint8_t* h_inf; size_t h_len;
+  const uint64_t* l_query; const uint8_t* l_inf; size_t l_len;
+} zkp_groth16_pk_desc;
+
+typedef struct zkp_groth16_pk zkp_groth16_pk; /* opaque device-resident proving key */
+
+int32_t zkp_groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, zkp_groth16_pk** out);
+int32_t zkp_groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk);
+
+/* R1CStoQAP::witness_map (groth16/src/r1cs_to_qap.rs:113-172): z (num_inputs+num_aux Fr, Montgomery)
+ * -> h (domain_size Fr, Montgomery).  *_dev: both pointers are device memory. */
+int32_t zkp_groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_host, uint64_t* h_host);
+int32_t zkp_groth16_witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_dev, uint64_t* h_dev);
+int32_t zkp_groth16_domain_size(zkp_groth16_pk* pk, uint64_t* n);
+
+/* create_proof(params, circuit, r, s): z = full assignment (Montgomery), r/s Fr Montgomery (4 limbs).
+ * proof_out: A (G1 affine) | B (G2 affine) | C (G1 affine), Montgomery; inf_out[3] identity flags. */
+int32_t zkp_groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_host, const uint64_t* r,
+                          const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
+int32_t zkp_groth16_prove_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_dev, const uint64_t* r,
+                              const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
+
+/* ---- introspection for bench.py / rocprof bookkeeping ------------------------------------------ */
+typedef struct {
+  float ms_total;          /* last zkp_groth16_prove*: stream time, HIP events */
+  float ms_witness_map;
+  float ms_msm[5];         /* A, B1, B2, H, L */
+  float ms_assemble;
+  float ms_msm_accumulate; /* sum over the five MSMs of the bucket-accumulate kernel (dominant kernel) */
+  uint64_t msm_accumulate_launches;
+  uint64_t msm_points;     /* non-identity (scalar, base) pairs fed to the five MSMs */
+} zkp_groth16_timing;
+int32_t zkp_groth16_last_timing(zkp_ctx* ctx, zkp_groth16_timing* out);
+int32_t zkp_set_profiling(zkp_ctx* ctx, int32_t enable); /* per-phase HIP events (adds sync points) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKP_ACCEL_H */

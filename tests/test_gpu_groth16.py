@@ -1,0 +1,103 @@
+"""Groth16 prover parity (config 1 of BASELINE.json and the reference's own Mini round trip,
+/root/reference/groth16/tests/mini.rs:46-97): device proof == oracle create_proof == trapdoor-expected proof."""
+import random
+
+import pytest
+
+from ckb_zkp_amd import codec, groth16
+from ckb_zkp_amd.circuits import Mini, MimcChain, mimc_chain_instance
+from oracle.pyref import groth16 as og
+from tests.util import OC
+
+pytestmark = pytest.mark.gpu
+TOXIC = dict(alpha=0x1234567890ABCDEF1, beta=0xFEDCBA09876543211, gamma=0x1111111111111111111,
+             delta=0x2222222222222222223, tau=0x3333333333333333335)
+
+
+def _oracle_params(curve, circuit, g1_k=1, g2_k=1):
+    return og.generate_parameters(OC[curve], circuit, TOXIC["alpha"], TOXIC["beta"], TOXIC["gamma"], TOXIC["delta"],
+                                  TOXIC["tau"], g1_k, g2_k)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_mini_roundtrip(ctx, curve):
+    """x=2, y=3, z=10, num=10 (mini.rs:53-76).  Key from the device's fixed-base kernels == oracle key;
+    proof == oracle prover == proof computed in the exponent."""
+    params = groth16.generate_parameters(ctx, curve, Mini(num=10), **TOXIC, g1_k=3, g2_k=5)
+    opk = _oracle_params(curve, og.MiniCircuit(num=10), 3, 5)
+    c = params.curve
+    assert codec.g1_from_mont(*params.a_query, c) == opk.a_query
+    assert codec.g1_from_mont(*params.b_g1_query, c) == opk.b_g1_query
+    assert codec.g2_from_mont(*params.b_g2_query, c) == opk.b_g2_query
+    assert codec.g1_from_mont(*params.h_query, c) == opk.h_query
+    assert codec.g1_from_mont(*params.l_query, c) == opk.l_query
+    pk = groth16.ProvingKey(ctx, params, Mini(num=10))
+    try:
+        for r_, s_ in ((77, 88), (0, 0), (0, 5), (c.r - 1, c.r - 2)):
+            proof = groth16.create_proof(pk, Mini(2, 3, 10, 10), r_, s_)
+            oproof, inter = og.create_proof(opk, og.MiniCircuit(2, 3, 10, 10), r_, s_)
+            assert (proof.a, proof.b, proof.c) == (oproof.a, oproof.b, oproof.c), (r_, s_)
+            exp = og.expected_proof_trapdoor(opk, inter["cs"], inter["h"], r_, s_)
+            assert (proof.a, proof.b, proof.c) == (exp.a, exp.b, exp.c)
+    finally:
+        pk.free()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_witness_map_matches_oracle(ctx, curve):
+    """R1CStoQAP::witness_map (r1cs_to_qap.rs:113-172) on a 30-constraint MiMC chain and on Mini."""
+    rnd = random.Random(4)
+    inst = mimc_chain_instance(curve, 3, seed=99)
+    circ = MimcChain(curve, inst.constants, inst.preimages)
+    ocirc = og.MimcChain(OC[curve], inst.constants, inst.preimages)
+    params = groth16.generate_parameters(ctx, curve, circ, **TOXIC)
+    pk = groth16.ProvingKey(ctx, params, inst)
+    try:
+        cs = og.ConstraintSystem(OC[curve], True)
+        ocirc.generate_constraints(cs)
+        h_exp, _ = og.witness_map(cs)
+        z = codec.fr_to_mont(inst.z, params.curve).reshape(-1, 4)
+        assert codec.fr_from_mont(pk.witness_map(z), params.curve) == h_exp
+        assert h_exp[-1] == 0                                  # deg h <= N-2
+    finally:
+        pk.free()
+
+
+@pytest.mark.parametrize("curve,k", [("bn254", 10), ("bls12_381", 8)])
+def test_mimc_chain_proof_trapdoor(ctx, curve, k):
+    """BASELINE.json configs[0]: 2^10-constraint MiMC R1CS (S=102 -> 1020 constraints, N=2^10): the device proof
+    equals the proof computed in the exponent from the toxic waste (oracle, no MSM/NTT involved except h)."""
+    from ckb_zkp_amd.circuits import samples_for_domain
+    S = samples_for_domain(k)
+    inst = mimc_chain_instance(curve, S)
+    params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    pk = groth16.ProvingKey(ctx, params, inst)
+    try:
+        assert pk.domain_size == 1 << k
+        c = params.curve
+        z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+        h = codec.fr_from_mont(pk.witness_map(z), c)
+        r_, s_ = 0xABCDEF0123456789, 0x9876543210FEDCBA
+        out, inf = pk.prove_raw(z, codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0])
+        proof = pk.decode_proof(out, inf)
+        # expected, in the exponent
+        t = params.toxic
+        r = c.r
+        ni = inst.num_inputs
+        A = (t["alpha"] + sum(zi * ai for zi, ai in zip(inst.z, t["a"])) + r_ * t["delta"]) % r
+        B = (t["beta"] + sum(zi * bi for zi, bi in zip(inst.z, t["b"])) + s_ * t["delta"]) % r
+        L = sum(zi * li for zi, li in zip(inst.z[ni:], t["l"][ni:])) % r
+        H = sum(hi * qi for hi, qi in zip(h, t["h"])) % r
+        Cc = (s_ * A + r_ * B - r_ * s_ % r * t["delta"] + L + H) % r
+        from oracle.pyref.curves import Group
+        G1, G2 = Group(OC[curve], 1), Group(OC[curve], 2)
+        assert proof.a == G1.mul(G1.gen, A)
+        assert proof.b == G2.mul(G2.gen, B)
+        assert proof.c == G1.mul(G1.gen, Cc)
+        # h itself against the oracle's witness_map at this size (Python NTT of 2^k is still fast)
+        cs = og.ConstraintSystem(OC[curve], True)
+        og.MimcChain(OC[curve], inst.constants, inst.preimages).generate_constraints(cs)
+        h_exp, _ = og.witness_map(cs)
+        assert h == h_exp
+    finally:
+        pk.free()

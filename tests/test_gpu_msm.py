@@ -1,0 +1,110 @@
+"""MSM parity: HIP Pippenger (C ABI) vs the oracle.  Replaces ark-ec VariableBaseMSM::multi_scalar_mul
+(/root/reference/groth16/src/prover.rs:187,190,220)."""
+import random
+
+import numpy as np
+import pytest
+
+from ckb_zkp_amd import codec
+from ckb_zkp_amd.params import get_curve
+from oracle.pyref.curves import Group
+from tests.util import OC, jac_limbs_to_affine_oracle, jac_to_affine, random_points, to_abi_points
+
+pytestmark = pytest.mark.gpu
+CFG = [("bn254", 1), ("bn254", 2), ("bls12_381", 1), ("bls12_381", 2)]
+
+
+@pytest.mark.parametrize("curve,group", CFG)
+def test_msm_small_edge_cases(ctx, curve, group):
+    """zero/one/r-1/2^k scalars, identity bases, duplicate bases (doubling branch), P and -P, n < len(bases)."""
+    c = get_curve(curve)
+    G = Group(OC[curve], group)
+    rnd = random.Random(7)
+    pts = random_points(curve, group, 24, seed=11 + group)
+    pts[3] = None                      # identity base
+    pts[5] = pts[4]                    # duplicate -> doubling inside a bucket
+    pts[7] = G.neg(pts[6])             # P, -P
+    ks = [rnd.randrange(c.r) for _ in range(24)]
+    ks[0], ks[1], ks[2], ks[8], ks[9] = 0, 1, c.r - 1, 2, 1 << 253
+    ks[5] = ks[4]                      # same scalar for the duplicate pair -> same buckets
+    ks[7] = ks[6]                      # k*P + k*(-P) = 0 inside the buckets
+    xy, inf = to_abi_points(curve, group, pts)
+    bases = ctx.upload_bases(c, group, xy, inf)
+    try:
+        for n, off in ((24, 0), (17, 3), (1, 0), (0, 0), (30, 0), (5, 19)):
+            sc = codec.fr_canonical(ks[:n], c).reshape(-1, 4)
+            out = bases.msm(sc, off)
+            m = min(n, 24 - off)
+            exp = G.msm_naive(pts[off:off + m], ks[:m])
+            assert jac_limbs_to_affine_oracle(curve, group, out) == exp, (n, off)
+            assert jac_to_affine(ctx, curve, group, out) == exp
+    finally:
+        bases.free()
+
+
+@pytest.mark.parametrize("curve,group", CFG)
+def test_msm_all_equal_scalars_and_all_ones(ctx, curve, group):
+    """Adversarial bucket skew: every scalar equal (one bucket per window gets everything)."""
+    c = get_curve(curve)
+    G = Group(OC[curve], group)
+    n = 300
+    g_xy, _ = to_abi_points(curve, group, [G.gen])
+    ds = list(range(1, n + 1))
+    xy, inf = ctx.fixed_base_mul(c, group, g_xy, codec.fr_canonical(ds, c))
+    bases = ctx.upload_bases(c, group, xy, inf)
+    try:
+        for k in (1, 0x1234567, c.r - 1):
+            out = bases.msm(codec.fr_canonical([k] * n, c))
+            assert jac_limbs_to_affine_oracle(curve, group, out) == G.mul(G.gen, k * sum(ds) % c.r)
+    finally:
+        bases.free()
+
+
+@pytest.mark.parametrize("curve,group,log_n", [("bn254", 1, 12), ("bn254", 1, 16), ("bn254", 2, 14),
+                                               ("bls12_381", 1, 14), ("bls12_381", 2, 12), ("bn254", 1, 20)])
+def test_msm_known_dlog(ctx, curve, group, log_n):
+    """bases P_i = d_i*G (built on the device), expected = (sum d_i k_i mod r)*G."""
+    c = get_curve(curve)
+    G = Group(OC[curve], group)
+    n = (1 << log_n) - 3
+    rng = np.random.default_rng(log_n * 10 + group)
+    d = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    d[:, 3] >>= np.uint64(4)            # < 2^251 < r
+    k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    k[:, 3] >>= np.uint64(4)
+    k[::7] = 0                          # zero scalars (ark skips them)
+    k[1::11, 1:] = 0
+    k[1::11, 0] = 1                     # ones (ark fast path)
+    g_xy, _ = to_abi_points(curve, group, [G.gen])
+    xy, inf = ctx.fixed_base_mul(c, group, g_xy, d)
+    assert not inf.any()
+    bases = ctx.upload_bases(c, group, xy, inf)
+    try:
+        out = bases.msm(k)
+        dl, kl = codec.limbs_to_ints(d), codec.limbs_to_ints(k)
+        e = sum(a * b for a, b in zip(dl, kl)) % c.r
+        assert jac_limbs_to_affine_oracle(curve, group, out) == G.mul(G.gen, e)
+        # linearity: msm(k) + msm(k') == msm(k + k')  (scalars kept < r)
+        k2 = np.zeros_like(k)
+        k2[:, 0] = rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
+        ks = codec.fr_canonical([(a + b) % c.r for a, b in zip(kl, codec.limbs_to_ints(k2))], c)
+        s1 = ctx.fold(c, group, np.concatenate([out, bases.msm(k2)]))
+        assert jac_limbs_to_affine_oracle(curve, group, s1) == jac_limbs_to_affine_oracle(curve, group, bases.msm(ks))
+    finally:
+        bases.free()
+
+
+def test_vartime_multiscalar_mul_montgomery_scalars(ctx):
+    """zkp_curve::Curve::vartime_multiscalar_mul (curve/src/lib.rs:38-45): Fr scalars in Montgomery form."""
+    c = get_curve("bn254")
+    G = Group(OC["bn254"], 1)
+    pts = random_points("bn254", 1, 40, seed=5)
+    rnd = random.Random(9)
+    ks = [rnd.randrange(c.r) for _ in range(40)]
+    xy, inf = to_abi_points("bn254", 1, pts)
+    bases = ctx.upload_bases(c, 1, xy, inf)
+    try:
+        out = bases.vartime_multiscalar_mul(codec.fr_to_mont(ks, c))
+        assert jac_limbs_to_affine_oracle("bn254", 1, out) == G.msm_naive(pts, ks)
+    finally:
+        bases.free()
