@@ -94,7 +94,7 @@ struct zkp_ctx {
   zkp::DevBuf ntt_scratch, ntt_io;
   // MSM scratch
   zkp::DevBuf msm_scalars, msm_keys, msm_vals, msm_keys2, msm_vals2, msm_sort_tmp, msm_offsets, msm_buckets,
-      msm_tmp, msm_out, msm_misc;
+      msm_tmp, msm_out, msm_misc, msm_sched, msm_scan_tmp, msm_partial;
   std::unordered_map<uint64_t, std::shared_ptr<zkp::BasesEntry>> bases;
   uint64_t next_handle = 1;
   zkp_groth16_timing last_timing{};

@@ -160,6 +160,83 @@ __global__ void bounds_kernel(const uint32_t* __restrict__ keys, size_t E, uint3
   if (e + 1 == E || keys[e + 1] != k) end[k] = (uint32_t)(e + 1);
 }
 
+// ------------------------------------------------------------------------------------------- task scheduling
+// A bucket of len entries becomes ceil(len / CAP) tasks.  Tasks are then ordered by length (counting sort on
+// CAP+1 bins) so that the 64 lanes of a wave walk runs of (almost) equal length: with Poisson-distributed
+// bucket sizes this turns ~65 % lane utilisation into > 95 %, and it bounds the serial chain of any lane by CAP
+// even for adversarial inputs (all scalars equal) or the thinly populated top window.
+// tmeta layout (uint32): [0] n_long  [1..CAP+1] histogram by length  [128..128+CAP] cursors
+constexpr int TM_NLONG = 0, TM_HIST = 1, TM_CUR = 128, TM_WORDS = 256;
+
+__global__ void task_count_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nb,
+                                  uint32_t* __restrict__ tcount) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nb) return;
+  tcount[b] = b < nb ? (end[b] - start[b] + MSM_TASK_CAP - 1) / MSM_TASK_CAP : 0;
+}
+
+__global__ __launch_bounds__(256) void task_fill_kernel(const uint32_t* __restrict__ start,
+                                                        const uint32_t* __restrict__ end,
+                                                        const uint32_t* __restrict__ toff, uint32_t nb,
+                                                        uint32_t* __restrict__ task_start,
+                                                        uint32_t* __restrict__ task_len,
+                                                        uint32_t* __restrict__ task_dst,
+                                                        uint32_t* __restrict__ long_list,
+                                                        uint32_t* __restrict__ tmeta) {
+  __shared__ uint32_t hist[MSM_TASK_CAP + 1];
+  for (int i = threadIdx.x; i <= (int)MSM_TASK_CAP; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) {
+    const uint32_t s = start[b], len = end[b] - s;
+    const uint32_t t0 = toff[b], nt = toff[b + 1] - t0;
+    if (nt > 1) long_list[atomicAdd(&tmeta[TM_NLONG], 1u)] = b;
+    for (uint32_t j = 0; j < nt; j++) {
+      uint32_t l = min(MSM_TASK_CAP, len - j * MSM_TASK_CAP);
+      task_start[t0 + j] = s + j * MSM_TASK_CAP;
+      task_len[t0 + j] = l;
+      task_dst[t0 + j] = nt == 1 ? b : (0x80000000u | (t0 + j));
+      atomicAdd(&hist[l], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= (int)MSM_TASK_CAP; i += blockDim.x)
+    if (hist[i]) atomicAdd(&tmeta[TM_HIST + i], hist[i]);
+}
+
+// cursors: longest tasks first
+__global__ void task_cursor_kernel(uint32_t* tmeta) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint32_t acc = 0;
+  for (int l = MSM_TASK_CAP; l >= 0; l--) {
+    tmeta[TM_CUR + l] = acc;
+    acc += tmeta[TM_HIST + l];
+  }
+}
+
+__global__ __launch_bounds__(256) void task_order_kernel(const uint32_t* __restrict__ task_len,
+                                                         const uint32_t* __restrict__ n_tasks_dev,
+                                                         uint32_t* __restrict__ tmeta, uint32_t* __restrict__ order) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = t < *n_tasks_dev;
+  const uint32_t l = live ? task_len[t] : 0xffffffffu;
+  // wave-aggregated atomics: lanes with the same length elect a leader (ballot loop over distinct values)
+  uint64_t todo = __ballot(live);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t lv = __shfl(l, leader);
+    const uint64_t same = __ballot(live && l == lv);
+    if (live && l == lv) {
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&tmeta[TM_CUR + lv], (uint32_t)__popcll(same));
+      base = __shfl(base, leader);
+      const uint32_t rank = __popcll(same & ((1ull << lane) - 1));
+      order[base + rank] = t;
+    }
+    todo &= ~same;
+  }
+}
 
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
              uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries) {
@@ -198,16 +275,43 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     uint32_t* end = start + nb;
     ZKP_HIP(hipMemsetAsync(start, 0, 2 * (size_t)nb * 4, st));
     hipLaunchKernelGGL(bounds_kernel, dim3((E + 255) / 256), dim3(256), 0, st, keys2, E, nb, start, end);
-    // K7 — level l of the reduction pyramid lives at element offset lvl_off[l] of `buckets` (level 0 = buckets)
+    // K7 scheduling: buckets -> tasks (<= CAP entries), ordered by length
+    const uint32_t max_tasks = nb + (uint32_t)(E / MSM_TASK_CAP) + 1;
+    uint32_t* sched = ctx->msm_sched.as<uint32_t>((size_t)2 * (nb + 2) + (size_t)5 * max_tasks + TM_WORDS);
+    uint32_t* tcount = sched;                       // nb + 1
+    uint32_t* toff = tcount + (nb + 2);             // nb + 1  (toff[nb] = number of tasks)
+    uint32_t* task_start = toff + (nb + 2);
+    uint32_t* task_len = task_start + max_tasks;
+    uint32_t* task_dst = task_len + max_tasks;
+    uint32_t* order = task_dst + max_tasks;
+    uint32_t* long_list = order + max_tasks;
+    uint32_t* tmeta = long_list + max_tasks;
+    ZKP_HIP(hipMemsetAsync(tmeta, 0, TM_WORDS * 4, st));
+    hipLaunchKernelGGL(task_count_kernel, dim3((nb + 256) / 256), dim3(256), 0, st, start, end, nb, tcount);
+    size_t scan_bytes = 0;
+    ZKP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, tcount, toff, (int)(nb + 1), st));
+    void* scan_tmp = ctx->msm_scan_tmp.get(scan_bytes);
+    ZKP_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, tcount, toff, (int)(nb + 1), st));
+    hipLaunchKernelGGL(task_fill_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, start, end, toff, nb, task_start,
+                       task_len, task_dst, long_list, tmeta);
+    hipLaunchKernelGGL(task_cursor_kernel, dim3(1), dim3(64), 0, st, tmeta);
+    hipLaunchKernelGGL(task_order_kernel, dim3((max_tasks + 255) / 256), dim3(256), 0, st, task_len, toff + nb, tmeta,
+                       order);
+    // level l of the reduction pyramid lives at element offset lvl_off[l] of `buckets` (level 0 = buckets);
+    // all-zero bytes are a valid identity (zz == 0), so empty buckets need no kernel
     char* buckets = reinterpret_cast<char*>(ctx->msm_buckets.get((size_t)2 * nb * XB + XB));
+    char* task_partial = reinterpret_cast<char*>(ctx->msm_partial.get((size_t)max_tasks * XB));
+    ZKP_HIP(hipMemsetAsync(buckets, 0, (size_t)nb * XB, st));
     const bool timed = ms_accumulate && ctx->profiling;
     if (timed) ZKP_HIP(hipEventRecord(ctx->ev2, st));
-    vt->accumulate(st, be->table, vals2, start, end, nb, buckets);
+    vt->accumulate(st, be->table, vals2, order, task_start, task_len, task_dst, toff + nb, max_tasks, buckets,
+                   task_partial);
     if (timed) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
       ZKP_HIP(hipEventSynchronize(ctx->ev3));
       ZKP_HIP(hipEventElapsedTime(ms_accumulate, ctx->ev2, ctx->ev3));
     }
+    vt->combine(st, long_list, tmeta + TM_NLONG, toff, task_partial, buckets);
     if (n_entries) *n_entries = E;
     // K8: pyramid
     const int L = c - 1;                           // levels with odd entries: 0..L-1 ; root = level L

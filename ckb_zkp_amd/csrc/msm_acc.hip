@@ -33,13 +33,17 @@ using namespace ZKP_CFG_SYM(cfg);
 namespace ZKP_CFG_SYM(cfg) {
 __global__ __launch_bounds__(256) void accumulate_kernel(const char* __restrict__ table,
                                                          const uint32_t* __restrict__ vals,
-                                                         const uint32_t* __restrict__ start,
-                                                         const uint32_t* __restrict__ end, uint32_t nb,
-                                                         char* __restrict__ buckets) {
+                                                         const uint32_t* __restrict__ order,
+                                                         const uint32_t* __restrict__ task_start,
+                                                         const uint32_t* __restrict__ task_len,
+                                                         const uint32_t* __restrict__ task_dst,
+                                                         const uint32_t* __restrict__ n_tasks_dev,
+                                                         char* __restrict__ buckets, char* __restrict__ partial) {
   using F = CfgF;
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
-  uint32_t e0 = start[b], e1 = end[b];
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= *n_tasks_dev) return;
+  const uint32_t id = order[t];
+  const uint32_t e0 = task_start[id], e1 = e0 + task_len[id];
   XYZZ<F> acc = XYZZ<F>::inf();
   for (uint32_t e = e0; e < e1; e++) {
     uint32_t v = vals[e];
@@ -47,13 +51,17 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const char* __restrict_
     if (v >> 31) p.y = p.y.neg();
     acc.madd(p);
   }
-  acc.store(buckets + (size_t)b * XYZZ<F>::BYTES);
+  const uint32_t d = task_dst[id];
+  char* out = (d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * XYZZ<F>::BYTES : buckets + (size_t)d * XYZZ<F>::BYTES;
+  acc.store(out);
 }
 }  // namespace ZKP_CFG_SYM(cfg)
 
-void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint32_t* start,
-                                        const uint32_t* end, uint32_t nb, char* buckets) {
-  hipLaunchKernelGGL(accumulate_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, table, vals, start, end, nb, buckets);
+void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint32_t* order,
+                                        const uint32_t* task_start, const uint32_t* task_len, const uint32_t* task_dst,
+                                        const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial) {
+  hipLaunchKernelGGL(accumulate_kernel, dim3((max_tasks + 255) / 256), dim3(256), 0, s, table, vals, order, task_start,
+                     task_len, task_dst, n_tasks_dev, buckets, partial);
 }
 
 }  // namespace zkp

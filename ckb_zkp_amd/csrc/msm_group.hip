@@ -94,6 +94,39 @@ __global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ ba
   if (threadIdx.x == 0) acc.store(partial + (size_t)blockIdx.x * XYZZ<F>::BYTES);
 }
 
+// buckets[b] = sum of the partial sums of a bucket that was split into several tasks; one wave per bucket
+template <class F>
+__global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict__ long_list,
+                                                      const uint32_t* __restrict__ n_long_dev,
+                                                      const uint32_t* __restrict__ toff,
+                                                      const char* __restrict__ partial, char* __restrict__ buckets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  char* my = smem + (size_t)wv * 64 * XYZZ<F>::BYTES;
+  const uint32_t n_long = *n_long_dev;
+  for (uint32_t w = blockIdx.x * 4 + wv; w < n_long; w += gridDim.x * 4) {
+    const uint32_t b = long_list[w];
+    const uint32_t p0 = toff[b], p1 = toff[b + 1];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t i = p0 + lane; i < p1; i += 64) acc.add(XYZZ<F>::load(partial + (size_t)i * XYZZ<F>::BYTES));
+    acc.store(my + lane * XYZZ<F>::BYTES);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int s = 32; s > 0; s >>= 1) {
+      __builtin_amdgcn_wave_barrier();
+      if (lane < s) {
+        XYZZ<F> o = XYZZ<F>::load(my + (lane + s) * XYZZ<F>::BYTES);
+        if (!o.is_inf()) {
+          acc.add(o);
+          acc.store(my + lane * XYZZ<F>::BYTES);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane == 0) acc.store(buckets + (size_t)b * XYZZ<F>::BYTES);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // out = sum_l 2^l * O[l] + root ; one wave
 template <class F>
 __global__ __launch_bounds__(64) void final_kernel(const char* __restrict__ O, int L, const char* __restrict__ root,
@@ -232,7 +265,8 @@ __global__ __launch_bounds__(64) void assemble_g2_kernel(const char* __restrict_
 
 // ------------------------------------------------------------------------------------------- launch table
 void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t, const char*, const uint32_t*, const uint32_t*, const uint32_t*,
-                                        uint32_t, char*);   // msm_acc.hip
+                                        const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*,
+                                        char*);   // msm_acc.hip
 
 namespace {
 using F = CfgF;
@@ -242,6 +276,10 @@ void l_ingest(hipStream_t s, char* table, const uint8_t* inf, size_t n) {
 }
 void l_precompute(hipStream_t s, char* table, size_t n, int c, int W) {
   hipLaunchKernelGGL(precompute_kernel<F>, dim3((n + 127) / 128), dim3(128), 0, s, table, n, c, W);
+}
+void l_combine(hipStream_t s, const uint32_t* long_list, const uint32_t* n_long_dev, const uint32_t* toff,
+               const char* partial, char* buckets) {
+  hipLaunchKernelGGL(combine_kernel<F>, dim3(512), dim3(256), 256 * XB, s, long_list, n_long_dev, toff, partial, buckets);
 }
 void l_pair(hipStream_t s, const char* in, char* out, uint32_t count) {
   hipLaunchKernelGGL(pair_kernel<F>, dim3((count + 255) / 256), dim3(256), 0, s, in, out, count);
@@ -281,7 +319,7 @@ void l_assemble_g2(hipStream_t s, const char* res, size_t slot, uint32_t* out, u
 const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
   static const MsmVtbl v = {
       F::N, Affine<F>::BYTES, XYZZ<F>::BYTES, CFG_BITS,
-      l_ingest, l_precompute, ZKP_CFG_SYM(msm_accumulate_launch), l_pair, l_segsum, l_final, l_identity, l_fold,
+      l_ingest, l_precompute, ZKP_CFG_SYM(msm_accumulate_launch), l_combine, l_pair, l_segsum, l_final, l_identity, l_fold,
       l_into_affine, l_fixed_base,
 #if ZKP_CFG_GROUP == 1
       l_assemble_g1, nullptr,

@@ -9,6 +9,7 @@
 namespace zkp {
 
 constexpr int SEG_CHUNK = 1024;
+constexpr uint32_t MSM_TASK_CAP = 64;      // max entries one lane accumulates before the bucket is split
 struct SegPlan {
   int L;                       // number of segments
   uint32_t first_block[26];    // blocks of segment l: first_block[l] .. first_block[l+1]
@@ -23,8 +24,14 @@ struct MsmVtbl {
   int scalar_bits;
   void (*ingest)(hipStream_t, char* table, const uint8_t* inf, size_t n);
   void (*precompute)(hipStream_t, char* table, size_t n, int c, int W);
-  void (*accumulate)(hipStream_t, const char* table, const uint32_t* vals, const uint32_t* start, const uint32_t* end,
-                     uint32_t nb, char* buckets);
+  // one lane per TASK (<= MSM_TASK_CAP consecutive entries of one bucket, tasks ordered by length);
+  // dst < 0x80000000: bucket index (single-task bucket), else partial slot (dst & 0x7fffffff)
+  void (*accumulate)(hipStream_t, const char* table, const uint32_t* vals, const uint32_t* order,
+                     const uint32_t* task_start, const uint32_t* task_len, const uint32_t* task_dst,
+                     const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial);
+  // one wave per multi-task bucket: buckets[b] = sum of its partials
+  void (*combine)(hipStream_t, const uint32_t* long_list, const uint32_t* n_long_dev, const uint32_t* toff,
+                  const char* partial, char* buckets);
   void (*pair)(hipStream_t, const char* in, char* out, uint32_t count);
   void (*segsum)(hipStream_t, const char* base, const SegPlan* plan, char* partial, uint32_t blocks);
   void (*final)(hipStream_t, const char* O, int L, const char* root, char* out_xyzz, uint32_t* out_jac);

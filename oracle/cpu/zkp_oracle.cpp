@@ -259,61 +259,56 @@ struct Domain {
     g = F::from_limbs(P::GEN);
     g_inv = g.inv();
   }
-  // ark-poly serial_radix2_fft: bit-reverse, then log n DIT stages with running twiddle
-  void transform(F* a, const F& omega, int threads) const {
-    for (size_t k = 0; k < n; k++) {
-      size_t rk = 0; for (int b = 0; b < log_n; b++) rk |= ((k >> b) & 1) << (log_n - 1 - b);
-      if (k < rk) std::swap(a[k], a[rk]);
+  // ark-poly serial_radix2_fft: bit-reverse, then log n DIT stages with running twiddle.
+  // Threading (stand-in for ark's rayon `parallel` feature): T = 2^t threads; the first log n - t stages touch
+  // only a thread's own contiguous n/T chunk (one spawn for all of them); the last t stages split the j-range.
+  static void stage_range(F* a, size_t k, size_t m, size_t j0, size_t j1, const F& w_m) {
+    F wj = j0 ? w_m.pow64(j0) : F::one();
+    for (size_t j = j0; j < j1; j++) {
+      F t = a[k + j + m] * wj;
+      a[k + j + m] = a[k + j] - t;
+      a[k + j] = a[k + j] + t;
+      wj = wj * w_m;
     }
-    size_t m = 1;
-    for (int s = 0; s < log_n; s++) {
-      F w_m = omega.pow64(n / (2 * m));
-      size_t blocks = n / (2 * m);
-      auto body = [&](size_t b0, size_t b1) {
-        for (size_t blk = b0; blk < b1; blk++) {
-          size_t k = blk * 2 * m;
-          F wj = F::one();
-          for (size_t j = 0; j < m; j++) {
-            F t = a[k + j + m] * wj;
-            a[k + j + m] = a[k + j] - t;
-            a[k + j] = a[k + j] + t;
-            wj = wj * w_m;
-          }
-        }
-      };
-      if (threads > 1 && blocks >= (size_t)threads * 4) {
-        std::vector<std::thread> pool;
-        size_t per = (blocks + threads - 1) / threads;
-        for (int t = 0; t < threads; t++) {
-          size_t b0 = t * per, b1 = std::min(blocks, b0 + per);
-          if (b0 < b1) pool.emplace_back(body, b0, b1);
-        }
-        for (auto& t : pool) t.join();
-      } else if (threads > 1 && m >= (size_t)threads * 64) {
-        // few big blocks: split j-range, each thread starts from w_m^(j0)
-        for (size_t blk = 0; blk < blocks; blk++) {
-          size_t k = blk * 2 * m;
-          std::vector<std::thread> pool;
-          size_t per = (m + threads - 1) / threads;
-          for (int t = 0; t < threads; t++) {
-            size_t j0 = t * per, j1 = std::min(m, j0 + per);
-            if (j0 >= j1) continue;
-            pool.emplace_back([&, j0, j1, k]() {
-              F wj = w_m.pow64(j0);
-              for (size_t j = j0; j < j1; j++) {
-                F tt = a[k + j + m] * wj;
-                a[k + j + m] = a[k + j] - tt;
-                a[k + j] = a[k + j] + tt;
-                wj = wj * w_m;
-              }
-            });
-          }
-          for (auto& t : pool) t.join();
-        }
-      } else {
-        body(0, blocks);
+  }
+  void transform(F* a, const F& omega, int threads) const {
+    int t = 0;
+    while ((2 << t) <= threads && t + 1 <= 6 && log_n - (t + 1) >= 10) t++;   // <= 64 threads, chunks >= 1024
+    const size_t T = (size_t)1 << t;
+    auto par = [&](const std::function<void(size_t)>& fn) {
+      if (T == 1) { fn(0); return; }
+      std::vector<std::thread> pool;
+      for (size_t i = 1; i < T; i++) pool.emplace_back(fn, i);
+      fn(0);
+      for (auto& th : pool) th.join();
+    };
+    // bit reversal
+    par([&](size_t ti) {
+      size_t per = n / T;
+      for (size_t k = ti * per; k < (ti + 1) * per; k++) {
+        size_t rk = 0; for (int b = 0; b < log_n; b++) rk |= ((k >> b) & 1) << (log_n - 1 - b);
+        if (k < rk) std::swap(a[k], a[rk]);
       }
-      m *= 2;
+    });
+    const int local_stages = log_n - t;
+    std::vector<F> wm(log_n);
+    for (int s = 0; s < log_n; s++) wm[s] = omega.pow64(n >> (s + 1));
+    par([&](size_t ti) {
+      size_t per = n / T, base = ti * per;
+      for (int s = 0; s < local_stages; s++) {
+        size_t m = (size_t)1 << s;
+        for (size_t k = base; k < base + per; k += 2 * m) stage_range(a, k, m, 0, m, wm[s]);
+      }
+    });
+    for (int s = local_stages; s < log_n; s++) {
+      size_t m = (size_t)1 << s;
+      size_t blocks = n / (2 * m);               // < T
+      size_t split = T / blocks;                 // threads per block
+      par([&](size_t ti) {
+        size_t blk = ti / split, part = ti % split;
+        size_t per = m / split;
+        stage_range(a, blk * 2 * m, m, part * per, (part + 1) * per, wm[s]);
+      });
     }
   }
   void distribute_powers(F* a, const F& gg, const F& c0) const { F p = c0; for (size_t i = 0; i < n; i++) { a[i] = a[i] * p; p = p * gg; } }
