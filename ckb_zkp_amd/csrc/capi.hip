@@ -66,6 +66,14 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
     ZKP_HIP(hipEventCreate(&ctx->ev1));
     ZKP_HIP(hipEventCreate(&ctx->ev2));
     ZKP_HIP(hipEventCreate(&ctx->ev3));
+    ZKP_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < zkp_ctx::N_WS; i++) {
+      ZKP_HIP(hipEventCreateWithFlags(&ctx->ws[i].done, hipEventDisableTiming));
+      if (i > 0) {
+        ZKP_HIP(hipStreamCreateWithFlags(&ctx->ws[i].stream, hipStreamNonBlocking));
+        ctx->ws[i].own_stream = true;
+      }
+    }
   });
   if (st != ZKP_OK) {
     delete ctx;
@@ -85,6 +93,12 @@ int32_t zkp_ctx_destroy(zkp_ctx* ctx) {
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  for (int i = 0; i < zkp_ctx::N_WS; i++) {
+    if (ctx->ws[i].stream) (void)hipStreamSynchronize(ctx->ws[i].stream);
+    if (ctx->ws[i].done) (void)hipEventDestroy(ctx->ws[i].done);
+    if (ctx->ws[i].own_stream && ctx->ws[i].stream) (void)hipStreamDestroy(ctx->ws[i].stream);
+  }
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return ZKP_OK;

@@ -77,6 +77,16 @@ struct NttTables {
 };
 
 struct BasesEntry;   // msm.hip
+
+// Scratch + stream of ONE in-flight MSM.  A context owns several so that independent MSMs of one proof run
+// concurrently: the log-depth bucket-reduction tail of one MSM is latency-bound (a few wavefronts), and
+// overlapping it with the throughput-bound accumulate kernel of another keeps the 256 CUs busy.
+struct MsmWorkspace {
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t done = nullptr;
+  DevBuf keys, vals, keys2, vals2, sort_tmp, offsets, buckets, tmp, out, sched, scan_tmp, partial;
+};
 struct Groth16Timing {
   zkp_groth16_timing t{};
 };
@@ -93,8 +103,10 @@ struct zkp_ctx {
   std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)
   zkp::DevBuf ntt_scratch, ntt_io;
   // MSM scratch
-  zkp::DevBuf msm_scalars, msm_keys, msm_vals, msm_keys2, msm_vals2, msm_sort_tmp, msm_offsets, msm_buckets,
-      msm_tmp, msm_out, msm_misc, msm_sched, msm_scan_tmp, msm_partial;
+  zkp::DevBuf msm_scalars, msm_misc;
+  static constexpr int N_WS = 3;
+  zkp::MsmWorkspace ws[N_WS];                                  // ws[0].stream aliases `stream`
+  hipEvent_t ev_fork = nullptr;
   std::unordered_map<uint64_t, std::shared_ptr<zkp::BasesEntry>> bases;
   uint64_t next_handle = 1;
   zkp_groth16_timing last_timing{};

@@ -34,6 +34,15 @@ struct Affine {
 };
 
 template <class F>
+struct XYZZ;
+// exceptional-case paths (P + P inside add/madd) are rare: keep ONE out-of-line copy so that inlining the
+// multiplier into the hot formulas does not triple their code size
+template <class F>
+__device__ __noinline__ XYZZ<F> xyzz_dbl_slow(XYZZ<F> p);
+template <class F>
+__device__ __noinline__ XYZZ<F> xyzz_dbl_affine_slow(Affine<F> p);
+
+template <class F>
 struct XYZZ {
   F x, y, zz, zzz;
   static constexpr int BYTES = 16 * F::N;
@@ -94,7 +103,7 @@ struct XYZZ {
     F pp_ = u2 - x;
     F r = s2 - y;
     if (pp_.is_zero()) {
-      if (r.is_zero()) *this = dbl_affine(p);
+      if (r.is_zero()) *this = xyzz_dbl_affine_slow<F>(p);
       else *this = inf();
       return;
     }
@@ -122,7 +131,7 @@ struct XYZZ {
     F pp_ = u2 - u1;
     F r = s2 - s1;
     if (pp_.is_zero()) {
-      if (r.is_zero()) *this = dbl();
+      if (r.is_zero()) *this = xyzz_dbl_slow<F>(*this);
       else *this = inf();
       return;
     }
@@ -162,5 +171,10 @@ struct XYZZ {
     z.store(q + 8 * F::N);
   }
 };
+
+template <class F>
+__device__ __noinline__ XYZZ<F> xyzz_dbl_slow(XYZZ<F> p) { return p.dbl(); }
+template <class F>
+__device__ __noinline__ XYZZ<F> xyzz_dbl_affine_slow(Affine<F> p) { return XYZZ<F>::dbl_affine(p); }
 
 }  // namespace zkp

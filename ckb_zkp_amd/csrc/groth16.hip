@@ -269,10 +269,6 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
   ZKP_HIP(hipMemcpyAsync(rs + 8, s, 32, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(scalar_tail_kernel<FrP>, dim3(1), dim3(64), 0, st, S + pk->nz * 8, rs);
 
-  tic();
-  uint32_t* h = witness_map_dev<FrP>(ctx, pk, S);
-  toc(&tm.ms_witness_map);
-
   const MsmVtbl* v1 = msm_vtbl(pk->curve, 1);
   const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
   const size_t slot = v2->xyzz_bytes;                  // uniform slot size
@@ -280,21 +276,42 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
   const uint64_t* Sd = reinterpret_cast<const uint64_t*>(S);
   float acc_ms = 0.f;
   uint64_t ent = 0;
-  auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n) {
+  // Schedule.  profiling: everything on the main stream, one MSM at a time, with per-phase events.
+  // otherwise: three streams —  main: witness_map -> H ;  ws1: A -> L ;  ws2: B1 -> B2  — joined before assembly.
+  auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n, int w) {
     float ms = 0.f;
     uint64_t e = 0;
     tic();
-    msm_run(ctx, handle, 0, sc, n, true, nullptr, res + idx * slot, prof ? &ms : nullptr, &e);
+    msm_run(ctx, handle, 0, sc, n, true, nullptr, res + idx * slot, prof ? &ms : nullptr, &e, prof ? 0 : w);
     toc(&tm.ms_msm[idx]);
     acc_ms += ms;
     ent += e;
     tm.msm_accumulate_launches += 1;
   };
-  run(0, pk->hA, Sd, pk->nz + 4);                                                  // prover.rs:164-167
-  run(1, pk->hB1, Sd, pk->nz + 4);                                                 // prover.rs:170-177
-  run(2, pk->hB2, Sd, pk->nz + 4);                                                 // prover.rs:182-184
-  run(3, pk->hH, reinterpret_cast<const uint64_t*>(h), std::min(pk->N, bases_len(ctx, pk->hH)));  // :186-187
-  run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4);        // prover.rs:189-190
+  if (!prof) {
+    ZKP_HIP(hipEventRecord(ctx->ev_fork, st));                       // S is complete
+    for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->ws[w].stream, ctx->ev_fork, 0));
+    run(0, pk->hA, Sd, pk->nz + 4, 1);                                             // prover.rs:164-167
+    run(1, pk->hB1, Sd, pk->nz + 4, 2);                                            // prover.rs:170-177
+    run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 1);   // prover.rs:189-190
+    run(2, pk->hB2, Sd, pk->nz + 4, 2);                                            // prover.rs:182-184
+  }
+  tic();
+  uint32_t* h = witness_map_dev<FrP>(ctx, pk, S);
+  toc(&tm.ms_witness_map);
+  if (prof) {
+    run(0, pk->hA, Sd, pk->nz + 4, 0);
+    run(1, pk->hB1, Sd, pk->nz + 4, 0);
+    run(2, pk->hB2, Sd, pk->nz + 4, 0);
+  }
+  run(3, pk->hH, reinterpret_cast<const uint64_t*>(h), std::min(pk->N, bases_len(ctx, pk->hH)), 0);  // :186-187
+  if (prof) run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 0);
+  if (!prof) {
+    for (int w = 1; w < zkp_ctx::N_WS; w++) {
+      ZKP_HIP(hipEventRecord(ctx->ws[w].done, ctx->ws[w].stream));
+      ZKP_HIP(hipStreamWaitEvent(st, ctx->ws[w].done, 0));
+    }
+  }
   tm.ms_msm_accumulate = acc_ms;
   tm.msm_points = ent;
 

@@ -14,9 +14,10 @@ void bases_free(zkp_ctx* ctx, uint64_t handle);
 size_t bases_len(zkp_ctx* ctx, uint64_t handle);
 int bases_group(zkp_ctx* ctx, uint64_t handle);
 // result -> host Jacobian (out_xyz_host) ; if out_dev_xyzz != nullptr the XYZZ result is also left on device
+// runs on workspace `ws` (its stream + scratch); does not synchronise unless out_xyz_host != nullptr
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
              uint64_t* out_xyz_host, void* out_dev_xyzz = nullptr, float* ms_accumulate = nullptr,
-             uint64_t* n_entries = nullptr);
+             uint64_t* n_entries = nullptr, int ws = 0);
 void msm_free_all(zkp_ctx* ctx);
 void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz_host);
 void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, uint64_t* xy_out, uint8_t* inf_out);

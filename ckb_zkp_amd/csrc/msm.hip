@@ -217,35 +217,35 @@ __global__ void task_cursor_kernel(uint32_t* tmeta) {
 __global__ __launch_bounds__(256) void task_order_kernel(const uint32_t* __restrict__ task_len,
                                                          const uint32_t* __restrict__ n_tasks_dev,
                                                          uint32_t* __restrict__ tmeta, uint32_t* __restrict__ order) {
+  // counting-sort scatter: LDS histogram gives each task its rank among the block's tasks of equal length;
+  // one global atomic per (block, length) reserves the block's slice of that length's output range.
+  __shared__ uint32_t cnt[MSM_TASK_CAP + 1];
+  __shared__ uint32_t base[MSM_TASK_CAP + 1];
+  for (int i = threadIdx.x; i <= (int)MSM_TASK_CAP; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = t < *n_tasks_dev;
-  const uint32_t l = live ? task_len[t] : 0xffffffffu;
-  // wave-aggregated atomics: lanes with the same length elect a leader (ballot loop over distinct values)
-  uint64_t todo = __ballot(live);
-  const int lane = threadIdx.x & 63;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t lv = __shfl(l, leader);
-    const uint64_t same = __ballot(live && l == lv);
-    if (live && l == lv) {
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&tmeta[TM_CUR + lv], (uint32_t)__popcll(same));
-      base = __shfl(base, leader);
-      const uint32_t rank = __popcll(same & ((1ull << lane) - 1));
-      order[base + rank] = t;
-    }
-    todo &= ~same;
+  uint32_t l = 0, rank = 0;
+  if (live) {
+    l = task_len[t];
+    rank = atomicAdd(&cnt[l], 1u);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= (int)MSM_TASK_CAP; i += blockDim.x)
+    if (cnt[i]) base[i] = atomicAdd(&tmeta[TM_CUR + i], cnt[i]);
+  __syncthreads();
+  if (live) order[base[l] + rank] = t;
 }
 
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
-             uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries) {
+             uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries, int ws_idx) {
   auto be = get_bases(ctx, handle);
   const MsmVtbl* vt = be->vt;
-  hipStream_t st = ctx->stream;
+  MsmWorkspace& ws = ctx->ws[ws_idx];
+  hipStream_t st = ws_idx == 0 ? ctx->stream : ws.stream;
   const size_t XB = vt->xyzz_bytes;
   const size_t jac_words = 3 * (size_t)vt->fN;
-  uint32_t* out_jac = ctx->msm_out.as<uint32_t>(64 * 4);
+  uint32_t* out_jac = ws.out.as<uint32_t>(64 * 4);
   if (ms_accumulate) *ms_accumulate = 0.f;
   if (n_entries) *n_entries = 0;
   if (n == 0) {
@@ -255,10 +255,10 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     const uint32_t nb = 1u << (c - 1);
     const size_t E = n * (size_t)W;
     ZKP_REQUIRE(E < 2147483000ull, ZKP_ERR_BAD_ARG);
-    uint32_t* keys = ctx->msm_keys.as<uint32_t>(E);
-    uint32_t* vals = ctx->msm_vals.as<uint32_t>(E);
-    uint32_t* keys2 = ctx->msm_keys2.as<uint32_t>(E);
-    uint32_t* vals2 = ctx->msm_vals2.as<uint32_t>(E);
+    uint32_t* keys = ws.keys.as<uint32_t>(E);
+    uint32_t* vals = ws.vals.as<uint32_t>(E);
+    uint32_t* keys2 = ws.keys2.as<uint32_t>(E);
+    uint32_t* vals2 = ws.vals2.as<uint32_t>(E);
     const uint32_t* sc = reinterpret_cast<const uint32_t*>(scalars_dev);
     if (be->curve == ZKP_BN254)
       hipLaunchKernelGGL(digits_kernel<Bn254Fr>, dim3((n + 255) / 256), dim3(256), 0, st, sc, n, offset, be->inf, be->n,
@@ -269,15 +269,15 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     // K6: sort (key bits 0..c; key nb == sentinel sorts last)
     size_t tmp_bytes = 0;
     ZKP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)E, 0, c, st));
-    void* tmp = ctx->msm_sort_tmp.get(tmp_bytes);
+    void* tmp = ws.sort_tmp.get(tmp_bytes);
     ZKP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)E, 0, c, st));
-    uint32_t* start = ctx->msm_offsets.as<uint32_t>(2 * (size_t)nb);
+    uint32_t* start = ws.offsets.as<uint32_t>(2 * (size_t)nb);
     uint32_t* end = start + nb;
     ZKP_HIP(hipMemsetAsync(start, 0, 2 * (size_t)nb * 4, st));
     hipLaunchKernelGGL(bounds_kernel, dim3((E + 255) / 256), dim3(256), 0, st, keys2, E, nb, start, end);
     // K7 scheduling: buckets -> tasks (<= CAP entries), ordered by length
     const uint32_t max_tasks = nb + (uint32_t)(E / MSM_TASK_CAP) + 1;
-    uint32_t* sched = ctx->msm_sched.as<uint32_t>((size_t)2 * (nb + 2) + (size_t)5 * max_tasks + TM_WORDS);
+    uint32_t* sched = ws.sched.as<uint32_t>((size_t)2 * (nb + 2) + (size_t)5 * max_tasks + TM_WORDS);
     uint32_t* tcount = sched;                       // nb + 1
     uint32_t* toff = tcount + (nb + 2);             // nb + 1  (toff[nb] = number of tasks)
     uint32_t* task_start = toff + (nb + 2);
@@ -290,7 +290,7 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     hipLaunchKernelGGL(task_count_kernel, dim3((nb + 256) / 256), dim3(256), 0, st, start, end, nb, tcount);
     size_t scan_bytes = 0;
     ZKP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, tcount, toff, (int)(nb + 1), st));
-    void* scan_tmp = ctx->msm_scan_tmp.get(scan_bytes);
+    void* scan_tmp = ws.scan_tmp.get(scan_bytes);
     ZKP_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, tcount, toff, (int)(nb + 1), st));
     hipLaunchKernelGGL(task_fill_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, start, end, toff, nb, task_start,
                        task_len, task_dst, long_list, tmeta);
@@ -299,8 +299,8 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
                        order);
     // level l of the reduction pyramid lives at element offset lvl_off[l] of `buckets` (level 0 = buckets);
     // all-zero bytes are a valid identity (zz == 0), so empty buckets need no kernel
-    char* buckets = reinterpret_cast<char*>(ctx->msm_buckets.get((size_t)2 * nb * XB + XB));
-    char* task_partial = reinterpret_cast<char*>(ctx->msm_partial.get((size_t)max_tasks * XB));
+    char* buckets = reinterpret_cast<char*>(ws.buckets.get((size_t)2 * nb * XB + XB));
+    char* task_partial = reinterpret_cast<char*>(ws.partial.get((size_t)max_tasks * XB));
     ZKP_HIP(hipMemsetAsync(buckets, 0, (size_t)nb * XB, st));
     const bool timed = ms_accumulate && ctx->profiling;
     if (timed) ZKP_HIP(hipEventRecord(ctx->ev2, st));
@@ -331,7 +331,7 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     }
     plan.first_block[L] = blocks;
     const char* root = buckets + (size_t)lvl_off * XB;      // cnt == 1
-    char* partial = reinterpret_cast<char*>(ctx->msm_tmp.get(((size_t)blocks + 64) * XB));
+    char* partial = reinterpret_cast<char*>(ws.tmp.get(((size_t)blocks + 64) * XB));
     char* Obuf = partial + (size_t)blocks * XB;
     if (L > 0) {
       vt->segsum(st, buckets, &plan, partial, blocks);

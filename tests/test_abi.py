@@ -1,0 +1,50 @@
+"""CPU: the C-ABI library loads and exports exactly the symbols include/zkp_accel.h declares (no compute calls)."""
+import ctypes
+import re
+from pathlib import Path
+
+from ckb_zkp_amd import _lib
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def header_symbols():
+    text = (ROOT / "include" / "zkp_accel.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(zkp_[a-z0-9_]+)\s*\(", text))
+
+
+def test_header_symbols_exported_and_bound():
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in zkp_accel.h but not exported by libzkp_accel.so"
+    assert syms == set(_lib.SIGNATURES), (syms ^ set(_lib.SIGNATURES))
+
+
+def test_status_strings_and_no_cpu_fallback():
+    lib = _lib.load()
+    assert lib.zkp_status_string(0) == b"ok"
+    assert b"PolynomialDegreeTooLarge" in lib.zkp_status_string(-3)
+    assert b"no CPU fallback" in lib.zkp_status_string(-5)
+    assert lib.zkp_version().startswith(b"zkp_accel")
+    # NULL context is rejected, never dereferenced
+    assert lib.zkp_ctx_sync(None) == -1
+    assert lib.zkp_ntt(None, 0, None, 3, 0) == -1
+
+
+def test_desc_struct_layout_matches_header():
+    """ctypes mirror of zkp_groth16_pk_desc must have the C layout (x86-64 SysV): 4 ints, 3 CSR triples, 5+15 words."""
+    assert ctypes.sizeof(_lib.Csr) == 24
+    assert ctypes.sizeof(_lib.Groth16PkDesc) == 16 + 3 * 24 + 5 * 8 + 5 * 24
+    assert ctypes.sizeof(_lib.Groth16Timing) == 4 * 9 + 4 + 16   # 9 floats, pad, 2 u64
+
+
+def test_product_does_not_import_oracle():
+    """The product path must not reach into oracle/ (it is the checker, never the thing shipped)."""
+    for f in (ROOT / "ckb_zkp_amd").rglob("*"):
+        if f.suffix in (".py", ".hip", ".cuh", ".hpp", ".cpp", ".h") and f.is_file():
+            txt = f.read_text()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+            assert "libzkp_oracle" not in txt and "cpu_oracle" not in txt and "pyref" not in txt, f

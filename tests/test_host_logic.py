@@ -1,0 +1,83 @@
+"""CPU: host-side mirror of the reference's interfaces (r1cs, circuits, codecs, QAP exponents)."""
+import random
+
+import numpy as np
+import pytest
+
+from ckb_zkp_amd import codec, groth16
+from ckb_zkp_amd.circuits import Mini, MimcChain, mimc_chain_instance, samples_for_domain
+from ckb_zkp_amd.params import get_curve
+from ckb_zkp_amd.r1cs import AssignmentMissing, ConstraintSystem, PolynomialDegreeTooLarge, R1csInstance
+from oracle.pyref import groth16 as og
+from tests.util import OC
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_codec_roundtrip(curve):
+    c = get_curve(curve)
+    rnd = random.Random(1)
+    xs = [0, 1, c.r - 1] + [rnd.randrange(c.r) for _ in range(20)]
+    assert codec.fr_from_mont(codec.fr_to_mont(xs, c), c) == xs
+    assert codec.limbs_to_ints(codec.fr_canonical(xs, c)) == xs
+    pts = [None, c.g1]
+    xy, inf = codec.g1_to_mont(pts, c)
+    assert codec.g1_from_mont(xy, inf, c) == pts and inf.tolist() == [1, 0]
+    xy2, inf2 = codec.g2_to_mont([c.g2, None], c)
+    assert codec.g2_from_mont(xy2, inf2, c) == [c.g2, None]
+    # ark layout: Montgomery one = R mod p, little-endian limbs
+    assert codec.limbs_to_ints(codec.fr_to_mont([1], c))[0] == (1 << 256) % c.r
+
+
+def test_mini_matches_reference_shape():
+    """groth16/tests/mini.rs: 2 aux (x, y), 2 inputs (one, z), num constraints; missing witness -> AssignmentMissing."""
+    cs = ConstraintSystem("bn254", True)
+    Mini(2, 3, 10, 10).generate_constraints(cs)
+    assert (cs.num_inputs, cs.num_aux, cs.num_constraints()) == (2, 2, 10)
+    assert cs.full_assignment() == [1, 10, 2, 3]
+    with pytest.raises(AssignmentMissing):
+        Mini(num=1).generate_constraints(ConstraintSystem("bn254", True))
+    ks = ConstraintSystem("bn254", False)
+    Mini(num=10).generate_constraints(ks)          # KeypairAssembly needs no values
+    assert ks.num_constraints() == 10
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_array_form_mimc_equals_closure_form(curve):
+    inst = mimc_chain_instance(curve, 9)
+    cs = ConstraintSystem(curve, True)
+    MimcChain(curve, inst.constants, inst.preimages).generate_constraints(cs)
+    ref = R1csInstance.from_cs(cs)
+    assert ref.z == inst.z
+    assert (ref.num_inputs, ref.num_aux, ref.num_constraints()) == (1, 108, 90)
+    for w in "abc":
+        for x, y in zip(ref.csr(w), inst.csr(w)):
+            assert np.array_equal(x, y)
+    # and equals the oracle's synthesis
+    ocs = og.ConstraintSystem(OC[curve], True)
+    og.MimcChain(OC[curve], inst.constants, inst.preimages).generate_constraints(ocs)
+    assert ocs.input_assignment + ocs.aux_assignment == inst.z
+    # satisfiable: <A_i,z> * <B_i,z> == <C_i,z>
+    c = get_curve(curve)
+    for i in range(90):
+        ev = [og.evaluate_constraint(rows[i], inst.z, 1, c.r) for rows in (ocs.at, ocs.bt, ocs.ct)]
+        assert ev[0] * ev[1] % c.r == ev[2]
+
+
+def test_domain_sizes_of_baseline_configs():
+    assert samples_for_domain(10) == 102 and samples_for_domain(20) == 104857      # 1 048 570 constraints
+    assert 10 * samples_for_domain(20) + 1 <= 1 << 20 < 10 * (samples_for_domain(20) + 1) + 1
+    c = get_curve("bn254")
+    assert groth16._domain_log(c, 1 << 20) == 20 and groth16._domain_log(c, (1 << 20) + 1) == 21
+    with pytest.raises(PolynomialDegreeTooLarge):
+        groth16._domain_log(c, (1 << 28) + 1)                                        # r1cs_to_qap.rs:123-125
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_qap_exponents_match_oracle_instance_map(curve):
+    """Product-side `qap_exponents` (used to synthesise keys) == oracle instance_map_with_evaluation."""
+    inst = mimc_chain_instance(curve, 4, with_witness=False)
+    a, b, c_, zt, N = groth16.qap_exponents(inst, 0x3333333333333333335)
+    ocs = og.ConstraintSystem(OC[curve], False)
+    og.MimcChain(OC[curve], inst.constants, inst.preimages).generate_constraints(ocs)
+    oa, ob, oc, ozt, _, oN = og.instance_map_with_evaluation(ocs, 0x3333333333333333335)
+    assert (a, b, c_, zt, N) == (oa, ob, oc, ozt, oN)
