@@ -69,6 +69,7 @@ SIGNATURES = {
     "zkp_msm_g1_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
     "zkp_msm_g2_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
     "zkp_vartime_multiscalar_mul_g1": (C.c_int32, [vp, C.c_uint64, vp, C.c_size_t, vp]),
+    "zkp_vartime_multiscalar_mul_g2": (C.c_int32, [vp, C.c_uint64, vp, C.c_size_t, vp]),
     "zkp_g1_fold": (C.c_int32, [vp, C.c_int, vp, C.c_size_t, vp]),
     "zkp_g2_fold": (C.c_int32, [vp, C.c_int, vp, C.c_size_t, vp]),
     "zkp_g1_into_affine": (C.c_int32, [vp, C.c_int, vp, vp, vp]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "zkp_groth16_domain_size": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
     "zkp_groth16_prove": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp]),
     "zkp_groth16_prove_dev": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp]),
+    "zkp_groth16_assemble": (C.c_int32, [vp, C.c_int, vp, vp, vp, vp, vp]),
     "zkp_groth16_last_timing": (C.c_int32, [vp, C.POINTER(Groth16Timing)]),
     "zkp_set_profiling": (C.c_int32, [vp, C.c_int32]),
 }

@@ -177,11 +177,12 @@ class Bases:
 
     def vartime_multiscalar_mul(self, fr_scalars_mont: np.ndarray) -> np.ndarray:
         """zkp_curve::Curve::vartime_multiscalar_mul (curve/src/lib.rs:38-45): Montgomery Fr scalars."""
-        assert self.group == 1
         s = _c64(fr_scalars_mont)
         out = self._out()
-        _lib.check(self.ctx.lib.zkp_vartime_multiscalar_mul_g1(self.ctx.h, self.handle, _ptr(s), s.shape[0], _ptr(out)),
-                   "zkp_vartime_multiscalar_mul_g1")
+        fn = self.ctx.lib.zkp_vartime_multiscalar_mul_g1 if self.group == 1 else \
+            self.ctx.lib.zkp_vartime_multiscalar_mul_g2
+        _lib.check(fn(self.ctx.h, self.handle, _ptr(s), s.shape[0] if s.ndim == 2 else 0, _ptr(out)),
+                   "zkp_vartime_multiscalar_mul")
         return out
 
     def msm_affine(self, scalars: np.ndarray, offset: int = 0):

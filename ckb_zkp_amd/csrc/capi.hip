@@ -67,6 +67,8 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
     ZKP_HIP(hipEventCreate(&ctx->ev2));
     ZKP_HIP(hipEventCreate(&ctx->ev3));
     ZKP_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    ZKP_HIP(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
+    ZKP_HIP(hipEventCreateWithFlags(&ctx->ev_b1, hipEventDisableTiming));
     for (int i = 0; i < zkp_ctx::N_WS; i++) {
       ZKP_HIP(hipEventCreateWithFlags(&ctx->ws[i].done, hipEventDisableTiming));
       if (i > 0) {
@@ -94,6 +96,8 @@ int32_t zkp_ctx_destroy(zkp_ctx* ctx) {
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
+  if (ctx->ev_b1) (void)hipEventDestroy(ctx->ev_b1);
   for (int i = 0; i < zkp_ctx::N_WS; i++) {
     if (ctx->ws[i].stream) (void)hipStreamSynchronize(ctx->ws[i].stream);
     if (ctx->ws[i].done) (void)hipEventDestroy(ctx->ws[i].done);
@@ -241,6 +245,10 @@ int32_t zkp_vartime_multiscalar_mul_g1(zkp_ctx* ctx, uint64_t h, const uint64_t*
   return msm_common(ctx, 1, h, 0, s, n, out, false, true);
 }
 
+int32_t zkp_vartime_multiscalar_mul_g2(zkp_ctx* ctx, uint64_t h, const uint64_t* s, size_t n, uint64_t* out) {
+  return msm_common(ctx, 2, h, 0, s, n, out, false, true);
+}
+
 int32_t zkp_g1_fold(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz, size_t k, uint64_t* out) {
   if (!out || (k && !xyz)) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { point_fold(ctx, curve, 1, xyz, k, out); });
@@ -299,6 +307,11 @@ int32_t zkp_groth16_prove_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* 
                               const uint64_t* s, uint64_t* proof, uint8_t* inf) {
   if (!pk || !z || !r || !s || !proof || !inf) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { groth16_prove(ctx, pk, z, true, r, s, proof, inf); });
+}
+int32_t zkp_groth16_assemble(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* sums, const uint64_t* r,
+                             const uint64_t* s, uint64_t* proof, uint8_t* inf) {
+  if (!sums || !r || !s || !proof || !inf) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_assemble(ctx, curve, sums, r, s, proof, inf); });
 }
 int32_t zkp_groth16_last_timing(zkp_ctx* ctx, zkp_groth16_timing* out) {
   if (!ctx || !out) return ZKP_ERR_BAD_ARG;

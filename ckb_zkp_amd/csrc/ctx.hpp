@@ -104,9 +104,9 @@ struct zkp_ctx {
   zkp::DevBuf ntt_scratch, ntt_io;
   // MSM scratch
   zkp::DevBuf msm_scalars, msm_misc;
-  static constexpr int N_WS = 3;
+  static constexpr int N_WS = 4;                                // ws[3]: assembly stream (no scratch)
   zkp::MsmWorkspace ws[N_WS];                                  // ws[0].stream aliases `stream`
-  hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b1 = nullptr;
   std::unordered_map<uint64_t, std::shared_ptr<zkp::BasesEntry>> bases;
   uint64_t next_handle = 1;
   zkp_groth16_timing last_timing{};

@@ -162,29 +162,34 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d) {
   ZKP_REQUIRE(lg <= (d->curve == ZKP_BN254 ? 28 : 32) && lg <= 30, ZKP_ERR_DOMAIN_TOO_LARGE);
   pk->log_n = lg;
   pk->N = (size_t)1 << lg;
-  ZKP_REQUIRE(d->a_len == pk->nz && d->b_g1_len == pk->nz && d->b_g2_len == pk->nz, ZKP_ERR_BAD_ARG);
-  ZKP_REQUIRE(d->l_len == d->num_aux, ZKP_ERR_BAD_ARG);
+  const bool matrices_only = d->a_query == nullptr;
+  if (!matrices_only) {
+    ZKP_REQUIRE(d->a_len == pk->nz && d->b_g1_len == pk->nz && d->b_g2_len == pk->nz, ZKP_ERR_BAD_ARG);
+    ZKP_REQUIRE(d->l_len == d->num_aux, ZKP_ERR_BAD_ARG);
+  }
   const size_t fq = d->curve == ZKP_BN254 ? 4 : 6;
   const uint64_t* tA[4] = {d->alpha_g1, d->delta_g1, nullptr, nullptr};
   const uint64_t* tB1[4] = {d->beta_g1, nullptr, d->delta_g1, nullptr};
   const uint64_t* tB2[4] = {d->beta_g2, nullptr, d->delta_g2, nullptr};
   const uint64_t* tL[4] = {nullptr, nullptr, nullptr, d->delta_g1};
-  for (auto p : {d->alpha_g1, d->beta_g1, d->delta_g1, d->beta_g2, d->delta_g2}) ZKP_REQUIRE(p, ZKP_ERR_BAD_ARG);
   pk->m[0] = upload_csr(ctx, d->at, d->num_constraints);
   pk->m[1] = upload_csr(ctx, d->bt, d->num_constraints);
   pk->m[2] = upload_csr(ctx, d->ct, d->num_constraints);
-  pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA);
-  pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1);
-  pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2);
-  pk->hH = bases_upload(ctx, d->curve, 1, d->h_query, d->h_inf, d->h_len);
-  pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL);
+  if (!matrices_only) {
+    for (auto p : {d->alpha_g1, d->beta_g1, d->delta_g1, d->beta_g2, d->delta_g2}) ZKP_REQUIRE(p, ZKP_ERR_BAD_ARG);
+    pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA);
+    pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1);
+    pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2);
+    pk->hH = bases_upload(ctx, d->curve, 1, d->h_query, d->h_inf, d->h_len);
+    pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL);
+  }
   uint32_t* consts = pk->consts.as<uint32_t>(64);
   if (d->curve == ZKP_BN254) hipLaunchKernelGGL(qap_consts_kernel<Bn254Fr>, dim3(1), dim3(64), 0, ctx->stream, consts, lg);
   else hipLaunchKernelGGL(qap_consts_kernel<Bls381Fr>, dim3(1), dim3(64), 0, ctx->stream, consts, lg);
   ZKP_HIP(hipGetLastError());
   pk->abc.get(3 * pk->N * 32);
   pk->S.get((pk->nz + 4) * 32);
-  pk->results.get(5 * 16 * 24 * 4 + 64);
+  pk->results.get(6 * 16 * 24 * 4 + 64);
   pk->proof.get(4096);
   ZKP_HIP(hipStreamSynchronize(ctx->stream));
   return pk.release();
@@ -242,6 +247,7 @@ void groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, ui
 template <class FrP>
 static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
                     const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out) {
+  ZKP_REQUIRE(pk->hA != 0, ZKP_ERR_BAD_ARG);             // matrices-only key: use the sharded path
   hipStream_t st = ctx->stream;
   const bool prof = ctx->profiling;
   zkp_groth16_timing tm{};
@@ -272,7 +278,7 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
   const MsmVtbl* v1 = msm_vtbl(pk->curve, 1);
   const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
   const size_t slot = v2->xyzz_bytes;                  // uniform slot size
-  char* res = reinterpret_cast<char*>(pk->results.get(5 * slot));
+  char* res = reinterpret_cast<char*>(pk->results.get(6 * slot));
   const uint64_t* Sd = reinterpret_cast<const uint64_t*>(S);
   float acc_ms = 0.f;
   uint64_t ent = 0;
@@ -292,7 +298,14 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
     ZKP_HIP(hipEventRecord(ctx->ev_fork, st));                       // S is complete
     for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->ws[w].stream, ctx->ev_fork, 0));
     run(0, pk->hA, Sd, pk->nz + 4, 1);                                             // prover.rs:164-167
+    ZKP_HIP(hipEventRecord(ctx->ev_a, ctx->ws[1].stream));
     run(1, pk->hB1, Sd, pk->nz + 4, 2);                                            // prover.rs:170-177
+    ZKP_HIP(hipEventRecord(ctx->ev_b1, ctx->ws[2].stream));
+    // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~5 ms single-wave chain: start them as soon as
+    // A and B1 exist so they hide under the remaining three MSMs
+    ZKP_HIP(hipStreamWaitEvent(ctx->ws[3].stream, ctx->ev_a, 0));
+    ZKP_HIP(hipStreamWaitEvent(ctx->ws[3].stream, ctx->ev_b1, 0));
+    v1->assemble_g1_part1(ctx->ws[3].stream, res, slot, rs, proof_dev, flags_dev);
     run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 1);   // prover.rs:189-190
     run(2, pk->hB2, Sd, pk->nz + 4, 2);                                            // prover.rs:182-184
   }
@@ -317,7 +330,8 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
 
   tic();
   // proof layout (32-bit words): A = 2*fN1 | B = 2*fN2 | C = 2*fN1
-  v1->assemble_g1(st, res, slot, rs, proof_dev, flags_dev, 2 * v1->fN + 2 * v2->fN);
+  if (prof) v1->assemble_g1_part1(st, res, slot, rs, proof_dev, flags_dev);
+  v1->assemble_g1_part2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN + 2 * v2->fN);
   v2->assemble_g2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN);
   ZKP_HIP(hipGetLastError());
   toc(&tm.ms_assemble);
@@ -336,6 +350,37 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
   }
+}
+
+void groth16_assemble(zkp_ctx* ctx, int curve, const uint64_t* sums, const uint64_t* r, const uint64_t* s,
+                      uint64_t* proof_out, uint8_t* inf_out) {
+  const MsmVtbl* v1 = msm_vtbl(curve, 1);
+  const MsmVtbl* v2 = msm_vtbl(curve, 2);
+  hipStream_t st = ctx->stream;
+  const size_t slot = v2->xyzz_bytes;
+  const size_t j1 = 3 * (size_t)v1->fN, j2 = 3 * (size_t)v2->fN;          // words
+  const size_t in_words = 4 * j1 + j2;
+  uint32_t* buf = ctx->msm_misc.as<uint32_t>(in_words + 16 + 6 * slot / 4 + 256 + 16);
+  uint32_t* jac = buf;
+  uint32_t* rs = jac + in_words;
+  char* res = reinterpret_cast<char*>(rs + 16);
+  uint32_t* proof_dev = reinterpret_cast<uint32_t*>(res + 6 * slot);
+  uint32_t* flags_dev = proof_dev + 240;
+  ZKP_HIP(hipMemcpyAsync(jac, sums, in_words * 4, hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipMemcpyAsync(rs, r, 32, hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipMemcpyAsync(rs + 8, s, 32, hipMemcpyHostToDevice, st));
+  const size_t off[5] = {0, j1, 2 * j1, 2 * j1 + j2, 3 * j1 + j2};
+  for (int i = 0; i < 5; i++) (i == 2 ? v2 : v1)->from_jacobian(st, jac + off[i], res + i * slot);
+  v1->assemble_g1_part1(st, res, slot, rs, proof_dev, flags_dev);
+  v1->assemble_g1_part2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN + 2 * v2->fN);
+  v2->assemble_g2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN);
+  ZKP_HIP(hipGetLastError());
+  const size_t proof_words = 4 * (size_t)v1->fN + 2 * (size_t)v2->fN;
+  uint32_t flags_host[4] = {0, 0, 0, 0};
+  ZKP_HIP(hipMemcpyAsync(proof_out, proof_dev, proof_words * 4, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(flags_host, flags_dev, 12, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < 3; i++) inf_out[i] = (uint8_t)flags_host[i];
 }
 
 void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,

@@ -193,6 +193,12 @@ __global__ void into_affine_kernel(const uint32_t* jac, uint32_t* xy, uint32_t* 
   *inf = p.is_inf() ? 1 : 0;
 }
 
+template <class F>
+__global__ void from_jacobian_kernel(const uint32_t* jac, char* out) {
+  if (threadIdx.x || blockIdx.x) return;
+  jac_to_xyzz<F>(jac).store(out);
+}
+
 // k_i * P, one lane per scalar (setup-side helper; double-and-add, MSB first)
 template <class F, int BITS>
 __global__ __launch_bounds__(128) void fixed_base_kernel(const uint32_t* base, const uint32_t* scalars, size_t n,
@@ -218,10 +224,11 @@ __global__ __launch_bounds__(128) void fixed_base_kernel(const uint32_t* base, c
 // (prover.rs:192-210 after the folding described in groth16.hip)
 namespace ZKP_CFG_SYM(cfg) {
 #if ZKP_CFG_GROUP == 1
-// lanes 0/1: s*g_a and r*g1_b (double-and-add on the affine-normalised point); lane 0 then sums C.
-__global__ __launch_bounds__(64) void assemble_g1_kernel(const char* __restrict__ res, size_t slot,
-                                                         const uint32_t* __restrict__ rs, uint32_t* __restrict__ out,
-                                                         uint32_t* __restrict__ flags, int c_off_words) {
+// part 1 — lanes 0/1: s*g_a and r*g1_b (double-and-add on the affine-normalised point); T = sum -> slot 5
+__global__ __launch_bounds__(64) void assemble_g1_part1_kernel(char* __restrict__ res, size_t slot,
+                                                               const uint32_t* __restrict__ rs,
+                                                               uint32_t* __restrict__ out,
+                                                               uint32_t* __restrict__ flags) {
   using F = CfgF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -244,12 +251,21 @@ __global__ __launch_bounds__(64) void assemble_g1_kernel(const char* __restrict_
   __syncthreads();
   if (t == 0) {
     acc.add(XYZZ<F>::load(smem + XYZZ<F>::BYTES));
-    acc.add(XYZZ<F>::load(res + 3 * slot));      // h_acc
-    acc.add(XYZZ<F>::load(res + 4 * slot));      // l' (includes -rs*delta)
-    Affine<F> c = acc.to_affine();
-    c.store(out + c_off_words);
-    flags[2] = acc.is_inf() ? 1 : 0;
+    acc.store(res + 5 * slot);
   }
+}
+// part 2 — C = T + h_acc + l'  (l' includes -rs*delta)
+__global__ __launch_bounds__(64) void assemble_g1_part2_kernel(const char* __restrict__ res, size_t slot,
+                                                               uint32_t* __restrict__ out,
+                                                               uint32_t* __restrict__ flags, int c_off_words) {
+  using F = CfgF;
+  if (threadIdx.x || blockIdx.x) return;
+  XYZZ<F> acc = XYZZ<F>::load(res + 5 * slot);
+  acc.add(XYZZ<F>::load(res + 3 * slot));
+  acc.add(XYZZ<F>::load(res + 4 * slot));
+  Affine<F> c = acc.to_affine();
+  c.store(out + c_off_words);
+  flags[2] = acc.is_inf() ? 1 : 0;
 }
 #else
 __global__ __launch_bounds__(64) void assemble_g2_kernel(const char* __restrict__ res, size_t slot,
@@ -299,15 +315,20 @@ void l_fold(hipStream_t s, const uint32_t* pts, int k, uint32_t* out_jac) {
 void l_into_affine(hipStream_t s, const uint32_t* jac, uint32_t* xy, uint32_t* inf) {
   hipLaunchKernelGGL(into_affine_kernel<F>, dim3(1), dim3(64), 0, s, jac, xy, inf);
 }
+void l_from_jacobian(hipStream_t s, const uint32_t* jac, char* out) {
+  hipLaunchKernelGGL(from_jacobian_kernel<F>, dim3(1), dim3(64), 0, s, jac, out);
+}
 void l_fixed_base(hipStream_t s, const uint32_t* base, const uint32_t* scalars, size_t n, char* out_xy,
                   uint8_t* out_inf) {
   hipLaunchKernelGGL((fixed_base_kernel<F, CFG_BITS>), dim3((n + 127) / 128), dim3(128), 0, s, base, scalars, n,
                      out_xy, out_inf);
 }
 #if ZKP_CFG_GROUP == 1
-void l_assemble_g1(hipStream_t s, const char* res, size_t slot, const uint32_t* rs, uint32_t* out, uint32_t* flags,
-                   int c_off_words) {
-  hipLaunchKernelGGL(assemble_g1_kernel, dim3(1), dim3(64), 64 * XB, s, res, slot, rs, out, flags, c_off_words);
+void l_assemble_g1_p1(hipStream_t s, char* res, size_t slot, const uint32_t* rs, uint32_t* out, uint32_t* flags) {
+  hipLaunchKernelGGL(assemble_g1_part1_kernel, dim3(1), dim3(64), 64 * XB, s, res, slot, rs, out, flags);
+}
+void l_assemble_g1_p2(hipStream_t s, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int c_off_words) {
+  hipLaunchKernelGGL(assemble_g1_part2_kernel, dim3(1), dim3(64), 0, s, res, slot, out, flags, c_off_words);
 }
 #else
 void l_assemble_g2(hipStream_t s, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int off) {
@@ -320,11 +341,11 @@ const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
   static const MsmVtbl v = {
       F::N, Affine<F>::BYTES, XYZZ<F>::BYTES, CFG_BITS,
       l_ingest, l_precompute, ZKP_CFG_SYM(msm_accumulate_launch), l_combine, l_pair, l_segsum, l_final, l_identity, l_fold,
-      l_into_affine, l_fixed_base,
+      l_into_affine, l_from_jacobian, l_fixed_base,
 #if ZKP_CFG_GROUP == 1
-      l_assemble_g1, nullptr,
+      l_assemble_g1_p1, l_assemble_g1_p2, nullptr,
 #else
-      nullptr, l_assemble_g2,
+      nullptr, nullptr, l_assemble_g2,
 #endif
   };
   return &v;

@@ -38,11 +38,14 @@ struct MsmVtbl {
   void (*write_identity)(hipStream_t, char* out_xyzz, uint32_t* out_jac);
   void (*fold)(hipStream_t, const uint32_t* pts, int k, uint32_t* out_jac);
   void (*into_affine)(hipStream_t, const uint32_t* jac, uint32_t* xy, uint32_t* inf);
+  void (*from_jacobian)(hipStream_t, const uint32_t* jac, char* out_xyzz);
   void (*fixed_base)(hipStream_t, const uint32_t* base, const uint32_t* scalars, size_t n, char* out_xy,
                      uint8_t* out_inf);
   // Groth16 assembly (groth16.hip): G1 tables implement assemble_g1, G2 tables assemble_g2
-  void (*assemble_g1)(hipStream_t, const char* res, size_t slot, const uint32_t* rs, uint32_t* out, uint32_t* flags,
-                      int c_off_words);
+  // part 1 needs only g_a (slot 0) and g1_b (slot 1): proof.a = affine(g_a); T = s*g_a + r*g1_b -> slot 5.
+  // part 2: C = T + h_acc (slot 3) + l' (slot 4) -> affine.  Split so part 1 overlaps the remaining MSMs.
+  void (*assemble_g1_part1)(hipStream_t, char* res, size_t slot, const uint32_t* rs, uint32_t* out, uint32_t* flags);
+  void (*assemble_g1_part2)(hipStream_t, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int c_off_words);
   void (*assemble_g2)(hipStream_t, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int out_off_words);
 };
 

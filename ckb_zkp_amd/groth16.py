@@ -152,10 +152,22 @@ def generate_parameters(ctx: Context, curve, circuit, alpha: int, beta: int, gam
     )
 
 
-class ProvingKey:
-    """Device-resident proving key + circuit matrices (zkp_groth16_pk_upload)."""
+def assemble(ctx: Context, curve, sums_xyz: np.ndarray, r: int, s: int):
+    """zkp_groth16_assemble: folded partial sums (A|B1|B2|H|L Jacobian) -> (proof limbs, identity flags)."""
+    c = get_curve(curve)
+    out = np.zeros(8 * c.fq_limbs, dtype=np.uint64)
+    inf = np.zeros(3, dtype=np.uint8)
+    rm, sm = fr_to_mont([r], c)[0], fr_to_mont([s], c)[0]
+    _lib.check(ctx.lib.zkp_groth16_assemble(ctx.h, c.cid, _ptr(np.ascontiguousarray(sums_xyz, dtype=np.uint64)),
+                                            _ptr(rm), _ptr(sm), _ptr(out), _ptr(inf)), "zkp_groth16_assemble")
+    return out, inf
 
-    def __init__(self, ctx: Context, params: Parameters, circuit):
+
+class ProvingKey:
+    """Device-resident proving key + circuit matrices (zkp_groth16_pk_upload).
+    matrices_only=True uploads just at/bt/ct (witness_map only) for the base-sharded multi-GPU prover."""
+
+    def __init__(self, ctx: Context, params: Parameters, circuit, matrices_only: bool = False):
         self.ctx, self.params, self.curve = ctx, params, params.curve
         inst = _as_instance(self.curve, circuit, assign=False)
         assert (inst.num_inputs, inst.num_aux, inst.num_constraints()) == \
@@ -176,8 +188,8 @@ class ProvingKey:
             m.row_ptr, m.col, m.coeff = P(rp.astype(np.uint32)), P(col.astype(np.uint32)), P(cf.astype(np.uint64))
         for name in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2"):
             setattr(d, name, P(getattr(params, name).astype(np.uint64)))
-        for name, fld in (("a", "a_query"), ("b_g1", "b_g1_query"), ("b_g2", "b_g2_query"), ("h", "h_query"),
-                          ("l", "l_query")):
+        for name, fld in (() if matrices_only else (("a", "a_query"), ("b_g1", "b_g1_query"), ("b_g2", "b_g2_query"),
+                                                    ("h", "h_query"), ("l", "l_query"))):
             xy, inf = getattr(params, fld)
             setattr(d, f"{name}_query", P(xy.astype(np.uint64)))
             setattr(d, f"{name}_inf", P(inf.astype(np.uint8)) if len(inf) else None)
@@ -221,6 +233,9 @@ class ProvingKey:
                                                 _ptr(inf))
         _lib.check(st, "zkp_groth16_prove")
         return out, inf
+
+    def witness_map_host(self, z_mont: np.ndarray) -> np.ndarray:
+        return self.witness_map(z_mont)
 
     def decode_proof(self, out: np.ndarray, inf) -> Proof:
         c = self.curve

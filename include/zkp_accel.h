@@ -92,6 +92,8 @@ int32_t zkp_msm_g2_dev(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint6
  * the into_repr() map is fused into the digit scan on the device. */
 int32_t zkp_vartime_multiscalar_mul_g1(zkp_ctx* ctx, uint64_t handle, const uint64_t* fr_scalars_host, size_t n,
                                        uint64_t* out_xyz);
+int32_t zkp_vartime_multiscalar_mul_g2(zkp_ctx* ctx, uint64_t handle, const uint64_t* fr_scalars_host, size_t n,
+                                       uint64_t* out_xyz);
 /* fold k Jacobian points (host) into one: the local step after the multi-GPU all-gather of partial MSM
  * results (EC addition is not an RCCL reduction op) */
 int32_t zkp_g1_fold(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz);
@@ -112,7 +114,9 @@ int32_t zkp_fixed_base_mul_g2(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* b
 /* ---- Groth16: replaces zkp_groth16::create_proof (groth16/src/prover.rs:124-211) ---------------
  * The circuit closures stay on the caller's side (Rust); the boundary receives what
  * `ProvingAssignment` holds after synthesis (prover.rs:16-25): the three sparse matrices and the
- * assignment.  Matrices are fixed per circuit -> uploaded with the key. */
+ * assignment.  Matrices are fixed per circuit -> uploaded with the key.
+ * A descriptor with a_query == NULL uploads the matrices only (witness_map works, prove is refused): used by
+ * the base-sharded multi-GPU prover, where every rank holds the matrices and a slice of each query. */
 typedef struct {
   /* CSR over constraints; coeffs Fr Montgomery; col = index into z = input_assignment ++ aux_assignment */
   const uint32_t* row_ptr; /* num_constraints + 1 */
@@ -153,6 +157,14 @@ int32_t zkp_groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_ho
                           const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 int32_t zkp_groth16_prove_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_dev, const uint64_t* r,
                               const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
+
+/* Multi-GPU (one process per GPU, bases sharded by index): every rank computes partial sums with zkp_msm_*,
+ * the host all-gathers them (RCCL / any transport: 5 points, < 2 KiB), folds them with zkp_g*_fold and finishes
+ * here.  sums_xyz: Jacobian Montgomery  g_a (G1) | g1_b (G1) | g2_b (G2) | h_acc (G1) | l_acc (G1)  where the
+ * key-point terms of prover.rs:165-177,183 are already folded in (see DESIGN.md "Folding").  Computes
+ * C = s*g_a + r*g1_b + l_acc + h_acc and the three into_affine() (prover.rs:192-210). */
+int32_t zkp_groth16_assemble(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* sums_xyz, const uint64_t* r,
+                             const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 
 /* ---- introspection for bench.py / rocprof bookkeeping ------------------------------------------ */
 typedef struct {
