@@ -181,38 +181,51 @@ struct Fp {
   }
 };
 
-// Montgomery product a*b*R^-1 mod p (CIOS, no-carry variant: every modulus here has a spare top bit).
+// Montgomery product a*b*R^-1 mod p.
+// Product scanning (column by column) with the running column sum held as a 64-bit accumulator plus a 32-bit
+// overflow counter; every partial product is ONE v_mad_u64_u32 (32x32 + 64 -> 64, carry to VCC) followed by ONE
+// v_addc_co_u32 that banks the carry — 2 VALU instructions per 32x32 product and two v_mov per column, versus
+// ~4.5 per product for the C (CIOS) formulation, whose 64-bit zero-extensions hipcc materialises as v_mov pairs
+// (measured on MI355X: 118-129 G products/s vs 86-95 G for 256-bit fields, 59 vs 44 G for the 384-bit field;
+// tools/ubench/mulasm.hip checks the two formulations against each other).  The modulus limbs are scalar
+// operands (SGPR / constant bus).  All moduli here have a spare top bit, so the result is < 2p and one
+// conditional subtraction finishes the reduction.
+#define ZKP_MAC_VV(acc, ovf, x, y)                                                              \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"             \
+      : "+v"(acc), "+v"(ovf) : "v"(x), "v"(y) : "vcc")
+#define ZKP_MAC_VS(acc, ovf, x, ys)                                                             \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"             \
+      : "+v"(acc), "+v"(ovf) : "v"(x), "s"(ys) : "vcc")
+
 template <class P>
 ZKP_MUL_ATTR Fp<P> fp_mul(Fp<P> a, Fp<P> b) {
   constexpr int N = P::N;
-  uint32_t t[N + 1];
-#pragma unroll
-  for (int j = 0; j <= N; j++) t[j] = 0;
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-      uint64_t x = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
-      t[j] = (uint32_t)x;
-      c = x >> 32;
-    }
-    t[N] += (uint32_t)c;
-    uint32_t m = t[0] * P::INV;
-    c = ((uint64_t)m * P::MOD[0] + t[0]) >> 32;
-#pragma unroll
-    for (int j = 1; j < N; j++) {
-      uint64_t x = (uint64_t)m * P::MOD[j] + t[j] + c;
-      t[j - 1] = (uint32_t)x;
-      c = x >> 32;
-    }
-    uint64_t x = (uint64_t)t[N] + c;
-    t[N - 1] = (uint32_t)x;
-    t[N] = (uint32_t)(x >> 32);
-  }
+  uint32_t m[N];
   Fp<P> r;
+  uint64_t acc = 0;
+  uint32_t ovf = 0;
 #pragma unroll
-  for (int j = 0; j < N; j++) r.v[j] = t[j];
+  for (int k = 0; k < 2 * N - 1; k++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < N) ZKP_MAC_VV(acc, ovf, a.v[i], b.v[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < N && i < k) ZKP_MAC_VS(acc, ovf, m[i], P::MOD[j]);
+    }
+    if (k < N) {
+      m[k] = (uint32_t)acc * P::INV;
+      ZKP_MAC_VS(acc, ovf, m[k], P::MOD[0]);            // low word of the column becomes 0
+    } else {
+      r.v[k - N] = (uint32_t)acc;
+    }
+    acc = (acc >> 32) | ((uint64_t)ovf << 32);
+    ovf = 0;
+  }
+  r.v[N - 1] = (uint32_t)acc;
   return Fp<P>::reduce_once(r);
 }
 
