@@ -297,17 +297,15 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
   if (!prof) {
     ZKP_HIP(hipEventRecord(ctx->ev_fork, st));                       // S is complete
     for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->ws[w].stream, ctx->ev_fork, 0));
+    // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H -> L | ws3: part 1 after A, B1
+    run(2, pk->hB2, Sd, pk->nz + 4, 2);                                            // prover.rs:182-184
     run(0, pk->hA, Sd, pk->nz + 4, 1);                                             // prover.rs:164-167
-    ZKP_HIP(hipEventRecord(ctx->ev_a, ctx->ws[1].stream));
-    run(1, pk->hB1, Sd, pk->nz + 4, 2);                                            // prover.rs:170-177
-    ZKP_HIP(hipEventRecord(ctx->ev_b1, ctx->ws[2].stream));
-    // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~5 ms single-wave chain: start them as soon as
-    // A and B1 exist so they hide under the remaining three MSMs
-    ZKP_HIP(hipStreamWaitEvent(ctx->ws[3].stream, ctx->ev_a, 0));
+    run(1, pk->hB1, Sd, pk->nz + 4, 1);                                            // prover.rs:170-177
+    ZKP_HIP(hipEventRecord(ctx->ev_b1, ctx->ws[1].stream));
+    // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~4 ms single-wave chain: start them as soon as
+    // A and B1 exist so they hide under the remaining MSMs
     ZKP_HIP(hipStreamWaitEvent(ctx->ws[3].stream, ctx->ev_b1, 0));
     v1->assemble_g1_part1(ctx->ws[3].stream, res, slot, rs, proof_dev, flags_dev);
-    run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 1);   // prover.rs:189-190
-    run(2, pk->hB2, Sd, pk->nz + 4, 2);                                            // prover.rs:182-184
   }
   tic();
   uint32_t* h = witness_map_dev<FrP>(ctx, pk, S);
@@ -318,7 +316,7 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
     run(2, pk->hB2, Sd, pk->nz + 4, 0);
   }
   run(3, pk->hH, reinterpret_cast<const uint64_t*>(h), std::min(pk->N, bases_len(ctx, pk->hH)), 0);  // :186-187
-  if (prof) run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 0);
+  run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 0);                        // :189-190
   if (!prof) {
     for (int w = 1; w < zkp_ctx::N_WS; w++) {
       ZKP_HIP(hipEventRecord(ctx->ws[w].done, ctx->ws[w].stream));

@@ -60,7 +60,13 @@ struct BasesEntry {
   }
 };
 
-static int pick_window_bits(size_t n) {
+static int pick_window_bits(size_t n, int group) {
+  if (group == 2) {
+    if (const char* e = getenv("ZKP_MSM_C_G2")) {
+      int c = atoi(e);
+      if (c >= 2 && c <= 22) return c;
+    }
+  }
   if (const char* e = getenv("ZKP_MSM_C")) {
     int c = atoi(e);
     if (c >= 2 && c <= 22) return c;
@@ -76,7 +82,7 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, co
   e->group = group;
   e->vt = msm_vtbl(curve, group);
   e->n = n;
-  e->c = pick_window_bits(n);
+  e->c = pick_window_bits(n, group);
   e->W = (e->vt->scalar_bits + 1 + e->c - 1) / e->c;
   ZKP_REQUIRE((double)n * e->W < 2147483000.0, ZKP_ERR_BAD_ARG);
   const size_t ab = e->vt->aff_bytes;

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const char* __restrict_
   const uint32_t id = order[t];
   const uint32_t e0 = task_start[id], e1 = e0 + task_len[id];
   XYZZ<F> acc = XYZZ<F>::inf();
+  // (a software-pipelined gather of entry e+1 was tried: +20 VGPRs -> scratch spills, no gain; 3 waves/SIMD
+  //  already cover the gather latency)
   for (uint32_t e = e0; e < e1; e++) {
     uint32_t v = vals[e];
     Affine<F> p = Affine<F>::load(table + (size_t)(v & 0x7fffffffu) * Affine<F>::BYTES);

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(128) void precompute_kernel(char* table, size_t n, 
 template <class F>
 __global__ __launch_bounds__(256) void pair_kernel(const char* __restrict__ in, char* __restrict__ out,
                                                    uint32_t count) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= count) return;
   XYZZ<F> a = XYZZ<F>::load(in + (size_t)(2 * k) * XYZZ<F>::BYTES);
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void pair_kernel(const char* __restrict__ in, 
 template <class F>
 __global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ base, SegPlan plan,
                                                      char* __restrict__ partial) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int l = 0;
   while (l + 1 < plan.L && blockIdx.x >= plan.first_block[l + 1]) l++;
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
 template <class F>
 __global__ __launch_bounds__(64) void final_kernel(const char* __restrict__ O, int L, const char* __restrict__ root,
                                                    char* __restrict__ out_xyzz, uint32_t* __restrict__ out_jac) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int t = threadIdx.x;
   XYZZ<F> acc = XYZZ<F>::inf();
