@@ -129,11 +129,16 @@ def main():
         bytes_per_launch = sum(msm_bytes) / 5.0
         avg_ms = acc_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None            # HBM bytes per launch from the PMC passes recorded under profiles/ (not live)
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_accumulate.json")
+        if args.log_n == 20 and c.name == "bn254" and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
         roofline = {"bound": "hbm", "kernel": "accumulate_kernel (MSM bucket accumulation, 5 launches/proof)",
                     "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "note": "integer-VALU bound: see DESIGN.md (mulmod/s vs measured v_mad_u64_u32 roof)"}
+                    "note": "integer-VALU bound (DESIGN.md); traffic = FETCH_SIZE*2 + WRITE_SIZE per launch (rocprofv3 PMC, profiles/): "
+                            "the window-table design gathers each base W=13 times at 128-B fabric granularity"}
 
     # ---- CPU baseline (rank 0, N=1 only): oracle/cpu port of the reference algorithm on a bounded sample
     cpu_baseline = None
