@@ -187,3 +187,53 @@ class Bases:
 
     def msm_affine(self, scalars: np.ndarray, offset: int = 0):
         return self.ctx.into_affine(self.curve, self.group, self.msm(scalars, offset))
+
+
+# ---- Fr vector / polynomial primitives (device pointers), see include/zkp_accel.h
+VEC_MUL, VEC_ADD, VEC_SUB, VEC_SCALE, VEC_AXPY = 0, 1, 2, 3, 4
+
+
+def _ctx_method(fn):
+    setattr(Context, fn.__name__, fn)
+    return fn
+
+
+@_ctx_method
+def fr_vec_op(self, curve, op: int, a_dev: int, b_dev: int | None, out_dev: int, n: int, k_mont: np.ndarray | None = None):
+    k = None if k_mont is None else _c64(k_mont)
+    _lib.check(self.lib.zkp_fr_vec_op_dev(self.h, get_curve(curve).cid, op, C.c_void_p(a_dev),
+                                          C.c_void_p(b_dev or 0), _ptr(k), C.c_void_p(out_dev), n), "zkp_fr_vec_op_dev")
+
+
+@_ctx_method
+def fr_batch_inverse(self, curve, v_dev: int, n: int):
+    _lib.check(self.lib.zkp_fr_batch_inverse_dev(self.h, get_curve(curve).cid, C.c_void_p(v_dev), n),
+               "zkp_fr_batch_inverse_dev")
+
+
+@_ctx_method
+def poly_evaluate(self, curve, p_dev: int, n: int, z_mont: np.ndarray) -> np.ndarray:
+    out = np.zeros(4, dtype=np.uint64)
+    _lib.check(self.lib.zkp_poly_evaluate_dev(self.h, get_curve(curve).cid, C.c_void_p(p_dev), n, _ptr(_c64(z_mont)),
+                                              _ptr(out)), "zkp_poly_evaluate_dev")
+    return out
+
+
+@_ctx_method
+def poly_div_linear(self, curve, p_dev: int, n: int, z_mont: np.ndarray, q_dev: int) -> np.ndarray:
+    out = np.zeros(4, dtype=np.uint64)
+    _lib.check(self.lib.zkp_poly_div_linear_dev(self.h, get_curve(curve).cid, C.c_void_p(p_dev), n, _ptr(_c64(z_mont)),
+                                                C.c_void_p(q_dev), _ptr(out)), "zkp_poly_div_linear_dev")
+    return out
+
+
+def _bases_msm_mont_dev(self, scalars_dev: int, n: int, offset: int = 0) -> np.ndarray:
+    """MSM of device-resident Montgomery Fr coefficients against powers[offset..] (KZG10 commit/open)."""
+    assert self.group == 1
+    out = self._out()
+    _lib.check(self.ctx.lib.zkp_msm_g1_mont_dev(self.ctx.h, self.handle, offset, C.c_void_p(scalars_dev), n, _ptr(out)),
+               "zkp_msm_g1_mont_dev")
+    return out
+
+
+Bases.msm_mont_dev = _bases_msm_mont_dev

@@ -19,6 +19,7 @@ CONFIGS = [(0, 1), (0, 2), (1, 1), (1, 2)]        # (curve, group): BN254 G1/G2,
 # (source, object name, extra flags).  ZKP_INLINE_MUL: the Montgomery multiplier is inlined into the hot loops
 # (NTT butterflies, BN254 bucket accumulation); everywhere else one out-of-line copy per field is called.
 UNITS = [("ntt.hip", "ntt.o", ["-DZKP_INLINE_MUL"]),
+         ("poly.hip", "poly.o", ["-DZKP_INLINE_MUL"]),
          ("msm.hip", "msm.o", []),
          ("groth16.hip", "groth16.o", ["-DZKP_INLINE_MUL"]),
          ("capi.hip", "capi.o", [])]

@@ -249,6 +249,33 @@ int32_t zkp_vartime_multiscalar_mul_g2(zkp_ctx* ctx, uint64_t h, const uint64_t*
   return msm_common(ctx, 2, h, 0, s, n, out, false, true);
 }
 
+int32_t zkp_msm_g1_mont_dev(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t* s, size_t n, uint64_t* out) {
+  return msm_common(ctx, 1, h, off, s, n, out, true, true);
+}
+
+// ------------------------------------------------------------------------------------------- Fr vectors / polynomials
+int32_t zkp_fr_vec_op_dev(zkp_ctx* ctx, zkp_curve_t curve, int32_t op, const uint64_t* a, const uint64_t* b,
+                          const uint64_t* k, uint64_t* out, size_t n) {
+  if (n && (!a || !out)) return ZKP_ERR_BAD_ARG;
+  if (n && op != ZKP_VEC_SCALE && !b) return ZKP_ERR_BAD_ARG;
+  if ((op == ZKP_VEC_SCALE || op == ZKP_VEC_AXPY) && !k) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { fr_vec_op(ctx, curve, op, a, b, k, out, n); });
+}
+int32_t zkp_fr_batch_inverse_dev(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* v, size_t n) {
+  if (n && !v) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { fr_batch_inverse(ctx, curve, v, n); });
+}
+int32_t zkp_poly_evaluate_dev(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* p, size_t n, const uint64_t* z,
+                              uint64_t* eval_out) {
+  if ((n && !p) || !z || !eval_out) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { poly_div_linear(ctx, curve, p, n, z, nullptr, eval_out); });
+}
+int32_t zkp_poly_div_linear_dev(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* p, size_t n, const uint64_t* z,
+                                uint64_t* q, uint64_t* eval_out) {
+  if ((n && !p) || !z || (n > 1 && !q) || q == p) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { poly_div_linear(ctx, curve, p, n, z, n > 1 ? q : nullptr, eval_out); });
+}
+
 int32_t zkp_g1_fold(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz, size_t k, uint64_t* out) {
   if (!out || (k && !xyz)) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { point_fold(ctx, curve, 1, xyz, k, out); });

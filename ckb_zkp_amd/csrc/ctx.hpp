@@ -101,7 +101,7 @@ struct zkp_ctx {
   hipEvent_t ev2 = nullptr, ev3 = nullptr;   // internal per-kernel timing
   bool profiling = false;
   std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)
-  zkp::DevBuf ntt_scratch, ntt_io;
+  zkp::DevBuf ntt_scratch, ntt_io, poly_tmp, poly_consts;
   // MSM scratch
   zkp::DevBuf msm_scalars, msm_misc;
   static constexpr int N_WS = 4;                                // ws[3]: assembly stream (no scratch)

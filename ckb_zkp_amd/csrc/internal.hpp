@@ -8,6 +8,13 @@ namespace zkp {
 void ntt_run(zkp_ctx* ctx, int curve, uint32_t* data_dev, int log_n, int op);
 void ntt_free_tables(zkp_ctx* ctx);
 
+// poly.hip (all pointers device memory unless *_host)
+void fr_vec_op(zkp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, const uint64_t* k_host,
+               uint64_t* out, size_t n);
+void fr_batch_inverse(zkp_ctx* ctx, int curve, uint64_t* v, size_t n);
+void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const uint64_t* z_host, uint64_t* q,
+                     uint64_t* eval_out_host);
+
 // msm.hip
 uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, const uint8_t* inf_host, size_t n);
 void bases_free(zkp_ctx* ctx, uint64_t handle);

@@ -1,0 +1,217 @@
+// Fr polynomial / vector primitives for the Marlin prover's polynomial pipeline and KZG10 openings.
+//
+// Replaces (device side) the ark-poly / ark-ff helpers that /root/reference/marlin/src calls around its MSMs and NTTs:
+//   * `p / (X - z)`  — witness polynomial of KZG10::open          marlin/src/pc/kzg10.rs:211-226
+//   * `p.evaluate(z)` — Horner evaluations                          marlin/src/lib.rs:147-156, pc/kzg10.rs:142
+//   * `fields::batch_inversion`                                     marlin/src/ahp/prover.rs:357-367, ahp/arithmetic.rs:32
+//   * element-wise products / sums / axpy of evaluation vectors     marlin/src/ahp/prover.rs:248-252,298-305,399-411
+// All vectors: Fr Montgomery, AoS 32 B/element, device memory.
+//
+// Synthetic division and evaluation are first-order linear recurrences (q_{i-1} = p_i + z q_i); a single lane needs
+// ~1 us per Montgomery product, so they are evaluated as a three-phase blocked scan: per-chunk local Horner,
+// a short scan over chunk heads with z^CHUNK, then a per-chunk replay — 3 products per coefficient, log depth.
+#include <algorithm>
+
+#include "field.cuh"
+#include "internal.hpp"
+
+namespace zkp {
+
+constexpr int POLY_CHUNK = 32;        // coefficients per lane
+
+template <class P>
+__global__ __launch_bounds__(256) void vec_op_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                     const uint32_t* __restrict__ k, uint32_t* __restrict__ out,
+                                                     size_t n, int op) {
+  using F = Fp<P>;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  F x = F::load(a + i * 8);
+  F r;
+  switch (op) {
+    case 0: r = x * F::load(b + i * 8); break;                       // mul
+    case 1: r = x + F::load(b + i * 8); break;                       // add
+    case 2: r = x - F::load(b + i * 8); break;                       // sub
+    case 3: r = x * F::load(k); break;                               // scale by constant
+    default: r = x + F::load(b + i * 8) * F::load(k); break;         // axpy: a + k*b
+  }
+  r.store(out + i * 8);
+}
+
+// batch inversion, Montgomery's trick per lane over a strided chunk (zeros are left untouched, as ark does)
+template <class P>
+__global__ __launch_bounds__(256) void batch_inverse_kernel(uint32_t* __restrict__ v, size_t n, size_t lanes) {
+  using F = Fp<P>;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lanes) return;
+  // elements t, t+lanes, t+2*lanes, ... (coalesced across lanes)
+  F pref[POLY_CHUNK];
+  F acc = F::one();
+  int cnt = 0;
+  for (size_t i = t; i < n && cnt < POLY_CHUNK; i += lanes, cnt++) {
+    F x = F::load(v + i * 8);
+    pref[cnt] = acc;
+    if (!x.is_zero()) acc = acc * x;
+  }
+  F inv = acc.inv();
+  for (int c = cnt - 1; c >= 0; c--) {
+    size_t i = t + (size_t)c * lanes;
+    F x = F::load(v + i * 8);
+    if (x.is_zero()) continue;
+    (inv * pref[c]).store(v + i * 8);
+    inv = inv * x;
+  }
+}
+
+// phase 1: chunk c covers coefficients [c*CH, min(n,(c+1)*CH)); head[c] = sum_j p_j z^(j - c*CH)
+template <class P>
+__global__ __launch_bounds__(256) void horner_chunk_kernel(const uint32_t* __restrict__ p, size_t n,
+                                                           const uint32_t* __restrict__ z, uint32_t* __restrict__ head,
+                                                           size_t chunks) {
+  using F = Fp<P>;
+  size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= chunks) return;
+  F zz = F::load(z);
+  size_t lo = c * POLY_CHUNK, hi = lo + POLY_CHUNK < n ? lo + POLY_CHUNK : n;
+  F acc = F::zero();
+  for (size_t j = hi; j-- > lo;) acc = acc * zz + F::load(p + j * 8);
+  acc.store(head + c * 8);
+}
+
+// phase 2 (one block): suffix scan over chunk heads: S[c] = head[c] + zc * S[c+1], zc = z^CHUNK.  Hillis-Steele on
+// (value, multiplier) pairs in LDS, processed in tiles of 256 from the top with a running carry.
+template <class P>
+__global__ __launch_bounds__(256) void horner_scan_kernel(uint32_t* __restrict__ head, size_t chunks,
+                                                          const uint32_t* __restrict__ z, uint32_t* __restrict__ total) {
+  using F = Fp<P>;
+  __shared__ uint32_t sv[256 * 8], sm[256 * 8];
+  const int t = threadIdx.x;
+  F zc = F::load(z);
+  for (int i = 0; i < 5; i++) zc = zc.sqr();          // z^32 == z^POLY_CHUNK
+  static_assert(POLY_CHUNK == 32, "zc exponent");
+  F carry = F::zero();                                  // S of the chunk just above the current tile
+  const size_t tiles = (chunks + 255) / 256;
+  for (size_t tile = tiles; tile-- > 0;) {
+    size_t c = tile * 256 + t;
+    // reversed index inside the tile so that the scan runs from high chunk to low chunk
+    F val = c < chunks ? F::load(head + c * 8) : F::zero();
+    F mul = c < chunks ? zc : F::one();
+    // element e = 255 - t  (e = 0 is the highest chunk of the tile)
+    val.store(sv + (255 - t) * 8);
+    mul.store(sm + (255 - t) * 8);
+    __syncthreads();
+    // inclusive scan of affine maps x -> val + mul * x, composed from e = 0 upwards
+    for (int d = 1; d < 256; d <<= 1) {
+      F v2, m2;
+      const int e = t;
+      bool act = e >= d;
+      if (act) {
+        F vlo = F::load(sv + (e - d) * 8), mlo = F::load(sm + (e - d) * 8);
+        F vhi = F::load(sv + e * 8), mhi = F::load(sm + e * 8);
+        v2 = vhi + mhi * vlo;                             // apply lower-index (higher chunk) map first
+        m2 = mhi * mlo;
+      }
+      __syncthreads();
+      if (act) {
+        v2.store(sv + e * 8);
+        m2.store(sm + e * 8);
+      }
+      __syncthreads();
+    }
+    // S for chunk c: element e = 255 - t
+    F v = F::load(sv + (255 - t) * 8), m = F::load(sm + (255 - t) * 8);
+    F s = v + m * carry;
+    if (c < chunks) s.store(head + c * 8);
+    __syncthreads();
+    // carry for the next (lower) tile = S of this tile's lowest chunk (t = 0 -> e = 255)
+    F v0 = F::load(sv + 255 * 8), m0 = F::load(sm + 255 * 8);
+    carry = v0 + m0 * carry;
+    __syncthreads();
+  }
+  if (t == 0 && total) carry.store(total);               // S[0] = p(z)
+}
+
+// phase 3: q_{i-1} = S_i for i = 1..n-1 (quotient of p by (X - z)); S_i = local Horner from the chunk top + z^k S_top
+template <class P>
+__global__ __launch_bounds__(256) void horner_replay_kernel(const uint32_t* __restrict__ p, size_t n,
+                                                            const uint32_t* __restrict__ z,
+                                                            const uint32_t* __restrict__ head, size_t chunks,
+                                                            uint32_t* __restrict__ q) {
+  using F = Fp<P>;
+  size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= chunks) return;
+  F zz = F::load(z);
+  size_t lo = c * POLY_CHUNK, hi = lo + POLY_CHUNK < n ? lo + POLY_CHUNK : n;
+  F acc = c + 1 < chunks ? F::load(head + (c + 1) * 8) : F::zero();      // S_hi
+  for (size_t j = hi; j-- > lo;) {
+    acc = acc * zz + F::load(p + j * 8);                                // S_j
+    if (j >= 1) acc.store(q + (j - 1) * 8);
+  }
+}
+
+template <class P>
+static void poly_div_linear_t(zkp_ctx* ctx, const uint32_t* p, size_t n, const uint32_t* z_dev, uint32_t* q,
+                              uint32_t* eval_dev) {
+  hipStream_t st = ctx->stream;
+  size_t chunks = (n + POLY_CHUNK - 1) / POLY_CHUNK;
+  uint32_t* head = ctx->poly_tmp.as<uint32_t>((chunks + 1) * 8);
+  hipLaunchKernelGGL(horner_chunk_kernel<P>, dim3((chunks + 255) / 256), dim3(256), 0, st, p, n, z_dev, head, chunks);
+  hipLaunchKernelGGL(horner_scan_kernel<P>, dim3(1), dim3(256), 0, st, head, chunks, z_dev, eval_dev);
+  if (q) hipLaunchKernelGGL(horner_replay_kernel<P>, dim3((chunks + 255) / 256), dim3(256), 0, st, p, n, z_dev, head, chunks, q);
+  ZKP_HIP(hipGetLastError());
+}
+
+void fr_vec_op(zkp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, const uint64_t* k_host,
+               uint64_t* out, size_t n) {
+  ZKP_REQUIRE(op >= 0 && op <= 4, ZKP_ERR_BAD_ARG);
+  uint32_t* kd = ctx->poly_consts.as<uint32_t>(64);
+  if (k_host) ZKP_HIP(hipMemcpyAsync(kd, k_host, 32, hipMemcpyHostToDevice, ctx->stream));
+  if (n == 0) return;
+  auto launch = [&](auto tag) {
+    using P = decltype(tag);
+    hipLaunchKernelGGL(vec_op_kernel<P>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const uint32_t*>(a), reinterpret_cast<const uint32_t*>(b), kd,
+                       reinterpret_cast<uint32_t*>(out), n, op);
+  };
+  if (curve == ZKP_BN254) launch(Bn254Fr{});
+  else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});
+  else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+  ZKP_HIP(hipGetLastError());
+}
+
+void fr_batch_inverse(zkp_ctx* ctx, int curve, uint64_t* v, size_t n) {
+  if (n == 0) return;
+  size_t lanes = (n + POLY_CHUNK - 1) / POLY_CHUNK;
+  auto launch = [&](auto tag) {
+    using P = decltype(tag);
+    hipLaunchKernelGGL(batch_inverse_kernel<P>, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<uint32_t*>(v), n, lanes);
+  };
+  if (curve == ZKP_BN254) launch(Bn254Fr{});
+  else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});
+  else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+  ZKP_HIP(hipGetLastError());
+}
+
+// q (n-1 coeffs, may be nullptr) = p / (X - z) ; eval_out (host, may be nullptr) = p(z)
+void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const uint64_t* z_host, uint64_t* q,
+                     uint64_t* eval_out_host) {
+  uint32_t* zd = ctx->poly_consts.as<uint32_t>(64);
+  ZKP_HIP(hipMemcpyAsync(zd, z_host, 32, hipMemcpyHostToDevice, ctx->stream));
+  uint32_t* ev = zd + 16;
+  if (n == 0) {
+    ZKP_HIP(hipMemsetAsync(ev, 0, 32, ctx->stream));
+  } else if (curve == ZKP_BN254) {
+    poly_div_linear_t<Bn254Fr>(ctx, reinterpret_cast<const uint32_t*>(p), n, zd, reinterpret_cast<uint32_t*>(q), ev);
+  } else if (curve == ZKP_BLS12_381) {
+    poly_div_linear_t<Bls381Fr>(ctx, reinterpret_cast<const uint32_t*>(p), n, zd, reinterpret_cast<uint32_t*>(q), ev);
+  } else {
+    throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+  }
+  if (eval_out_host) {
+    ZKP_HIP(hipMemcpyAsync(eval_out_host, ev, 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  }
+}
+
+}  // namespace zkp

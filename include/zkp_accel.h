@@ -65,6 +65,23 @@ int32_t zkp_timer_stop_ms(zkp_ctx* ctx, float* ms);
 int32_t zkp_ntt(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* data_host, uint32_t log_n, int32_t op);
 int32_t zkp_ntt_dev(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* data_dev, uint32_t log_n, int32_t op);
 
+/* ---- Fr vector / polynomial primitives around the Marlin prover's NTTs and KZG10 MSMs (device pointers) -----
+ * vectors: Fr Montgomery, 4 x u64 per element.  k / z: one Fr element in HOST memory. */
+typedef enum { ZKP_VEC_MUL = 0, ZKP_VEC_ADD = 1, ZKP_VEC_SUB = 2, ZKP_VEC_SCALE = 3, ZKP_VEC_AXPY = 4 } zkp_vec_op;
+/* out[i] = a[i]*b[i] | a[i]+b[i] | a[i]-b[i] | k*a[i] | a[i]+k*b[i]   (marlin/src/ahp/prover.rs:248-252,298-305,399-411);
+ * out may alias a or b */
+int32_t zkp_fr_vec_op_dev(zkp_ctx* ctx, zkp_curve_t curve, int32_t op, const uint64_t* a, const uint64_t* b,
+                          const uint64_t* k_host, uint64_t* out, size_t n);
+/* ark_ff::fields::batch_inversion, in place; zeros stay zero (marlin/src/ahp/prover.rs:357-367) */
+int32_t zkp_fr_batch_inverse_dev(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* v, size_t n);
+/* DensePolynomial::evaluate (marlin/src/lib.rs:147-156): eval_out_host = sum_i p[i] z^i */
+int32_t zkp_poly_evaluate_dev(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* p, size_t n, const uint64_t* z_host,
+                              uint64_t* eval_out_host);
+/* KZG10 witness polynomial p / (X - z), remainder discarded (marlin/src/pc/kzg10.rs:211-226):
+ * q_dev receives n-1 coefficients (q_dev != p); eval_out_host (optional) receives p(z) */
+int32_t zkp_poly_div_linear_dev(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* p, size_t n, const uint64_t* z_host,
+                                uint64_t* q_dev, uint64_t* eval_out_host);
+
 /* ---- bases (proving-key queries / SRS powers): upload once, prove many -------------------------
  * xy: n affine points (Montgomery); inf: n flags or NULL.  The library copies (and pre-computes its
  * window tables in HBM); the caller keeps ownership of the host buffers. */
@@ -94,6 +111,10 @@ int32_t zkp_vartime_multiscalar_mul_g1(zkp_ctx* ctx, uint64_t handle, const uint
                                        uint64_t* out_xyz);
 int32_t zkp_vartime_multiscalar_mul_g2(zkp_ctx* ctx, uint64_t handle, const uint64_t* fr_scalars_host, size_t n,
                                        uint64_t* out_xyz);
+/* KZG10::commit / open (marlin/src/pc/kzg10.rs:108-109,137-140): MSM of Montgomery Fr coefficients that are already
+ * on the DEVICE against powers[offset ..] (offset = number of skipped leading zeros) */
+int32_t zkp_msm_g1_mont_dev(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* fr_scalars_dev, size_t n,
+                            uint64_t* out_xyz_host);
 /* fold k Jacobian points (host) into one: the local step after the multi-GPU all-gather of partial MSM
  * results (EC addition is not an RCCL reduction op) */
 int32_t zkp_g1_fold(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz);
