@@ -73,6 +73,7 @@ static int pick_window_bits(size_t n, int group) {
   }
   int lg = 0;
   while (((size_t)2 << lg) <= n) lg++;          // floor(log2 n)
+  if (lg < 63 && (double)n >= 1.41421356 * (double)((size_t)1 << lg)) lg++;   // round(log2 n): 2^20 - 1 -> 20
   return std::min(20, std::max(4, lg));
 }
 

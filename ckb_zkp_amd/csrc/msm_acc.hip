@@ -7,6 +7,8 @@
 //
 // Replaces the bucket loop of ark-ec 0.2 `VariableBaseMSM::multi_scalar_mul`
 // (reference call sites: /root/reference/groth16/src/prover.rs:187,190,220).
+#include <cstdlib>
+
 #include "ec.cuh"
 #include "msm_vtbl.hpp"
 
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const char* __restrict_
                                                          const uint32_t* __restrict__ task_len,
                                                          const uint32_t* __restrict__ task_dst,
                                                          const uint32_t* __restrict__ n_tasks_dev,
-                                                         char* __restrict__ buckets, char* __restrict__ partial) {
+                                                         char* __restrict__ buckets, char* __restrict__ partial, uint32_t idx_mask) {
   using F = CfgF;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *n_tasks_dev) return;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const char* __restrict_
   //  already cover the gather latency)
   for (uint32_t e = e0; e < e1; e++) {
     uint32_t v = vals[e];
-    Affine<F> p = Affine<F>::load(table + (size_t)(v & 0x7fffffffu) * Affine<F>::BYTES);
+    Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
     if (v >> 31) p.y = p.y.neg();
     acc.madd(p);
   }
@@ -59,11 +61,15 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const char* __restrict_
 }
 }  // namespace ZKP_CFG_SYM(cfg)
 
+static uint32_t dbg_mask() {   // ZKP_DEBUG_GATHER_MASK=0xffff: wrong results, cache-resident gathers (profiling experiments only)
+  static uint32_t m = [] { const char* e = getenv("ZKP_DEBUG_GATHER_MASK"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0x7fffffffu; }();
+  return m;
+}
 void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint32_t* order,
                                         const uint32_t* task_start, const uint32_t* task_len, const uint32_t* task_dst,
                                         const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial) {
   hipLaunchKernelGGL(accumulate_kernel, dim3((max_tasks + 255) / 256), dim3(256), 0, s, table, vals, order, task_start,
-                     task_len, task_dst, n_tasks_dev, buckets, partial);
+                     task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
 }
 
 }  // namespace zkp
