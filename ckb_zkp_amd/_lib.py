@@ -88,6 +88,7 @@ SIGNATURES = {
     "zkp_groth16_domain_size": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
     "zkp_groth16_prove": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp]),
     "zkp_groth16_prove_dev": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp]),
+    "zkp_groth16_prove_batch_dev": (C.c_int32, [vp, vp, C.c_size_t, vp, vp, vp, vp, vp]),
     "zkp_groth16_assemble": (C.c_int32, [vp, C.c_int, vp, vp, vp, vp, vp]),
     "zkp_groth16_last_timing": (C.c_int32, [vp, C.POINTER(Groth16Timing)]),
     "zkp_set_profiling": (C.c_int32, [vp, C.c_int32]),

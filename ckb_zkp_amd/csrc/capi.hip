@@ -61,19 +61,23 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
   if (!ctx) return ZKP_ERR_OOM;
   ctx->device = device_id;
   int32_t st = guarded(ctx, [&] {
-    ZKP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ZKP_HIP(hipEventCreate(&ctx->ev0));
     ZKP_HIP(hipEventCreate(&ctx->ev1));
     ZKP_HIP(hipEventCreate(&ctx->ev2));
     ZKP_HIP(hipEventCreate(&ctx->ev3));
-    ZKP_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    ZKP_HIP(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
-    ZKP_HIP(hipEventCreateWithFlags(&ctx->ev_b1, hipEventDisableTiming));
-    for (int i = 0; i < zkp_ctx::N_WS; i++) {
-      ZKP_HIP(hipEventCreateWithFlags(&ctx->ws[i].done, hipEventDisableTiming));
-      if (i > 0) {
-        ZKP_HIP(hipStreamCreateWithFlags(&ctx->ws[i].stream, hipStreamNonBlocking));
-        ctx->ws[i].own_stream = true;
+    for (int l = 0; l < zkp_ctx::N_LANES; l++) {
+      zkp_lane& L = ctx->lanes[l];
+      ZKP_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+      ZKP_HIP(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
+      ZKP_HIP(hipEventCreateWithFlags(&L.ev_a, hipEventDisableTiming));
+      ZKP_HIP(hipEventCreateWithFlags(&L.ev_b1, hipEventDisableTiming));
+      ZKP_HIP(hipHostMalloc(reinterpret_cast<void**>(&L.host_proof), 1100));
+      for (int i = 0; i < zkp_lane::N_WS; i++) {
+        ZKP_HIP(hipEventCreateWithFlags(&L.ws[i].done, hipEventDisableTiming));
+        if (i > 0) {
+          ZKP_HIP(hipStreamCreateWithFlags(&L.ws[i].stream, hipStreamNonBlocking));
+          L.ws[i].own_stream = true;
+        }
       }
     }
   });
@@ -88,42 +92,43 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
 int32_t zkp_ctx_destroy(zkp_ctx* ctx) {
   if (!ctx) return ZKP_ERR_BAD_ARG;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipDeviceSynchronize();
   ntt_free_tables(ctx);
   msm_free_all(ctx);
-  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
-  if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
-  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
-  if (ctx->ev_b1) (void)hipEventDestroy(ctx->ev_b1);
-  for (int i = 0; i < zkp_ctx::N_WS; i++) {
-    if (ctx->ws[i].stream) (void)hipStreamSynchronize(ctx->ws[i].stream);
-    if (ctx->ws[i].done) (void)hipEventDestroy(ctx->ws[i].done);
-    if (ctx->ws[i].own_stream && ctx->ws[i].stream) (void)hipStreamDestroy(ctx->ws[i].stream);
+  for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev2, ctx->ev3})
+    if (e) (void)hipEventDestroy(e);
+  for (int l = 0; l < zkp_ctx::N_LANES; l++) {
+    zkp_lane& L = ctx->lanes[l];
+    for (hipEvent_t e : {L.ev_fork, L.ev_a, L.ev_b1})
+      if (e) (void)hipEventDestroy(e);
+    if (L.host_proof) (void)hipHostFree(L.host_proof);
+    for (int i = 0; i < zkp_lane::N_WS; i++) {
+      if (L.ws[i].done) (void)hipEventDestroy(L.ws[i].done);
+      if (L.ws[i].own_stream && L.ws[i].stream) (void)hipStreamDestroy(L.ws[i].stream);
+    }
+    if (L.own_stream && L.stream) (void)hipStreamDestroy(L.stream);
   }
-  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return ZKP_OK;
 }
 
 int32_t zkp_ctx_set_stream(zkp_ctx* ctx, void* s) {
   return guarded(ctx, [&] {
-    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+    zkp_lane& L = ctx->lanes[0];
+    ZKP_HIP(hipStreamSynchronize(L.stream));
     if (s) {
-      if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-      ctx->stream = reinterpret_cast<hipStream_t>(s);
-      ctx->own_stream = false;
-    } else if (!ctx->own_stream) {
-      ZKP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-      ctx->own_stream = true;
+      if (L.own_stream && L.stream) (void)hipStreamDestroy(L.stream);
+      L.stream = reinterpret_cast<hipStream_t>(s);
+      L.own_stream = false;
+    } else if (!L.own_stream) {
+      ZKP_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+      L.own_stream = true;
     }
   });
 }
 
 int32_t zkp_ctx_sync(zkp_ctx* ctx) {
-  return guarded(ctx, [&] { ZKP_HIP(hipStreamSynchronize(ctx->stream)); });
+  return guarded(ctx, [&] { ZKP_HIP(hipStreamSynchronize(ctx->cur->stream)); });
 }
 
 int32_t zkp_dev_alloc(zkp_ctx* ctx, size_t bytes, void** dptr) {
@@ -135,31 +140,31 @@ int32_t zkp_dev_alloc(zkp_ctx* ctx, size_t bytes, void** dptr) {
 }
 int32_t zkp_dev_free(zkp_ctx* ctx, void* dptr) {
   return guarded(ctx, [&] {
-    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+    ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
     if (dptr) ZKP_HIP(hipFree(dptr));
   });
 }
 int32_t zkp_h2d(zkp_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes && (!dst || !src)) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] {
-    if (bytes) ZKP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+    if (bytes) ZKP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->cur->stream));
+    ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   });
 }
 int32_t zkp_d2h(zkp_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes && (!dst || !src)) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] {
-    if (bytes) ZKP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+    if (bytes) ZKP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->cur->stream));
+    ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   });
 }
 int32_t zkp_timer_start(zkp_ctx* ctx) {
-  return guarded(ctx, [&] { ZKP_HIP(hipEventRecord(ctx->ev0, ctx->stream)); });
+  return guarded(ctx, [&] { ZKP_HIP(hipEventRecord(ctx->ev0, ctx->cur->stream)); });
 }
 int32_t zkp_timer_stop_ms(zkp_ctx* ctx, float* ms) {
   if (!ms) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] {
-    ZKP_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ZKP_HIP(hipEventRecord(ctx->ev1, ctx->cur->stream));
     ZKP_HIP(hipEventSynchronize(ctx->ev1));
     ZKP_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
   });
@@ -186,10 +191,10 @@ int32_t zkp_ntt(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* data, uint32_t log_n,
     ZKP_REQUIRE((int)log_n <= (curve == ZKP_BN254 ? 28 : 32), ZKP_ERR_DOMAIN_TOO_LARGE);
     size_t bytes = ((size_t)1 << log_n) * 32;
     uint32_t* d = ctx->ntt_io.as<uint32_t>(bytes / 4);
-    ZKP_HIP(hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZKP_HIP(hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->cur->stream));
     ntt_run(ctx, curve, d, (int)log_n, op);
-    ZKP_HIP(hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+    ZKP_HIP(hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->cur->stream));
+    ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   });
 }
 
@@ -223,7 +228,7 @@ static int32_t msm_common(zkp_ctx* ctx, int group, uint64_t handle, size_t offse
     const uint64_t* sdev = scalars;
     if (!scalars_on_device && n) {
       uint64_t* d = ctx->msm_scalars.as<uint64_t>(n * 4);
-      ZKP_HIP(hipMemcpyAsync(d, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+      ZKP_HIP(hipMemcpyAsync(d, scalars, n * 32, hipMemcpyHostToDevice, ctx->cur->stream));
       sdev = d;
     }
     msm_run(ctx, handle, offset, sdev, n, montgomery, out);
@@ -334,6 +339,11 @@ int32_t zkp_groth16_prove_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* 
                               const uint64_t* s, uint64_t* proof, uint8_t* inf) {
   if (!pk || !z || !r || !s || !proof || !inf) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { groth16_prove(ctx, pk, z, true, r, s, proof, inf); });
+}
+int32_t zkp_groth16_prove_batch_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint64_t* const* z_dev,
+                                    const uint64_t* r, const uint64_t* s, uint64_t* proofs, uint8_t* inf) {
+  if (!pk || (n && (!z_dev || !r || !s || !proofs || !inf))) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_prove_batch(ctx, pk, n, z_dev, r, s, proofs, inf); });
 }
 int32_t zkp_groth16_assemble(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* sums, const uint64_t* r,
                              const uint64_t* s, uint64_t* proof, uint8_t* inf) {

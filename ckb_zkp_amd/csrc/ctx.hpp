@@ -93,20 +93,35 @@ struct Groth16Timing {
 
 }  // namespace zkp
 
-struct zkp_ctx {
-  int device = 0;
+// Everything one in-flight proof needs: a main stream, MSM workspaces (each with its own stream), NTT scratch.
+// A context owns two lanes so that consecutive proofs overlap (zkp_groth16_prove_batch_dev): the latency-bound
+// tails of proof i run while the throughput-bound kernels of proof i+1 keep the CUs busy.
+struct zkp_lane {
   hipStream_t stream = nullptr;
   bool own_stream = true;
+  static constexpr int N_WS = 4;                                // ws[3]: assembly stream (no scratch)
+  zkp::MsmWorkspace ws[N_WS];                                   // ws[0].stream aliases `stream`
+  zkp::DevBuf ntt_scratch;
+  hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b1 = nullptr;
+  // pinned host landing zone of the async proof read-back
+  uint32_t* host_proof = nullptr;                               // 256 words proof + 4 words flags
+  bool busy = false;
+};
+
+struct zkp_ctx {
+  int device = 0;
+  static constexpr int N_LANES = 2;
+  static constexpr int N_WS = zkp_lane::N_WS;
+  zkp_lane lanes[N_LANES];
+  zkp_lane* cur = &lanes[0];
+  int cur_idx = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // zkp_timer_*
   hipEvent_t ev2 = nullptr, ev3 = nullptr;   // internal per-kernel timing
   bool profiling = false;
   std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)
-  zkp::DevBuf ntt_scratch, ntt_io, poly_tmp, poly_consts;
+  zkp::DevBuf ntt_io, poly_tmp, poly_consts;
   // MSM scratch
   zkp::DevBuf msm_scalars, msm_misc;
-  static constexpr int N_WS = 4;                                // ws[3]: assembly stream (no scratch)
-  zkp::MsmWorkspace ws[N_WS];                                  // ws[0].stream aliases `stream`
-  hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b1 = nullptr;
   std::unordered_map<uint64_t, std::shared_ptr<zkp::BasesEntry>> bases;
   uint64_t next_handle = 1;
   zkp_groth16_timing last_timing{};

@@ -47,11 +47,13 @@ struct zkp_groth16_pk {
   size_t N = 0, nz = 0;
   DevCsr m[3];
   uint64_t hA = 0, hB1 = 0, hB2 = 0, hH = 0, hL = 0;
-  DevBuf abc;        // 3 * N Fr
-  DevBuf S;          // nz + 4 Fr
-  DevBuf results;    // 5 XYZZ (G2-sized slots)
+  struct PerLane {   // per in-flight proof (zkp_ctx lanes)
+    DevBuf abc;      // 3 * N Fr
+    DevBuf S;        // nz + 4 Fr
+    DevBuf results;  // 6 XYZZ (G2-sized slots)
+    DevBuf proof;    // [r, s] + device proof + flags
+  } lane[zkp_ctx::N_LANES];
   DevBuf consts;     // zinv etc.
-  DevBuf proof;      // device proof + flags
 };
 
 namespace zkp {
@@ -125,10 +127,10 @@ static DevCsr upload_csr(zkp_ctx* ctx, const zkp_csr& m, uint32_t rows) {
   if (hipMalloc(&d.row_ptr, ((size_t)rows + 1) * 4) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
   if (hipMalloc(&d.col, std::max<size_t>(d.nnz, 1) * 4) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
   if (hipMalloc(&d.coeff, std::max<size_t>(d.nnz, 1) * 32) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
-  ZKP_HIP(hipMemcpyAsync(d.row_ptr, m.row_ptr, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  ZKP_HIP(hipMemcpyAsync(d.row_ptr, m.row_ptr, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice, ctx->cur->stream));
   if (d.nnz) {
-    ZKP_HIP(hipMemcpyAsync(d.col, m.col, d.nnz * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZKP_HIP(hipMemcpyAsync(d.coeff, m.coeff, d.nnz * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZKP_HIP(hipMemcpyAsync(d.col, m.col, d.nnz * 4, hipMemcpyHostToDevice, ctx->cur->stream));
+    ZKP_HIP(hipMemcpyAsync(d.coeff, m.coeff, d.nnz * 32, hipMemcpyHostToDevice, ctx->cur->stream));
   }
   return d;
 }
@@ -184,19 +186,21 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d) {
     pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL);
   }
   uint32_t* consts = pk->consts.as<uint32_t>(64);
-  if (d->curve == ZKP_BN254) hipLaunchKernelGGL(qap_consts_kernel<Bn254Fr>, dim3(1), dim3(64), 0, ctx->stream, consts, lg);
-  else hipLaunchKernelGGL(qap_consts_kernel<Bls381Fr>, dim3(1), dim3(64), 0, ctx->stream, consts, lg);
+  if (d->curve == ZKP_BN254) hipLaunchKernelGGL(qap_consts_kernel<Bn254Fr>, dim3(1), dim3(64), 0, ctx->cur->stream, consts, lg);
+  else hipLaunchKernelGGL(qap_consts_kernel<Bls381Fr>, dim3(1), dim3(64), 0, ctx->cur->stream, consts, lg);
   ZKP_HIP(hipGetLastError());
-  pk->abc.get(3 * pk->N * 32);
-  pk->S.get((pk->nz + 4) * 32);
-  pk->results.get(6 * 16 * 24 * 4 + 64);
-  pk->proof.get(4096);
-  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& L : pk->lane) {
+    L.abc.get(3 * pk->N * 32);
+    L.S.get((pk->nz + 4) * 32);
+    L.results.get(6 * 16 * 24 * 4 + 64);
+    L.proof.get(4096);
+  }
+  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   return pk.release();
 }
 
 void groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk) {
-  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   for (uint64_t h : {pk->hA, pk->hB1, pk->hB2, pk->hH, pk->hL})
     if (h) ctx->bases.erase(h);
   for (auto& m : pk->m) {
@@ -213,11 +217,11 @@ uint64_t groth16_domain_size(zkp_groth16_pk* pk) { return pk->N; }
 template <class P>
 static uint32_t* witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint32_t* z_dev) {
   const uint32_t N = (uint32_t)pk->N;
-  uint32_t* a = pk->abc.as<uint32_t>(3 * pk->N * 8);
+  uint32_t* a = pk->lane[ctx->cur_idx].abc.as<uint32_t>(3 * pk->N * 8);
   uint32_t* b = a + pk->N * 8;
   uint32_t* c = b + pk->N * 8;
   uint32_t* bufs[3] = {a, b, c};
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->cur->stream;
   for (int k = 0; k < 3; k++)
     hipLaunchKernelGGL(csr_eval_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, st, pk->m[k].row_ptr, pk->m[k].col,
                        pk->m[k].coeff, z_dev, pk->num_constraints, N, pk->num_inputs, k == 0 ? 1 : 0, bufs[k]);
@@ -235,20 +239,23 @@ static uint32_t* witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint32_
 void groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, uint64_t* h, bool on_device) {
   const uint32_t* zd = reinterpret_cast<const uint32_t*>(z);
   if (!on_device) {
-    uint32_t* s = pk->S.as<uint32_t>((pk->nz + 4) * 8);
-    ZKP_HIP(hipMemcpyAsync(s, z, pk->nz * 32, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* s = pk->lane[ctx->cur_idx].S.as<uint32_t>((pk->nz + 4) * 8);
+    ZKP_HIP(hipMemcpyAsync(s, z, pk->nz * 32, hipMemcpyHostToDevice, ctx->cur->stream));
     zd = s;
   }
   uint32_t* hd = pk->curve == ZKP_BN254 ? witness_map_dev<Bn254Fr>(ctx, pk, zd) : witness_map_dev<Bls381Fr>(ctx, pk, zd);
-  ZKP_HIP(hipMemcpyAsync(h, hd, pk->N * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-  if (!on_device) ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  ZKP_HIP(hipMemcpyAsync(h, hd, pk->N * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->cur->stream));
+  if (!on_device) ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
 }
 
+// Enqueue one proof on the current lane (ctx->cur): everything is asynchronous up to and including the read-back of
+// the 3 proof points into the lane's pinned host buffer; prove_finish() synchronises the lane and hands them out.
 template <class FrP>
-static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
-                    const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out) {
+static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
+                          const uint64_t* s) {
   ZKP_REQUIRE(pk->hA != 0, ZKP_ERR_BAD_ARG);             // matrices-only key: use the sharded path
-  hipStream_t st = ctx->stream;
+  zkp_groth16_pk::PerLane& PL = pk->lane[ctx->cur_idx];
+  hipStream_t st = ctx->cur->stream;
   const bool prof = ctx->profiling;
   zkp_groth16_timing tm{};
   hipEvent_t e0 = nullptr, e1 = nullptr, eT0 = nullptr, eT1 = nullptr;
@@ -266,9 +273,9 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
     ZKP_HIP(hipEventElapsedTime(dst, e0, e1));
   };
   ZKP_HIP(hipEventRecord(eT0, st));
-  uint32_t* S = pk->S.as<uint32_t>((pk->nz + 4) * 8);
+  uint32_t* S = PL.S.as<uint32_t>((pk->nz + 4) * 8);
   ZKP_HIP(hipMemcpyAsync(S, z, pk->nz * 32, z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-  uint32_t* rs = pk->proof.as<uint32_t>(1024);         // [r, s] then proof words then flags
+  uint32_t* rs = PL.proof.as<uint32_t>(1024);         // [r, s] then proof words then flags
   uint32_t* proof_dev = rs + 16;
   uint32_t* flags_dev = proof_dev + 256;
   ZKP_HIP(hipMemcpyAsync(rs, r, 32, hipMemcpyHostToDevice, st));
@@ -278,7 +285,7 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
   const MsmVtbl* v1 = msm_vtbl(pk->curve, 1);
   const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
   const size_t slot = v2->xyzz_bytes;                  // uniform slot size
-  char* res = reinterpret_cast<char*>(pk->results.get(6 * slot));
+  char* res = reinterpret_cast<char*>(PL.results.get(6 * slot));
   const uint64_t* Sd = reinterpret_cast<const uint64_t*>(S);
   float acc_ms = 0.f;
   uint64_t ent = 0;
@@ -295,17 +302,17 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
     tm.msm_accumulate_launches += 1;
   };
   if (!prof) {
-    ZKP_HIP(hipEventRecord(ctx->ev_fork, st));                       // S is complete
-    for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->ws[w].stream, ctx->ev_fork, 0));
+    ZKP_HIP(hipEventRecord(ctx->cur->ev_fork, st));                       // S is complete
+    for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[w].stream, ctx->cur->ev_fork, 0));
     // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H -> L | ws3: part 1 after A, B1
     run(2, pk->hB2, Sd, pk->nz + 4, 2);                                            // prover.rs:182-184
     run(0, pk->hA, Sd, pk->nz + 4, 1);                                             // prover.rs:164-167
     run(1, pk->hB1, Sd, pk->nz + 4, 1);                                            // prover.rs:170-177
-    ZKP_HIP(hipEventRecord(ctx->ev_b1, ctx->ws[1].stream));
+    ZKP_HIP(hipEventRecord(ctx->cur->ev_b1, ctx->cur->ws[1].stream));
     // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~4 ms single-wave chain: start them as soon as
     // A and B1 exist so they hide under the remaining MSMs
-    ZKP_HIP(hipStreamWaitEvent(ctx->ws[3].stream, ctx->ev_b1, 0));
-    v1->assemble_g1_part1(ctx->ws[3].stream, res, slot, rs, proof_dev, flags_dev);
+    ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_b1, 0));
+    v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, proof_dev, flags_dev);
   }
   tic();
   uint32_t* h = witness_map_dev<FrP>(ctx, pk, S);
@@ -319,8 +326,8 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
   run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 0);                        // :189-190
   if (!prof) {
     for (int w = 1; w < zkp_ctx::N_WS; w++) {
-      ZKP_HIP(hipEventRecord(ctx->ws[w].done, ctx->ws[w].stream));
-      ZKP_HIP(hipStreamWaitEvent(st, ctx->ws[w].done, 0));
+      ZKP_HIP(hipEventRecord(ctx->cur->ws[w].done, ctx->cur->ws[w].stream));
+      ZKP_HIP(hipStreamWaitEvent(st, ctx->cur->ws[w].done, 0));
     }
   }
   tm.ms_msm_accumulate = acc_ms;
@@ -334,27 +341,36 @@ static void prove_t(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_
   ZKP_HIP(hipGetLastError());
   toc(&tm.ms_assemble);
   const size_t proof_words = 4 * (size_t)v1->fN + 2 * (size_t)v2->fN;
-  uint32_t flags_host[4] = {0, 0, 0, 0};
-  ZKP_HIP(hipMemcpyAsync(proof_out, proof_dev, proof_words * 4, hipMemcpyDeviceToHost, st));
-  ZKP_HIP(hipMemcpyAsync(flags_host, flags_dev, 12, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(ctx->cur->host_proof, proof_dev, proof_words * 4, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(ctx->cur->host_proof + 256, flags_dev, 12, hipMemcpyDeviceToHost, st));
   ZKP_HIP(hipEventRecord(eT1, st));
-  ZKP_HIP(hipStreamSynchronize(st));
-  ZKP_HIP(hipEventElapsedTime(&tm.ms_total, eT0, eT1));
-  for (int i = 0; i < 3; i++) inf_out[i] = (uint8_t)flags_host[i];
-  ctx->last_timing = tm;
-  (void)hipEventDestroy(eT0);
-  (void)hipEventDestroy(eT1);
+  ctx->cur->busy = true;
   if (prof) {
+    ZKP_HIP(hipStreamSynchronize(st));
+    ZKP_HIP(hipEventElapsedTime(&tm.ms_total, eT0, eT1));
+    ctx->last_timing = tm;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
   }
+  (void)hipEventDestroy(eT0);
+  (void)hipEventDestroy(eT1);
+}
+
+static void prove_finish(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t* proof_out, uint8_t* inf_out) {
+  const MsmVtbl* v1 = msm_vtbl(pk->curve, 1);
+  const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
+  const size_t proof_words = 4 * (size_t)v1->fN + 2 * (size_t)v2->fN;
+  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
+  memcpy(proof_out, ctx->cur->host_proof, proof_words * 4);
+  for (int i = 0; i < 3; i++) inf_out[i] = (uint8_t)ctx->cur->host_proof[256 + i];
+  ctx->cur->busy = false;
 }
 
 void groth16_assemble(zkp_ctx* ctx, int curve, const uint64_t* sums, const uint64_t* r, const uint64_t* s,
                       uint64_t* proof_out, uint8_t* inf_out) {
   const MsmVtbl* v1 = msm_vtbl(curve, 1);
   const MsmVtbl* v2 = msm_vtbl(curve, 2);
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->cur->stream;
   const size_t slot = v2->xyzz_bytes;
   const size_t j1 = 3 * (size_t)v1->fN, j2 = 3 * (size_t)v2->fN;          // words
   const size_t in_words = 4 * j1 + j2;
@@ -383,8 +399,46 @@ void groth16_assemble(zkp_ctx* ctx, int curve, const uint64_t* sums, const uint6
 
 void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
                    const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out) {
-  if (pk->curve == ZKP_BN254) prove_t<Bn254Fr>(ctx, pk, z, z_on_device, r, s, proof_out, inf_out);
-  else prove_t<Bls381Fr>(ctx, pk, z, z_on_device, r, s, proof_out, inf_out);
+  ctx->cur = &ctx->lanes[0];
+  ctx->cur_idx = 0;
+  if (pk->curve == ZKP_BN254) prove_enqueue<Bn254Fr>(ctx, pk, z, z_on_device, r, s);
+  else prove_enqueue<Bls381Fr>(ctx, pk, z, z_on_device, r, s);
+  prove_finish(ctx, pk, proof_out, inf_out);
+}
+
+// n proofs, software-pipelined over the two lanes: proof i+1 is enqueued before proof i is awaited, so the
+// latency-bound tails (bucket reduction, assembly) of one proof overlap the throughput-bound kernels of the next.
+void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint64_t* const* z_dev, const uint64_t* r,
+                         const uint64_t* s, uint64_t* proofs_out, uint8_t* inf_out) {
+  const MsmVtbl* v1 = msm_vtbl(pk->curve, 1);
+  const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
+  const size_t pw64 = (4 * (size_t)v1->fN + 2 * (size_t)v2->fN) / 2;
+  const bool prof = ctx->profiling;
+  size_t pending[zkp_ctx::N_LANES] = {0, 0};
+  auto select = [&](int l) {
+    ctx->cur = &ctx->lanes[l];
+    ctx->cur_idx = l;
+  };
+  try {
+    for (size_t i = 0; i < n; i++) {
+      const int l = prof ? 0 : (int)(i % zkp_ctx::N_LANES);
+      select(l);
+      if (ctx->cur->busy) prove_finish(ctx, pk, proofs_out + pending[l] * pw64, inf_out + pending[l] * 3);
+      if (pk->curve == ZKP_BN254) prove_enqueue<Bn254Fr>(ctx, pk, z_dev[i], true, r + 4 * i, s + 4 * i);
+      else prove_enqueue<Bls381Fr>(ctx, pk, z_dev[i], true, r + 4 * i, s + 4 * i);
+      pending[l] = i;
+    }
+    for (int l = 0; l < zkp_ctx::N_LANES; l++) {
+      select(l);
+      if (ctx->cur->busy) prove_finish(ctx, pk, proofs_out + pending[l] * pw64, inf_out + pending[l] * 3);
+    }
+  } catch (...) {
+    (void)hipDeviceSynchronize();
+    for (auto& L : ctx->lanes) L.busy = false;
+    select(0);
+    throw;
+  }
+  select(0);
 }
 
 }  // namespace zkp

@@ -39,6 +39,8 @@ void groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, ui
 void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
                    const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 
+void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint64_t* const* z_dev, const uint64_t* r,
+                         const uint64_t* s, uint64_t* proofs_out, uint8_t* inf_out);
 void groth16_assemble(zkp_ctx* ctx, int curve, const uint64_t* sums_xyz, const uint64_t* r, const uint64_t* s,
                       uint64_t* proof_out, uint8_t* inf_out);
 

@@ -90,15 +90,15 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, co
   size_t bytes = std::max<size_t>(1, n) * e->W * ab;
   if (hipMalloc(&e->table, bytes) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
   if (n) {
-    ZKP_HIP(hipMemcpyAsync(e->table, xy, n * ab, hipMemcpyHostToDevice, ctx->stream));
+    ZKP_HIP(hipMemcpyAsync(e->table, xy, n * ab, hipMemcpyHostToDevice, ctx->cur->stream));
     if (inf) {
       if (hipMalloc(&e->inf, n) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
-      ZKP_HIP(hipMemcpyAsync(e->inf, inf, n, hipMemcpyHostToDevice, ctx->stream));
-      e->vt->ingest(ctx->stream, e->table, e->inf, n);
+      ZKP_HIP(hipMemcpyAsync(e->inf, inf, n, hipMemcpyHostToDevice, ctx->cur->stream));
+      e->vt->ingest(ctx->cur->stream, e->table, e->inf, n);
     }
-    e->vt->precompute(ctx->stream, e->table, n, e->c, e->W);
+    e->vt->precompute(ctx->cur->stream, e->table, n, e->c, e->W);
     ZKP_HIP(hipGetLastError());
-    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+    ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   }
   uint64_t h = ctx->next_handle++;
   ctx->bases[h] = e;
@@ -111,7 +111,7 @@ static std::shared_ptr<BasesEntry> get_bases(zkp_ctx* ctx, uint64_t handle) {
   return it->second;
 }
 void bases_free(zkp_ctx* ctx, uint64_t handle) {
-  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   if (ctx->bases.erase(handle) == 0) throw StatusError{ZKP_ERR_BAD_HANDLE};
 }
 size_t bases_len(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->n; }
@@ -248,8 +248,8 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
              uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries, int ws_idx) {
   auto be = get_bases(ctx, handle);
   const MsmVtbl* vt = be->vt;
-  MsmWorkspace& ws = ctx->ws[ws_idx];
-  hipStream_t st = ws_idx == 0 ? ctx->stream : ws.stream;
+  MsmWorkspace& ws = ctx->cur->ws[ws_idx];
+  hipStream_t st = ws_idx == 0 ? ctx->cur->stream : ws.stream;
   const size_t XB = vt->xyzz_bytes;
   const size_t jac_words = 3 * (size_t)vt->fN;
   uint32_t* out_jac = ws.out.as<uint32_t>(64 * 4);
@@ -367,24 +367,24 @@ void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz, size_t 
   const MsmVtbl* vt = msm_vtbl(curve, group);
   size_t words = 3 * (size_t)vt->fN;
   uint32_t* d = ctx->msm_misc.as<uint32_t>((k + 1) * words);
-  if (k) ZKP_HIP(hipMemcpyAsync(d + words, xyz, k * words * 4, hipMemcpyHostToDevice, ctx->stream));
-  vt->fold(ctx->stream, d + words, (int)k, d);
+  if (k) ZKP_HIP(hipMemcpyAsync(d + words, xyz, k * words * 4, hipMemcpyHostToDevice, ctx->cur->stream));
+  vt->fold(ctx->cur->stream, d + words, (int)k, d);
   ZKP_HIP(hipGetLastError());
-  ZKP_HIP(hipMemcpyAsync(out, d, words * 4, hipMemcpyDeviceToHost, ctx->stream));
-  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  ZKP_HIP(hipMemcpyAsync(out, d, words * 4, hipMemcpyDeviceToHost, ctx->cur->stream));
+  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
 }
 
 void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz, uint64_t* xy_out, uint8_t* inf_out) {
   const MsmVtbl* vt = msm_vtbl(curve, group);
   size_t jw = 3 * (size_t)vt->fN, aw = 2 * (size_t)vt->fN;
   uint32_t* d = ctx->msm_misc.as<uint32_t>(jw + aw + 4);
-  ZKP_HIP(hipMemcpyAsync(d, xyz, jw * 4, hipMemcpyHostToDevice, ctx->stream));
-  vt->into_affine(ctx->stream, d, d + jw, d + jw + aw);
+  ZKP_HIP(hipMemcpyAsync(d, xyz, jw * 4, hipMemcpyHostToDevice, ctx->cur->stream));
+  vt->into_affine(ctx->cur->stream, d, d + jw, d + jw + aw);
   ZKP_HIP(hipGetLastError());
   uint32_t flag = 0;
-  ZKP_HIP(hipMemcpyAsync(xy_out, d + jw, aw * 4, hipMemcpyDeviceToHost, ctx->stream));
-  ZKP_HIP(hipMemcpyAsync(&flag, d + jw + aw, 4, hipMemcpyDeviceToHost, ctx->stream));
-  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  ZKP_HIP(hipMemcpyAsync(xy_out, d + jw, aw * 4, hipMemcpyDeviceToHost, ctx->cur->stream));
+  ZKP_HIP(hipMemcpyAsync(&flag, d + jw + aw, 4, hipMemcpyDeviceToHost, ctx->cur->stream));
+  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   *inf_out = (uint8_t)flag;
 }
 
@@ -398,14 +398,14 @@ void fixed_base_mul(zkp_ctx* ctx, int curve, int group, const uint64_t* base_xy,
   char* d_sc = d_base + ab;
   char* d_out = d_sc + n * 32;
   uint8_t* d_inf = reinterpret_cast<uint8_t*>(d_out + n * ab);
-  ZKP_HIP(hipMemcpyAsync(d_base, base_xy, ab, hipMemcpyHostToDevice, ctx->stream));
-  ZKP_HIP(hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  vt->fixed_base(ctx->stream, reinterpret_cast<const uint32_t*>(d_base), reinterpret_cast<const uint32_t*>(d_sc), n,
+  ZKP_HIP(hipMemcpyAsync(d_base, base_xy, ab, hipMemcpyHostToDevice, ctx->cur->stream));
+  ZKP_HIP(hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->cur->stream));
+  vt->fixed_base(ctx->cur->stream, reinterpret_cast<const uint32_t*>(d_base), reinterpret_cast<const uint32_t*>(d_sc), n,
                  d_out, d_inf);
   ZKP_HIP(hipGetLastError());
-  ZKP_HIP(hipMemcpyAsync(out_xy, d_out, n * ab, hipMemcpyDeviceToHost, ctx->stream));
-  ZKP_HIP(hipMemcpyAsync(out_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
-  ZKP_HIP(hipStreamSynchronize(ctx->stream));
+  ZKP_HIP(hipMemcpyAsync(out_xy, d_out, n * ab, hipMemcpyDeviceToHost, ctx->cur->stream));
+  ZKP_HIP(hipMemcpyAsync(out_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->cur->stream));
+  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
 }
 
 }  // namespace zkp

@@ -121,7 +121,7 @@ static NttTables& get_tables(zkp_ctx* ctx, int curve, int log_n) {
   t.sub_fwd = p; p += subn * 8;
   t.sub_inv = p; p += subn * 8;
   t.n_inv = consts + 6 * 8;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->cur->stream;
   hipLaunchKernelGGL(ntt_setup_kernel<P>, dim3(1), dim3(64), 0, s, consts, log_n, t.h);
   auto gen = [&](uint32_t* out, uint32_t* base, uint32_t* mult, size_t cnt) {
     hipLaunchKernelGGL(pow_table_kernel<P>, dim3((cnt + 255) / 256), dim3(256), 0, s, out, base, mult, (uint32_t)cnt);
@@ -137,6 +137,7 @@ static NttTables& get_tables(zkp_ctx* ctx, int curve, int log_n) {
   gen(t.sub_fwd, consts + 7 * 8, nullptr, subn);
   gen(t.sub_inv, consts + 8 * 8, nullptr, subn);
   ZKP_HIP(hipGetLastError());
+  ZKP_HIP(hipStreamSynchronize(s));      // one-time: the tables are shared by every lane / stream afterwards
   ctx->ntt_tables[key] = t;
   return ctx->ntt_tables[key];
 }
@@ -263,14 +264,14 @@ static void ntt_plan(int log_n, int* S, int* P) {
   *P = p;
 }
 
-// data: N elements (device).  In place from the caller's view; uses ctx->ntt_scratch.
+// data: N elements (device).  In place from the caller's view; uses ctx->cur->ntt_scratch.
 template <class P>
 void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* data, int log_n, int op) {
   ZKP_REQUIRE(log_n <= P::TWO_ADICITY, ZKP_ERR_DOMAIN_TOO_LARGE);
   if (log_n == 0) return;  // size-1 transform is the identity (coset scale by g^0, 1/N = 1)
   NttTables& t = get_tables<P>(ctx, curve, log_n);
   const size_t N = (size_t)1 << log_n;
-  uint32_t* scratch = ctx->ntt_scratch.as<uint32_t>(N * 8);
+  uint32_t* scratch = ctx->cur->ntt_scratch.as<uint32_t>(N * 8);
   int S[8], np;
   ntt_plan(log_n, S, &np);
   const bool inverse = (op == ZKP_NTT_IFFT || op == ZKP_NTT_COSET_IFFT);
@@ -309,12 +310,12 @@ void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* data, int log_n, int op) {
     const int tile = 1 << (S[p] + logC);
     const size_t lds_bytes = (size_t)tile * 32 + ((size_t)1 << S[p]) / 2 * 32 + 32;
     const uint32_t grid = (uint32_t)(N >> (S[p] + logC));
-    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid), dim3(NTT_THREADS), lds_bytes, ctx->stream, cur, dst, a);
+    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid), dim3(NTT_THREADS), lds_bytes, ctx->cur->stream, cur, dst, a);
     cur = dst;
     logB += S[p];
   }
   ZKP_HIP(hipGetLastError());
-  if (cur != data) ZKP_HIP(hipMemcpyAsync(data, cur, N * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  if (cur != data) ZKP_HIP(hipMemcpyAsync(data, cur, N * 32, hipMemcpyDeviceToDevice, ctx->cur->stream));
 }
 
 void ntt_run(zkp_ctx* ctx, int curve, uint32_t* data, int log_n, int op) {

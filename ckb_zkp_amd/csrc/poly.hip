@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void horner_replay_kernel(const uint32_t* __re
 template <class P>
 static void poly_div_linear_t(zkp_ctx* ctx, const uint32_t* p, size_t n, const uint32_t* z_dev, uint32_t* q,
                               uint32_t* eval_dev) {
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->cur->stream;
   size_t chunks = (n + POLY_CHUNK - 1) / POLY_CHUNK;
   uint32_t* head = ctx->poly_tmp.as<uint32_t>((chunks + 1) * 8);
   hipLaunchKernelGGL(horner_chunk_kernel<P>, dim3((chunks + 255) / 256), dim3(256), 0, st, p, n, z_dev, head, chunks);
@@ -165,11 +165,11 @@ void fr_vec_op(zkp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_
                uint64_t* out, size_t n) {
   ZKP_REQUIRE(op >= 0 && op <= 4, ZKP_ERR_BAD_ARG);
   uint32_t* kd = ctx->poly_consts.as<uint32_t>(64);
-  if (k_host) ZKP_HIP(hipMemcpyAsync(kd, k_host, 32, hipMemcpyHostToDevice, ctx->stream));
+  if (k_host) ZKP_HIP(hipMemcpyAsync(kd, k_host, 32, hipMemcpyHostToDevice, ctx->cur->stream));
   if (n == 0) return;
   auto launch = [&](auto tag) {
     using P = decltype(tag);
-    hipLaunchKernelGGL(vec_op_kernel<P>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(vec_op_kernel<P>, dim3((n + 255) / 256), dim3(256), 0, ctx->cur->stream,
                        reinterpret_cast<const uint32_t*>(a), reinterpret_cast<const uint32_t*>(b), kd,
                        reinterpret_cast<uint32_t*>(out), n, op);
   };
@@ -184,7 +184,7 @@ void fr_batch_inverse(zkp_ctx* ctx, int curve, uint64_t* v, size_t n) {
   size_t lanes = (n + POLY_CHUNK - 1) / POLY_CHUNK;
   auto launch = [&](auto tag) {
     using P = decltype(tag);
-    hipLaunchKernelGGL(batch_inverse_kernel<P>, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(batch_inverse_kernel<P>, dim3((lanes + 255) / 256), dim3(256), 0, ctx->cur->stream,
                        reinterpret_cast<uint32_t*>(v), n, lanes);
   };
   if (curve == ZKP_BN254) launch(Bn254Fr{});
@@ -197,10 +197,10 @@ void fr_batch_inverse(zkp_ctx* ctx, int curve, uint64_t* v, size_t n) {
 void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const uint64_t* z_host, uint64_t* q,
                      uint64_t* eval_out_host) {
   uint32_t* zd = ctx->poly_consts.as<uint32_t>(64);
-  ZKP_HIP(hipMemcpyAsync(zd, z_host, 32, hipMemcpyHostToDevice, ctx->stream));
+  ZKP_HIP(hipMemcpyAsync(zd, z_host, 32, hipMemcpyHostToDevice, ctx->cur->stream));
   uint32_t* ev = zd + 16;
   if (n == 0) {
-    ZKP_HIP(hipMemsetAsync(ev, 0, 32, ctx->stream));
+    ZKP_HIP(hipMemsetAsync(ev, 0, 32, ctx->cur->stream));
   } else if (curve == ZKP_BN254) {
     poly_div_linear_t<Bn254Fr>(ctx, reinterpret_cast<const uint32_t*>(p), n, zd, reinterpret_cast<uint32_t*>(q), ev);
   } else if (curve == ZKP_BLS12_381) {
@@ -209,8 +209,8 @@ void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const
     throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
   }
   if (eval_out_host) {
-    ZKP_HIP(hipMemcpyAsync(eval_out_host, ev, 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZKP_HIP(hipStreamSynchronize(ctx->stream));
+    ZKP_HIP(hipMemcpyAsync(eval_out_host, ev, 32, hipMemcpyDeviceToHost, ctx->cur->stream));
+    ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   }
 }
 

@@ -237,6 +237,20 @@ class ProvingKey:
     def witness_map_host(self, z_mont: np.ndarray) -> np.ndarray:
         return self.witness_map(z_mont)
 
+    def prove_batch_raw(self, z_devs, r_mont: np.ndarray, s_mont: np.ndarray):
+        """zkp_groth16_prove_batch_dev: n proofs pipelined over two lanes -> (n x proof limbs, n x 3 flags)."""
+        n = len(z_devs)
+        words = 8 * self.curve.fq_limbs
+        out = np.zeros((n, words), dtype=np.uint64)
+        inf = np.zeros((n, 3), dtype=np.uint8)
+        zp = (C.c_void_p * n)(*[C.c_void_p(z) for z in z_devs])
+        r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64).reshape(n, 4)
+        s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64).reshape(n, 4)
+        _lib.check(self.ctx.lib.zkp_groth16_prove_batch_dev(self.ctx.h, self.h, n, C.cast(zp, C.c_void_p), _ptr(r_mont),
+                                                            _ptr(s_mont), _ptr(out), _ptr(inf)),
+                   "zkp_groth16_prove_batch_dev")
+        return out, inf
+
     def decode_proof(self, out: np.ndarray, inf) -> Proof:
         c = self.curve
         f = c.fq_limbs

@@ -179,6 +179,13 @@ int32_t zkp_groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_ho
 int32_t zkp_groth16_prove_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_dev, const uint64_t* r,
                               const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 
+/* Throughput mode: n independent proofs with the same key, software-pipelined inside the library over two
+ * "lanes" (stream sets + scratch), so that the latency-bound tail of proof i (log-depth bucket reduction, the two
+ * dynamic scalar multiplications of the assembly) overlaps the throughput-bound kernels of proof i+1.
+ * z_dev: n device pointers (may repeat); r, s: n x 4 limbs (host); proofs_out: n x (A|B|C); inf_out: n x 3. */
+int32_t zkp_groth16_prove_batch_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint64_t* const* z_dev,
+                                    const uint64_t* r, const uint64_t* s, uint64_t* proofs_out, uint8_t* inf_out);
+
 /* Multi-GPU (one process per GPU, bases sharded by index): every rank computes partial sums with zkp_msm_*,
  * the host all-gathers them (RCCL / any transport: 5 points, < 2 KiB), folds them with zkp_g*_fold and finishes
  * here.  sums_xyz: Jacobian Montgomery  g_a (G1) | g1_b (G1) | g2_b (G2) | h_acc (G1) | l_acc (G1)  where the

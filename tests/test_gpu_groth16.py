@@ -101,3 +101,37 @@ def test_mimc_chain_proof_trapdoor(ctx, curve, k):
         assert h == h_exp
     finally:
         pk.free()
+
+
+def test_batch_prove_equals_sequential(ctx):
+    """zkp_groth16_prove_batch_dev (two proofs in flight on two lanes) returns exactly the proofs of n blocking calls,
+    for odd/even n, distinct witnesses and distinct (r, s) per proof."""
+    import numpy as np
+    from ckb_zkp_amd.circuits import samples_for_domain
+    curve = "bn254"
+    S = samples_for_domain(11)
+    insts = [mimc_chain_instance(curve, S, seed=0xC0FFEE)]
+    params = groth16.generate_parameters(ctx, curve, insts[0], **TOXIC)
+    pk = groth16.ProvingKey(ctx, params, insts[0])
+    c = params.curve
+    try:
+        # second witness for the same circuit: same constants, different preimages
+        from ckb_zkp_amd.circuits import MimcChain
+        from ckb_zkp_amd.r1cs import ConstraintSystem
+        rnd = random.Random(8)
+        cs = ConstraintSystem(curve, True)
+        MimcChain(curve, insts[0].constants, [(rnd.randrange(c.r), rnd.randrange(c.r)) for _ in range(S)]).generate_constraints(cs)
+        zs = [codec.fr_to_mont(insts[0].z, c).reshape(-1, 4), codec.fr_to_mont(cs.full_assignment(), c).reshape(-1, 4)]
+        zd = [ctx.to_device(z) for z in zs]
+        for n in (1, 2, 5):
+            rs = [rnd.randrange(c.r) for _ in range(n)]
+            ss = [rnd.randrange(c.r) for _ in range(n)]
+            rm, sm = codec.fr_to_mont(rs, c), codec.fr_to_mont(ss, c)
+            out, inf = pk.prove_batch_raw([zd[i % 2] for i in range(n)], rm, sm)
+            for i in range(n):
+                o1, i1 = pk.prove_raw(zd[i % 2], rm[i], sm[i], z_on_device=True)
+                assert np.array_equal(out[i], o1) and np.array_equal(inf[i], i1), (n, i)
+        for d in zd:
+            ctx.dev_free(d)
+    finally:
+        pk.free()
