@@ -33,7 +33,8 @@ namespace ZKP_CFG_SYM(cfg) {}
 using namespace ZKP_CFG_SYM(cfg);
 
 namespace ZKP_CFG_SYM(cfg) {
-__global__ __launch_bounds__(256) void accumulate_kernel(const char* __restrict__ table,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __restrict__ table,
                                                          const uint32_t* __restrict__ vals,
                                                          const uint32_t* __restrict__ order,
                                                          const uint32_t* __restrict__ task_start,
@@ -68,8 +69,15 @@ static uint32_t dbg_mask() {   // ZKP_DEBUG_GATHER_MASK=0xffff: wrong results, c
 void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint32_t* order,
                                         const uint32_t* task_start, const uint32_t* task_len, const uint32_t* task_dst,
                                         const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial) {
-  hipLaunchKernelGGL(accumulate_kernel, dim3((max_tasks + 255) / 256), dim3(256), 0, s, table, vals, order, task_start,
-                     task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
+  // G2: 1 wave/SIMD (VGPRs + AGPRs as spill space, default) vs 2 waves/SIMD (256 VGPRs + 704 B scratch): the latter makes
+  // the kernel itself 7 % faster but the whole proof 8 % slower (it starves the concurrent streams) — ZKP_G2_ACC_OCC=1|2
+  static const int occ = [] { const char* e = getenv("ZKP_G2_ACC_OCC"); return e ? atoi(e) : 1; }();
+  if (ZKP_CFG_GROUP == 2 && occ == 2)
+    hipLaunchKernelGGL(accumulate_kernel<2>, dim3((max_tasks + 255) / 256), dim3(256), 0, s, table, vals, order,
+                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
+  else
+    hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), 0, s, table, vals, order,
+                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
 }
 
 }  // namespace zkp
