@@ -85,7 +85,7 @@ struct MsmWorkspace {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t done = nullptr;
-  DevBuf keys, vals, keys2, vals2, sort_tmp, offsets, buckets, tmp, out, sched, scan_tmp, partial;
+  DevBuf keys, vals, keys2, vals2, sort_tmp, offsets, buckets, tmp, out, sched, scan_tmp, scan_tmp2, partial;
 };
 struct Groth16Timing {
   zkp_groth16_timing t{};

@@ -14,7 +14,8 @@
 //                         (bucket |d_w|-1, point w*n+i, sign) — all windows share ONE bucket set because
 //                         the window weight already lives in T.  Coalesced 32 B/scalar read, 8 B/entry
 //                         written.  Identity bases / zero digits emit a sentinel key.
-//     K6  sort by bucket  radix sort of (key, val) on c bits (rocPRIM device radix sort as scaffolding).
+//     K6  group by bucket hand-written two-level counting sort (LDS histograms + LDS-atomic scatter); also yields
+//                         the start/end of every bucket.
 //     K7  accumulate      one lane per bucket walks its run of the sorted list: gather T[val] (64 B,
 //                         negate y on sign) and mixed-add into an XYZZ accumulator held in VGPRs.
 //     K8  reduce          sum_b (b+1) B_b  with log-depth kernels only: pairwise-sum pyramid A^(l+1)_k =
@@ -22,8 +23,6 @@
 //                         sum_l 2^l O_l + root.  No running sums, no Horner over windows.
 //
 // The result is a group element: any correct schedule is bit-identical after `into_affine()`.
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -156,15 +155,181 @@ __global__ __launch_bounds__(256) void digits_kernel(const uint32_t* __restrict_
   }
 }
 
-// ------------------------------------------------------------------------------------------- bucket bounds
-__global__ void bounds_kernel(const uint32_t* __restrict__ keys, size_t E, uint32_t nb, uint32_t* __restrict__ start,
-                              uint32_t* __restrict__ end) {
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  uint32_t k = keys[e];
-  if (k >= nb) return;
-  if (e == 0 || keys[e - 1] != k) start[k] = (uint32_t)e;
-  if (e + 1 == E || keys[e + 1] != k) end[k] = (uint32_t)(e + 1);
+// ------------------------------------------------------------------------------------------- exclusive scan (u32)
+// three launches: per-2048-chunk sums -> one block scans the chunk sums (tiles of 1024 with a running carry) ->
+// per-chunk exclusive scan + base.  Used for the sort's (bin, block) histogram and for the task offsets.
+constexpr int SCAN_CHUNK = 2048;
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
+                                                          uint32_t* __restrict__ sums) {
+  __shared__ uint32_t red[256];
+  size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
+  uint32_t acc = 0;
+  for (int k = 0; k < SCAN_CHUNK / 256; k++) {
+    size_t i = base + (size_t)k * 256 + threadIdx.x;
+    if (i < n) acc += in[i];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ sums, size_t m) {
+  __shared__ uint32_t buf[1024];
+  uint32_t carry = 0;
+  for (size_t t0 = 0; t0 < m; t0 += 1024) {
+    size_t i = t0 + threadIdx.x;
+    uint32_t v = i < m ? sums[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      uint32_t add = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < m) sums[i] = carry + buf[threadIdx.x] - v;       // exclusive
+    uint32_t total = buf[1023];
+    __syncthreads();
+    carry += total;
+  }
+}
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t* __restrict__ in, size_t n,
+                                                         const uint32_t* __restrict__ sums,
+                                                         uint32_t* __restrict__ out) {
+  __shared__ uint32_t part[256];
+  size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
+  constexpr int PER = SCAN_CHUNK / 256;                         // 8 consecutive elements per thread
+  uint32_t v[PER];
+  uint32_t acc = 0;
+  for (int k = 0; k < PER; k++) {
+    size_t i = base + (size_t)threadIdx.x * PER + k;
+    v[k] = i < n ? in[i] : 0;
+    acc += v[k];
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t add = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = sums[blockIdx.x] + part[threadIdx.x] - acc;
+  for (int k = 0; k < PER; k++) {
+    size_t i = base + (size_t)threadIdx.x * PER + k;
+    if (i < n) out[i] = run;
+    run += v[k];
+  }
+}
+static void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n, DevBuf& tmp) {
+  if (n == 0) return;
+  size_t chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  uint32_t* sums = tmp.as<uint32_t>(chunks + 1);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(chunks), dim3(256), 0, st, in, n, sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, chunks);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(chunks), dim3(256), 0, st, in, n, sums, out);
+}
+
+// ------------------------------------------------------------------------------------------- K6 bucket sort
+// Hand-written two-level counting sort of the (bucket, point) entries — it only has to GROUP entries by bucket
+// (order inside a bucket is irrelevant: EC addition commutes), which is cheaper than a general radix sort:
+//   level 1  bins = top <= 10 bits of the bucket id.  Per 8192-entry tile: LDS histogram (one pass over the
+//            keys), global exclusive scan of the (bin, tile) counts, then a scatter pass in which an LDS atomic
+//            hands every entry its slot inside its bin's region.
+//   level 2  one workgroup per bin (~16 K entries, <= 1024 distinct low keys): LDS histogram, LDS scan — which
+//            directly yields start/end of every bucket of the bin — and an LDS-atomic scatter of the values.
+// LDS atomics resolve same-bucket conflicts inside a wave in hardware; no global atomics on the data path.
+constexpr int SORT_H1_MAX = 10;        // level-1 bins <= 1024 (static LDS histogram)
+constexpr int SORT_L_MAX = 13;         // level-2 keys per bin <= 8192 (dynamic LDS)
+__global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restrict__ keys, size_t E, uint32_t nb,
+                                                        int L, uint32_t nbins1, uint32_t* __restrict__ hist,
+                                                        uint32_t nblocks, uint32_t tile) {
+  __shared__ uint32_t cnt[(1 << SORT_H1_MAX) + 1];
+  for (uint32_t i = threadIdx.x; i <= nbins1; i += 256) cnt[i] = 0;
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * tile;
+  for (uint32_t k = 0; k < tile / 256; k++) {
+    size_t i = base + (size_t)k * 256 + threadIdx.x;
+    if (i < E) {
+      uint32_t key = keys[i];
+      atomicAdd(&cnt[key >= nb ? nbins1 : (key >> L)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i <= nbins1; i += 256) hist[(size_t)i * nblocks + blockIdx.x] = cnt[i];
+}
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ vals, size_t E, uint32_t nb,
+                                                           int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
+                                                           uint32_t nblocks, uint32_t tile,
+                                                           uint32_t* __restrict__ klow, uint32_t* __restrict__ vout) {
+  __shared__ uint32_t cur[(1 << SORT_H1_MAX) + 1];
+  for (uint32_t i = threadIdx.x; i < nbins1; i += 256) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * tile;
+  const uint32_t lmask = (1u << L) - 1;
+  for (uint32_t k = 0; k < tile / 256; k++) {
+    size_t i = base + (size_t)k * 256 + threadIdx.x;
+    if (i < E) {
+      uint32_t key = keys[i];
+      if (key < nb) {                                  // sentinel entries (zero digits / identity bases) are dropped
+        uint32_t pos = atomicAdd(&cur[key >> L], 1u);
+        klow[pos] = key & lmask;
+        vout[pos] = vals[i];
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void sort_bin_kernel(const uint32_t* __restrict__ klow,
+                                                       const uint32_t* __restrict__ vin,
+                                                       const uint32_t* __restrict__ offs, uint32_t nblocks, int L,
+                                                       uint32_t* __restrict__ vout, uint32_t* __restrict__ start,
+                                                       uint32_t* __restrict__ end) {
+  extern __shared__ uint32_t cnt[];                    // nk counters, reused as cursors
+  __shared__ uint32_t pre[256];
+  const uint32_t nk = 1u << L;
+  const uint32_t b = blockIdx.x;
+  const uint32_t lo = offs[(size_t)b * nblocks], hi = offs[(size_t)(b + 1) * nblocks];
+  for (uint32_t i = threadIdx.x; i < nk; i += 256) cnt[i] = 0;
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&cnt[klow[i]], 1u);
+  __syncthreads();
+  // exclusive scan of the nk counters: `per` consecutive counters per thread + Hillis-Steele over 256 partials
+  {
+    const uint32_t per = (nk + 255) / 256;
+    uint32_t acc = 0;
+    for (uint32_t k = 0; k < per; k++) {
+      uint32_t idx = threadIdx.x * per + k;
+      if (idx < nk) acc += cnt[idx];
+    }
+    pre[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      uint32_t add = (int)threadIdx.x >= d ? pre[threadIdx.x - d] : 0;
+      __syncthreads();
+      pre[threadIdx.x] += add;
+      __syncthreads();
+    }
+    uint32_t run = pre[threadIdx.x] - acc;
+    for (uint32_t k = 0; k < per; k++) {
+      uint32_t idx = threadIdx.x * per + k;
+      if (idx < nk) {
+        uint32_t v = cnt[idx];
+        start[((size_t)b << L) + idx] = lo + run;
+        end[((size_t)b << L) + idx] = lo + run + v;
+        cnt[idx] = lo + run;                            // cursor
+        run += v;
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+    uint32_t pos = atomicAdd(&cnt[klow[i]], 1u);
+    vout[pos] = vin[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------- task scheduling
@@ -273,15 +438,25 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     else
       hipLaunchKernelGGL(digits_kernel<Bls381Fr>, dim3((n + 255) / 256), dim3(256), 0, st, sc, n, offset, be->inf,
                          be->n, c, W, nb, keys, vals, montgomery ? 1 : 0);
-    // K6: sort (key bits 0..c; key nb == sentinel sorts last)
-    size_t tmp_bytes = 0;
-    ZKP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)E, 0, c, st));
-    void* tmp = ws.sort_tmp.get(tmp_bytes);
-    ZKP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)E, 0, c, st));
+    // K6: group entries by bucket (two-level counting sort); sorted values land back in `vals`
+    static const int h1_env = [] { const char* e = getenv("ZKP_SORT_H1"); return e ? atoi(e) : 10; }();
+    static const uint32_t SORT_TILE = [] { const char* e = getenv("ZKP_SORT_TILE"); return e ? (uint32_t)atoi(e) : 8192u; }();
+    int H1 = std::min(std::min(SORT_H1_MAX, h1_env), c - 1);
+    if ((c - 1) - H1 > SORT_L_MAX) H1 = (c - 1) - SORT_L_MAX;
+    const int LB = (c - 1) - H1;                                       // low bits per level-1 bin
+    const uint32_t nbins1 = 1u << H1;
+    const uint32_t nblocks = (uint32_t)((E + SORT_TILE - 1) / SORT_TILE);
+    const size_t hist_n = (size_t)(nbins1 + 1) * nblocks + 1;
+    uint32_t* hist = ws.sort_tmp.as<uint32_t>(2 * hist_n);
+    uint32_t* offs = hist + hist_n;
     uint32_t* start = ws.offsets.as<uint32_t>(2 * (size_t)nb);
     uint32_t* end = start + nb;
-    ZKP_HIP(hipMemsetAsync(start, 0, 2 * (size_t)nb * 4, st));
-    hipLaunchKernelGGL(bounds_kernel, dim3((E + 255) / 256), dim3(256), 0, st, keys2, E, nb, start, end);
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(256), 0, st, keys, E, nb, LB, nbins1, hist, nblocks, SORT_TILE);
+    exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(256), 0, st, keys, vals, E, nb, LB, nbins1, offs, nblocks,
+                       SORT_TILE, keys2, vals2);
+    hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(256), ((size_t)4 << LB), st, keys2, vals2, offs, nblocks, LB, vals, start, end);
+    uint32_t* const sorted_vals = vals;
     // K7 scheduling: buckets -> tasks (<= CAP entries), ordered by length
     const uint32_t max_tasks = nb + (uint32_t)(E / MSM_TASK_CAP) + 1;
     uint32_t* sched = ws.sched.as<uint32_t>((size_t)2 * (nb + 2) + (size_t)5 * max_tasks + TM_WORDS);
@@ -295,10 +470,7 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     uint32_t* tmeta = long_list + max_tasks;
     ZKP_HIP(hipMemsetAsync(tmeta, 0, TM_WORDS * 4, st));
     hipLaunchKernelGGL(task_count_kernel, dim3((nb + 256) / 256), dim3(256), 0, st, start, end, nb, tcount);
-    size_t scan_bytes = 0;
-    ZKP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, tcount, toff, (int)(nb + 1), st));
-    void* scan_tmp = ws.scan_tmp.get(scan_bytes);
-    ZKP_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, tcount, toff, (int)(nb + 1), st));
+    exclusive_scan_u32(st, tcount, toff, (size_t)nb + 1, ws.scan_tmp2);
     hipLaunchKernelGGL(task_fill_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, start, end, toff, nb, task_start,
                        task_len, task_dst, long_list, tmeta);
     hipLaunchKernelGGL(task_cursor_kernel, dim3(1), dim3(64), 0, st, tmeta);
@@ -311,7 +483,7 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     ZKP_HIP(hipMemsetAsync(buckets, 0, (size_t)nb * XB, st));
     const bool timed = ms_accumulate && ctx->profiling;
     if (timed) ZKP_HIP(hipEventRecord(ctx->ev2, st));
-    vt->accumulate(st, be->table, vals2, order, task_start, task_len, task_dst, toff + nb, max_tasks, buckets,
+    vt->accumulate(st, be->table, sorted_vals, order, task_start, task_len, task_dst, toff + nb, max_tasks, buckets,
                    task_partial);
     if (timed) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));

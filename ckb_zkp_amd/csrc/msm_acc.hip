@@ -71,12 +71,13 @@ void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const 
                                         const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial) {
   // G2: 1 wave/SIMD (VGPRs + AGPRs as spill space, default) vs 2 waves/SIMD (256 VGPRs + 704 B scratch): the latter makes
   // the kernel itself 7 % faster but the whole proof 8 % slower (it starves the concurrent streams) — ZKP_G2_ACC_OCC=1|2
+  static const unsigned lds = [] { const char* e = getenv("ZKP_ACC_LDS_BYTES"); return e ? (unsigned)atoi(e) : 0u; }();
   static const int occ = [] { const char* e = getenv("ZKP_G2_ACC_OCC"); return e ? atoi(e) : 1; }();
   if (ZKP_CFG_GROUP == 2 && occ == 2)
-    hipLaunchKernelGGL(accumulate_kernel<2>, dim3((max_tasks + 255) / 256), dim3(256), 0, s, table, vals, order,
+    hipLaunchKernelGGL(accumulate_kernel<2>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
                        task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
   else
-    hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), 0, s, table, vals, order,
+    hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
                        task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
 }
 

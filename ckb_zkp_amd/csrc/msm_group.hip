@@ -96,6 +96,27 @@ __global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ ba
   if (threadIdx.x == 0) acc.store(partial + (size_t)blockIdx.x * XYZZ<F>::BYTES);
 }
 
+// Buckets split into a handful of tasks (the common case: the thinly populated top window gives ~77 entries = 2
+// tasks per bucket) are folded by ONE lane each; only genuinely long buckets (skewed scalars) get a whole wave.
+constexpr uint32_t COMBINE_SMALL = 8;
+template <class F>
+__global__ __launch_bounds__(256) void combine_small_kernel(const uint32_t* __restrict__ long_list,
+                                                            const uint32_t* __restrict__ n_long_dev,
+                                                            const uint32_t* __restrict__ toff,
+                                                            const char* __restrict__ partial,
+                                                            char* __restrict__ buckets) {
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t n_long = *n_long_dev;
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_long; w += gridDim.x * blockDim.x) {
+    const uint32_t b = long_list[w];
+    const uint32_t p0 = toff[b], p1 = toff[b + 1];
+    if (p1 - p0 > COMBINE_SMALL) continue;
+    XYZZ<F> acc = XYZZ<F>::load(partial + (size_t)p0 * XYZZ<F>::BYTES);
+    for (uint32_t i = p0 + 1; i < p1; i++) acc.add(XYZZ<F>::load(partial + (size_t)i * XYZZ<F>::BYTES));
+    acc.store(buckets + (size_t)b * XYZZ<F>::BYTES);
+  }
+}
+
 // buckets[b] = sum of the partial sums of a bucket that was split into several tasks; one wave per bucket
 template <class F>
 __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict__ long_list,
@@ -109,6 +130,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
   for (uint32_t w = blockIdx.x * 4 + wv; w < n_long; w += gridDim.x * 4) {
     const uint32_t b = long_list[w];
     const uint32_t p0 = toff[b], p1 = toff[b + 1];
+    if (p1 - p0 <= COMBINE_SMALL) continue;            // handled by combine_small_kernel (wave-uniform branch)
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t i = p0 + lane; i < p1; i += 64) acc.add(XYZZ<F>::load(partial + (size_t)i * XYZZ<F>::BYTES));
     acc.store(my + lane * XYZZ<F>::BYTES);
@@ -298,6 +320,7 @@ void l_precompute(hipStream_t s, char* table, size_t n, int c, int W) {
 }
 void l_combine(hipStream_t s, const uint32_t* long_list, const uint32_t* n_long_dev, const uint32_t* toff,
                const char* partial, char* buckets) {
+  hipLaunchKernelGGL(combine_small_kernel<F>, dim3(256), dim3(256), 0, s, long_list, n_long_dev, toff, partial, buckets);
   hipLaunchKernelGGL(combine_kernel<F>, dim3(512), dim3(256), 256 * XB, s, long_list, n_long_dev, toff, partial, buckets);
 }
 void l_pair(hipStream_t s, const char* in, char* out, uint32_t count) {

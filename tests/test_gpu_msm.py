@@ -108,3 +108,31 @@ def test_vartime_multiscalar_mul_montgomery_scalars(ctx):
         assert jac_limbs_to_affine_oracle("bn254", 1, out) == G.msm_naive(pts, ks)
     finally:
         bases.free()
+
+
+@pytest.mark.parametrize("curve,group", CFG)
+def test_msm_repeatability_stress(ctx, curve, group):
+    """Race detector: skewed inputs (long buckets -> split tasks, wave-level combines, LDS-atomic sort scatter) run 25
+    times must give the identical group element every time and match the oracle once."""
+    c = get_curve(curve)
+    G = Group(OC[curve], group)
+    rng = np.random.default_rng(77 + group)
+    n = 3000
+    d = rng.integers(1, 1 << 62, size=(n, 4), dtype=np.uint64)
+    d[:, 3] >>= np.uint64(4)
+    g_xy, _ = to_abi_points(curve, group, [G.gen])
+    xy, inf = ctx.fixed_base_mul(c, group, g_xy, d)
+    k = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    k[:, 3] >>= np.uint64(4)
+    k[: n // 2] = k[0]                   # half the scalars identical -> 1500-entry buckets in every window
+    k[n // 2: n // 2 + 700, 1:] = 0
+    k[n // 2: n // 2 + 700, 0] = 1       # 700 ones -> one 700-entry bucket
+    bases = ctx.upload_bases(c, group, xy, inf)
+    try:
+        first = jac_to_affine(ctx, curve, group, bases.msm(k))
+        e = sum(a * b for a, b in zip(codec.limbs_to_ints(d), codec.limbs_to_ints(k))) % c.r
+        assert first == G.mul(G.gen, e)
+        for _ in range(24):
+            assert jac_to_affine(ctx, curve, group, bases.msm(k)) == first
+    finally:
+        bases.free()
