@@ -12,8 +12,9 @@
 //   per MSM:
 //     K5  digit scan      scalar i -> W signed c-bit digits d_w in [-2^(c-1), 2^(c-1)];  entry
 //                         (bucket |d_w|-1, point w*n+i, sign) — all windows share ONE bucket set because
-//                         the window weight already lives in T.  Coalesced 32 B/scalar read, 8 B/entry
-//                         written.  Identity bases / zero digits emit a sentinel key.
+//                         the window weight already lives in T.  Fused into both level-1 passes of the sort:
+//                         coalesced 32 B/scalar reads, one 8 B store per entry; identity bases / zero digits
+//                         emit nothing.
 //     K6  group by bucket hand-written two-level counting sort (LDS histograms + LDS-atomic scatter); also yields
 //                         the start/end of every bucket.
 //     K7  accumulate      one lane per bucket walks its run of the sorted list: gather T[val] (64 B,
@@ -118,29 +119,23 @@ int bases_group(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->
 void msm_free_all(zkp_ctx* ctx) { ctx->bases.clear(); }
 
 // ------------------------------------------------------------------------------------------- K5 digit scan
-template <class FrP>
-__global__ __launch_bounds__(256) void digits_kernel(const uint32_t* __restrict__ scalars, size_t n, size_t offset,
-                                                     const uint8_t* __restrict__ inf, size_t ntab, int c, int W,
-                                                     uint32_t nb, uint32_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ vals, int montgomery) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Fp<FrP> s = Fp<FrP>::load(scalars + i * 8);
-  if (montgomery) s = s.from_mont();            // ark into_repr(), fused (prover.rs:150-161)
-  const bool skip = inf && inf[offset + i];
-  uint32_t carry = 0;
-  const uint32_t cmask = (1u << c) - 1;
-  for (int w = 0; w < W; w++) {
-    int bit = w * c;
-    int limb = bit >> 5, sh = bit & 31;
+// Signed c-bit digits of one scalar, produced on the fly inside BOTH level-1 sort passes (histogram and scatter):
+// the (bucket, point) entries are never materialised unsorted, so the scan reads 32 B per scalar (twice) and writes
+// one 8-B (low key, point | sign) word per entry.  ark's `into_repr()` (prover.rs:150-161) is the fused from_mont().
+struct DigitIter {
+  uint32_t v[8];
+  uint32_t carry;
+  __device__ __forceinline__ void next(int w, int c, uint32_t nb, uint32_t& key, uint32_t& neg) {
+    const int bit = w * c;
+    const int limb = bit >> 5, sh = bit & 31;
     uint32_t d = 0;
     if (limb < 8) {
-      uint64_t two = s.v[limb];
-      if (limb + 1 < 8) two |= (uint64_t)s.v[limb + 1] << 32;
-      d = (uint32_t)(two >> sh) & cmask;
+      uint64_t two = v[limb];
+      if (limb + 1 < 8) two |= (uint64_t)v[limb + 1] << 32;
+      d = (uint32_t)(two >> sh) & ((1u << c) - 1);
     }
     d += carry;
-    uint32_t neg = 0;
+    neg = 0;
     if (d > nb) {
       d = (1u << c) - d;
       neg = 1;
@@ -148,11 +143,18 @@ __global__ __launch_bounds__(256) void digits_kernel(const uint32_t* __restrict_
     } else {
       carry = 0;
     }
-    uint32_t key = (d == 0 || skip) ? nb : d - 1;
-    uint32_t val = (uint32_t)((size_t)w * ntab + offset + i) | (neg << 31);
-    keys[(size_t)w * n + i] = key;
-    vals[(size_t)w * n + i] = val;
+    key = d == 0 ? nb : d - 1;                      // nb == sentinel (zero digit)
   }
+};
+template <class FrP>
+__device__ __forceinline__ DigitIter load_scalar(const uint32_t* __restrict__ scalars, size_t i, int montgomery) {
+  Fp<FrP> s = Fp<FrP>::load(scalars + i * 8);
+  if (montgomery) s = s.from_mont();
+  DigitIter it;
+#pragma unroll
+  for (int l = 0; l < 8; l++) it.v[l] = s.v[l];
+  it.carry = 0;
+  return it;
 }
 
 // ------------------------------------------------------------------------------------------- exclusive scan (u32)
@@ -244,47 +246,57 @@ static void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out
 // LDS atomics resolve same-bucket conflicts inside a wave in hardware; no global atomics on the data path.
 constexpr int SORT_H1_MAX = 10;        // level-1 bins <= 1024 (static LDS histogram)
 constexpr int SORT_L_MAX = 13;         // level-2 keys per bin <= 8192 (dynamic LDS)
-__global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restrict__ keys, size_t E, uint32_t nb,
-                                                        int L, uint32_t nbins1, uint32_t* __restrict__ hist,
-                                                        uint32_t nblocks, uint32_t tile) {
+constexpr int SORT_SCALARS = 512;      // scalars per workgroup in the level-1 passes (2 per lane)
+template <class FrP>
+__global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restrict__ scalars, size_t n, size_t offset,
+                                                        const uint8_t* __restrict__ inf, int montgomery, int c, int W,
+                                                        uint32_t nb, int L, uint32_t nbins1,
+                                                        uint32_t* __restrict__ hist, uint32_t nblocks) {
   __shared__ uint32_t cnt[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i <= nbins1; i += 256) cnt[i] = 0;
   __syncthreads();
-  size_t base = (size_t)blockIdx.x * tile;
-  for (uint32_t k = 0; k < tile / 256; k++) {
-    size_t i = base + (size_t)k * 256 + threadIdx.x;
-    if (i < E) {
-      uint32_t key = keys[i];
-      atomicAdd(&cnt[key >= nb ? nbins1 : (key >> L)], 1u);
+  for (int rep = 0; rep < SORT_SCALARS / 256; rep++) {
+    size_t i = (size_t)blockIdx.x * SORT_SCALARS + rep * 256 + threadIdx.x;
+    if (i < n && !(inf && inf[offset + i])) {
+      DigitIter it = load_scalar<FrP>(scalars, i, montgomery);
+      for (int w = 0; w < W; w++) {
+        uint32_t key, neg;
+        it.next(w, c, nb, key, neg);
+        if (key < nb) atomicAdd(&cnt[key >> L], 1u);
+      }
     }
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i <= nbins1; i += 256) hist[(size_t)i * nblocks + blockIdx.x] = cnt[i];
+  for (uint32_t i = threadIdx.x; i < nbins1; i += 256) hist[(size_t)i * nblocks + blockIdx.x] = cnt[i];
 }
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __restrict__ keys,
-                                                           const uint32_t* __restrict__ vals, size_t E, uint32_t nb,
+template <class FrP>
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __restrict__ scalars, size_t n,
+                                                           size_t offset, const uint8_t* __restrict__ inf,
+                                                           int montgomery, size_t ntab, int c, int W, uint32_t nb,
                                                            int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
-                                                           uint32_t nblocks, uint32_t tile,
-                                                           uint32_t* __restrict__ klow, uint32_t* __restrict__ vout) {
+                                                           uint32_t nblocks,
+                                                           uint64_t* __restrict__ kv) {   // (low key << 32) | val
   __shared__ uint32_t cur[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i < nbins1; i += 256) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
   __syncthreads();
-  size_t base = (size_t)blockIdx.x * tile;
   const uint32_t lmask = (1u << L) - 1;
-  for (uint32_t k = 0; k < tile / 256; k++) {
-    size_t i = base + (size_t)k * 256 + threadIdx.x;
-    if (i < E) {
-      uint32_t key = keys[i];
-      if (key < nb) {                                  // sentinel entries (zero digits / identity bases) are dropped
-        uint32_t pos = atomicAdd(&cur[key >> L], 1u);
-        klow[pos] = key & lmask;
-        vout[pos] = vals[i];
+  for (int rep = 0; rep < SORT_SCALARS / 256; rep++) {
+    size_t i = (size_t)blockIdx.x * SORT_SCALARS + rep * 256 + threadIdx.x;
+    if (i < n && !(inf && inf[offset + i])) {
+      DigitIter it = load_scalar<FrP>(scalars, i, montgomery);
+      for (int w = 0; w < W; w++) {
+        uint32_t key, neg;
+        it.next(w, c, nb, key, neg);
+        if (key < nb) {                                // zero digits are dropped here
+          uint32_t pos = atomicAdd(&cur[key >> L], 1u);
+          uint32_t val = (uint32_t)((size_t)w * ntab + offset + i) | (neg << 31);
+          kv[pos] = ((uint64_t)(key & lmask) << 32) | val;   // one 8-B store per entry
+        }
       }
     }
   }
 }
-__global__ __launch_bounds__(256) void sort_bin_kernel(const uint32_t* __restrict__ klow,
-                                                       const uint32_t* __restrict__ vin,
+__global__ __launch_bounds__(256) void sort_bin_kernel(const uint64_t* __restrict__ kv,
                                                        const uint32_t* __restrict__ offs, uint32_t nblocks, int L,
                                                        uint32_t* __restrict__ vout, uint32_t* __restrict__ start,
                                                        uint32_t* __restrict__ end) {
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(256) void sort_bin_kernel(const uint32_t* __restric
   const uint32_t lo = offs[(size_t)b * nblocks], hi = offs[(size_t)(b + 1) * nblocks];
   for (uint32_t i = threadIdx.x; i < nk; i += 256) cnt[i] = 0;
   __syncthreads();
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&cnt[klow[i]], 1u);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&cnt[(uint32_t)(kv[i] >> 32)], 1u);
   __syncthreads();
   // exclusive scan of the nk counters: `per` consecutive counters per thread + Hillis-Steele over 256 partials
   {
@@ -327,8 +339,9 @@ __global__ __launch_bounds__(256) void sort_bin_kernel(const uint32_t* __restric
   }
   __syncthreads();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-    uint32_t pos = atomicAdd(&cnt[klow[i]], 1u);
-    vout[pos] = vin[i];
+    const uint64_t x = kv[i];
+    uint32_t pos = atomicAdd(&cnt[(uint32_t)(x >> 32)], 1u);
+    vout[pos] = (uint32_t)x;
   }
 }
 
@@ -427,35 +440,38 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     const uint32_t nb = 1u << (c - 1);
     const size_t E = n * (size_t)W;
     ZKP_REQUIRE(E < 2147483000ull, ZKP_ERR_BAD_ARG);
-    uint32_t* keys = ws.keys.as<uint32_t>(E);
-    uint32_t* vals = ws.vals.as<uint32_t>(E);
-    uint32_t* keys2 = ws.keys2.as<uint32_t>(E);
-    uint32_t* vals2 = ws.vals2.as<uint32_t>(E);
+    uint32_t* vals = ws.vals.as<uint32_t>(E);                        // values grouped by bucket (level-2 output)
+    uint64_t* kv = ws.keys2.as<uint64_t>(E);                         // level-1 output: (low key, val) pairs
     const uint32_t* sc = reinterpret_cast<const uint32_t*>(scalars_dev);
-    if (be->curve == ZKP_BN254)
-      hipLaunchKernelGGL(digits_kernel<Bn254Fr>, dim3((n + 255) / 256), dim3(256), 0, st, sc, n, offset, be->inf, be->n,
-                         c, W, nb, keys, vals, montgomery ? 1 : 0);
-    else
-      hipLaunchKernelGGL(digits_kernel<Bls381Fr>, dim3((n + 255) / 256), dim3(256), 0, st, sc, n, offset, be->inf,
-                         be->n, c, W, nb, keys, vals, montgomery ? 1 : 0);
+    const int mont = montgomery ? 1 : 0;
     // K6: group entries by bucket (two-level counting sort); sorted values land back in `vals`
     static const int h1_env = [] { const char* e = getenv("ZKP_SORT_H1"); return e ? atoi(e) : 10; }();
-    static const uint32_t SORT_TILE = [] { const char* e = getenv("ZKP_SORT_TILE"); return e ? (uint32_t)atoi(e) : 8192u; }();
     int H1 = std::min(std::min(SORT_H1_MAX, h1_env), c - 1);
     if ((c - 1) - H1 > SORT_L_MAX) H1 = (c - 1) - SORT_L_MAX;
     const int LB = (c - 1) - H1;                                       // low bits per level-1 bin
     const uint32_t nbins1 = 1u << H1;
-    const uint32_t nblocks = (uint32_t)((E + SORT_TILE - 1) / SORT_TILE);
-    const size_t hist_n = (size_t)(nbins1 + 1) * nblocks + 1;
+    const uint32_t nblocks = (uint32_t)((n + SORT_SCALARS - 1) / SORT_SCALARS);
+    const size_t hist_n = (size_t)nbins1 * nblocks + 1;                // + total (== number of non-zero digits)
     uint32_t* hist = ws.sort_tmp.as<uint32_t>(2 * hist_n);
     uint32_t* offs = hist + hist_n;
     uint32_t* start = ws.offsets.as<uint32_t>(2 * (size_t)nb);
     uint32_t* end = start + nb;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(256), 0, st, keys, E, nb, LB, nbins1, hist, nblocks, SORT_TILE);
-    exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(256), 0, st, keys, vals, E, nb, LB, nbins1, offs, nblocks,
-                       SORT_TILE, keys2, vals2);
-    hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(256), ((size_t)4 << LB), st, keys2, vals2, offs, nblocks, LB, vals, start, end);
+    ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
+    if (be->curve == ZKP_BN254) {
+      hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
+                         nb, LB, nbins1, hist, nblocks);
+      exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
+      hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
+                         be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
+    } else {
+      hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
+                         nb, LB, nbins1, hist, nblocks);
+      exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
+      hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
+                         be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
+    }
+    hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(256), ((size_t)4 << LB), st, kv, offs, nblocks, LB, vals,
+                       start, end);
     uint32_t* const sorted_vals = vals;
     // K7 scheduling: buckets -> tasks (<= CAP entries), ordered by length
     const uint32_t max_tasks = nb + (uint32_t)(E / MSM_TASK_CAP) + 1;
