@@ -24,6 +24,7 @@
 // (z[0] = 1 so query[0] needs no special case; r == 0 makes r*g1_b the identity exactly as the reference's
 // `if r != 0` branch does).  What remains is  C = s*g_a + r*g1_b + l' + h_acc  and three `into_affine()`.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -414,14 +415,16 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
   const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
   const size_t pw64 = (4 * (size_t)v1->fN + 2 * (size_t)v2->fN) / 2;
   const bool prof = ctx->profiling;
-  size_t pending[zkp_ctx::N_LANES] = {0, 0};
+  size_t pending[zkp_ctx::N_LANES] = {};
+  static const int lanes_env = [] { const char* e = getenv("ZKP_LANES"); return e ? atoi(e) : 2; }();
+  const int nl = std::max(1, std::min(lanes_env, (int)zkp_ctx::N_LANES));
   auto select = [&](int l) {
     ctx->cur = &ctx->lanes[l];
     ctx->cur_idx = l;
   };
   try {
     for (size_t i = 0; i < n; i++) {
-      const int l = prof ? 0 : (int)(i % zkp_ctx::N_LANES);
+      const int l = prof ? 0 : (int)(i % nl);
       select(l);
       if (ctx->cur->busy) prove_finish(ctx, pk, proofs_out + pending[l] * pw64, inf_out + pending[l] * 3);
       if (pk->curve == ZKP_BN254) prove_enqueue<Bn254Fr>(ctx, pk, z_dev[i], true, r + 4 * i, s + 4 * i);
