@@ -184,18 +184,36 @@ struct Fp {
 // Montgomery product a*b*R^-1 mod p.
 // Product scanning (column by column) with the running column sum held as a 64-bit accumulator plus a 32-bit
 // overflow counter; every partial product is ONE v_mad_u64_u32 (32x32 + 64 -> 64, carry to VCC) followed by ONE
-// v_addc_co_u32 that banks the carry — 2 VALU instructions per 32x32 product and two v_mov per column, versus
+// v_addc_co_u32 that banks the carry (one asm statement per run of products of a column, tools/gen_mac.py) —
+// 2 VALU instructions per 32x32 product and two v_mov per column, versus
 // ~4.5 per product for the C (CIOS) formulation, whose 64-bit zero-extensions hipcc materialises as v_mov pairs
 // (measured on MI355X: 118-129 G products/s vs 86-95 G for 256-bit fields, 59 vs 44 G for the 384-bit field;
 // tools/ubench/mulasm.hip checks the two formulations against each other).  The modulus limbs are scalar
 // operands (SGPR / constant bus).  All moduli here have a spare top bit, so the result is < 2p and one
 // conditional subtraction finishes the reduction.
-#define ZKP_MAC_VV(acc, ovf, x, y)                                                              \
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"             \
-      : "+v"(acc), "+v"(ovf) : "v"(x), "v"(y) : "vcc")
-#define ZKP_MAC_VS(acc, ovf, x, ys)                                                             \
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"             \
-      : "+v"(acc), "+v"(ovf) : "v"(x), "s"(ys) : "vcc")
+#include "mac_gen.inc"
+
+// column K of the product scan (compile-time K so that each run of partial products is ONE asm statement)
+template <class P, int K>
+struct MontColumn {
+  static ZKP_DEV void run(uint64_t& acc, uint32_t& ovf, const Fp<P>& a, const Fp<P>& b, uint32_t* m, Fp<P>& r) {
+    constexpr int N = P::N;
+    constexpr int i0 = K < N ? 0 : K - N + 1;           // first row with a partner in column K
+    constexpr int i1 = K < N ? K : N - 1;
+    MacVV<i1 - i0 + 1>::run(acc, ovf, &a.v[i0], &b.v[K - i0]);
+    constexpr int mi1 = (K - 1 < N - 1) ? K - 1 : N - 1;  // m[i] is known for i < K
+    if constexpr (mi1 >= i0) MacVS<P, mi1 - i0 + 1, K - i0>::run(acc, ovf, &m[i0]);
+    if constexpr (K < N) {
+      m[K] = (uint32_t)acc * P::INV;
+      MacVS<P, 1, 0>::run(acc, ovf, &m[K]);             // low word of the column becomes 0
+    } else {
+      r.v[K - N] = (uint32_t)acc;
+    }
+    acc = (acc >> 32) | ((uint64_t)ovf << 32);
+    ovf = 0;
+    if constexpr (K + 1 < 2 * N - 1) MontColumn<P, K + 1>::run(acc, ovf, a, b, m, r);
+  }
+};
 
 template <class P>
 ZKP_MUL_ATTR Fp<P> fp_mul(Fp<P> a, Fp<P> b) {
@@ -204,27 +222,7 @@ ZKP_MUL_ATTR Fp<P> fp_mul(Fp<P> a, Fp<P> b) {
   Fp<P> r;
   uint64_t acc = 0;
   uint32_t ovf = 0;
-#pragma unroll
-  for (int k = 0; k < 2 * N - 1; k++) {
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      const int j = k - i;
-      if (j >= 0 && j < N) ZKP_MAC_VV(acc, ovf, a.v[i], b.v[j]);
-    }
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      const int j = k - i;
-      if (j >= 0 && j < N && i < k) ZKP_MAC_VS(acc, ovf, m[i], P::MOD[j]);
-    }
-    if (k < N) {
-      m[k] = (uint32_t)acc * P::INV;
-      ZKP_MAC_VS(acc, ovf, m[k], P::MOD[0]);            // low word of the column becomes 0
-    } else {
-      r.v[k - N] = (uint32_t)acc;
-    }
-    acc = (acc >> 32) | ((uint64_t)ovf << 32);
-    ovf = 0;
-  }
+  MontColumn<P, 0>::run(acc, ovf, a, b, m, r);
   r.v[N - 1] = (uint32_t)acc;
   return Fp<P>::reduce_once(r);
 }
