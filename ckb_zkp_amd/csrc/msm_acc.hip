@@ -73,7 +73,11 @@ void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const 
   // the kernel itself 7 % faster but the whole proof 8 % slower (it starves the concurrent streams) — ZKP_G2_ACC_OCC=1|2
   static const unsigned lds = [] { const char* e = getenv("ZKP_ACC_LDS_BYTES"); return e ? (unsigned)atoi(e) : 0u; }();
   static const int occ = [] { const char* e = getenv("ZKP_G2_ACC_OCC"); return e ? atoi(e) : 1; }();
-  if (ZKP_CFG_GROUP == 2 && occ == 2)
+  static const int occ1 = [] { const char* e = getenv("ZKP_G1_ACC_OCC"); return e ? atoi(e) : 3; }();
+  if (ZKP_CFG_GROUP == 1 && occ1 == 4)
+    hipLaunchKernelGGL(accumulate_kernel<4>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
+                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
+  else if (ZKP_CFG_GROUP == 2 && occ == 2)
     hipLaunchKernelGGL(accumulate_kernel<2>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
                        task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
   else

@@ -54,19 +54,22 @@ def _degree(coeffs_mont: np.ndarray) -> int:
     return int(nz[-1]) if len(nz) else 0
 
 
-def commit(ctx: Context, ck: CommitterKey, coeffs_mont: np.ndarray, blinding_mont: np.ndarray | None = None):
+def commit(ctx: Context, ck: CommitterKey, coeffs_mont: np.ndarray, blinding_mont: np.ndarray | None = None,
+           power_offset: int = 0):
     """KZG10::commit (kzg10.rs:100-123) -> affine commitment (canonical ints or None).
-    coeffs_mont: (deg+1, 4) Montgomery Fr; blinding_mont: the `Rand` blinding polynomial (hiding) or None."""
+    coeffs_mont: (deg+1, 4) Montgomery Fr; blinding_mont: the `Rand` blinding polynomial (hiding) or None.
+    power_offset > 0 commits against `ck.shifted_powers(degree_bound)` = powers_of_g[supported_degree - bound ..]
+    (pc/data_structures.rs:88-99) for degree-bounded polynomials."""
     c = ck.curve
     deg = _degree(coeffs_mont)
     if deg < 1:
         raise KzgError("DegreeIsZero")
-    if deg > ck.supported_degree:
+    if deg > ck.supported_degree - power_offset:
         raise KzgError("DegreeOutOfBound")
     lz = _leading_zeros(coeffs_mont)
     d = ctx.to_device(np.ascontiguousarray(coeffs_mont[lz:]))
     try:
-        comm = ck.powers_of_g.msm_mont_dev(d, len(coeffs_mont) - lz, offset=lz)
+        comm = ck.powers_of_g.msm_mont_dev(d, len(coeffs_mont) - lz, offset=power_offset + lz)
     finally:
         ctx.dev_free(d)
     if blinding_mont is not None:

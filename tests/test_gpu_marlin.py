@@ -1,0 +1,69 @@
+"""GPU: Marlin prover (BASELINE.json configs[3]) with fixed challenges — device-backed AHP rounds + KZG10 commitments,
+evaluations and batch openings equal the big-int oracle's, and the resulting proof passes the reference's own
+verifier (verifier_equality_check + PC::batch_check with a real pairing, marlin/src/lib.rs:184-250)."""
+import random
+
+import pytest
+
+from ckb_zkp_amd import kzg10, marlin
+from ckb_zkp_amd.circuits import Mini, MimcChain
+from ckb_zkp_amd.params import get_curve
+from oracle.pyref import groth16 as og
+from oracle.pyref import kzg10 as okzg
+from oracle.pyref import marlin as om
+from tests.util import OC
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_inputs(c, hs, seed):
+    rnd = random.Random(seed)
+    R = dict(w=[rnd.randrange(c.r)], z_a=[rnd.randrange(c.r)], z_b=[rnd.randrange(c.r)],
+             mask=[rnd.randrange(c.r) for _ in range(3 * hs)],
+             blind={l: [rnd.randrange(c.r), rnd.randrange(c.r)] for l in ("w", "z_a", "z_b", "g_1")},
+             blind_shifted={"g_1": [rnd.randrange(c.r), rnd.randrange(c.r)]})
+    ch = dict(alpha=rnd.randrange(c.r), eta_a=rnd.randrange(c.r), eta_b=rnd.randrange(c.r), eta_c=rnd.randrange(c.r),
+              beta=rnd.randrange(c.r), gamma=rnd.randrange(c.r), xi=rnd.randrange(1 << 128))
+    return R, ch
+
+
+@pytest.mark.parametrize("curve,kind", [("bn254", "mimc"), ("bls12_381", "mimc"), ("bn254", "mini")])
+def test_marlin_prover_matches_oracle_and_verifies(ctx, curve, kind):
+    c = get_curve(curve)
+    rnd = random.Random(5)
+    if kind == "mimc":
+        consts = [rnd.randrange(c.r) for _ in range(5)]
+        pre = [(rnd.randrange(c.r), rnd.randrange(c.r)) for _ in range(2)]
+        pcirc, pcirc_w = MimcChain(curve, consts, [(None, None)] * 2), MimcChain(curve, consts, pre)
+        ocirc, public = og.MimcChain(OC[curve], consts, pre), []
+    else:                                                   # marlin/tests/mini.rs: x*(y+2) = z, z public
+        pcirc, pcirc_w = Mini(num=10), Mini(2, 3, 10, 10)
+        ocirc, public = og.MiniCircuit(2, 3, 10, 10), [10]
+    oidx = om.index(OC[curve], ocirc)
+    idx = marlin.index(ctx, curve, pcirc)
+    assert (idx["hs"], idx["ks"], idx["bs"], idx["xs"], idx["max_degree"]) == \
+        (oidx["dh"].size, oidx["dk"].size, oidx["db"].size, oidx["dx"].size, oidx["max_degree"])
+    for m in "abc":
+        for k in ("row", "col", "val", "row_col"):
+            assert idx["star"][m]["polys"][k] == oidx["star"][m]["polys"][k], (m, k)
+            assert idx["star"][m]["on_b"][k] == oidx["star"][m]["on_b"][k], (m, k)
+    beta_srs = 0x123456789ABCDEF
+    pp = okzg.setup(OC[curve], idx["max_degree"], beta_srs)
+    ck = kzg10.setup(ctx, curve, idx["max_degree"], beta_srs)
+    try:
+        R, ch = _rand_inputs(c, idx["hs"], seed=9)
+        proof = marlin.create_proof(ctx, idx, ck, pcirc_w, R, ch)
+        oproof = om.create_proof(oidx, pp, ocirc, R, ch)
+        for l in marlin.LABELS_1 + marlin.LABELS_2 + marlin.LABELS_3:
+            assert proof["polys"][l] == oproof["polys"][l], l
+            assert proof["commitments"][l] == oproof["commitments"][l], l
+        assert proof["query"] == oproof["query"] and proof["evaluations"] == oproof["evaluations"]
+        assert proof["opening_proofs"] == oproof["opening_proofs"]
+        # the reference's acceptance test on the DEVICE proof
+        ic = om.index_commitments(oidx, pp)
+        assert om.verify_proof(oidx, pp, ic, proof, public, ch)
+        bad = dict(proof, evaluations=[(proof["evaluations"][0] + 1) % c.r] + proof["evaluations"][1:])
+        assert not om.verify_proof(oidx, pp, ic, bad, public, ch)
+    finally:
+        ck.powers_of_g.free()
+        ck.powers_of_gamma_g.free()
