@@ -212,8 +212,11 @@ def index(ctx: Context, curve, circuit):
 
 
 def create_proof(ctx: Context, idx, ck: kzg10.CommitterKey, circuit, rnd, ch):
-    """create_random_proof with explicit randomness `rnd` and challenges `ch` (see oracle/pyref/marlin.py for the
-    dictionary layout).  Returns commitments, evaluations (query-set order) and the two opening proofs."""
+    """create_random_proof with explicit randomness and challenges.
+    rnd: w, z_a, z_b (1 coefficient each: the zk masks of prover.rs:190,196,200), mask (3|H| coefficients, :202-205),
+         blind[label] / blind_shifted[label] (2 coefficients each: `Rand::rand(hiding_bound = 1)` of KZG10::commit);
+    ch:  alpha, eta_a, eta_b, eta_c, beta, gamma (verifier messages) and xi (the opening challenge).
+    Returns commitments, evaluations (query-set order) and the two opening proofs."""
     c = idx["curve"]
     r = c.r
     dev = Dev(ctx, c)
