@@ -296,52 +296,138 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
     }
   }
 }
-__global__ __launch_bounds__(256) void sort_bin_kernel(const uint64_t* __restrict__ kv,
-                                                       const uint32_t* __restrict__ offs, uint32_t nblocks, int L,
-                                                       uint32_t* __restrict__ vout, uint32_t* __restrict__ start,
-                                                       uint32_t* __restrict__ end) {
-  extern __shared__ uint32_t cnt[];                    // nk counters, reused as cursors
-  __shared__ uint32_t pre[256];
+// Level-1 scatter with LDS staging: the tile's entries are first grouped by bin in LDS (the per-(bin, tile) counts are
+// known from the scanned histogram), then written out so that the lanes of a wave store consecutive addresses
+// inside each bin run — 8-B scattered stores cost 3.2x write amplification at the HBM (rocprofv3 WRITE_SIZE).
+constexpr uint32_t SORT_STAGE_CAP = 8192;          // entries staged per tile (64 KiB)
+template <class FrP>
+__global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t* __restrict__ scalars, size_t n,
+                                                                  size_t offset, const uint8_t* __restrict__ inf,
+                                                                  int montgomery, size_t ntab, int c, int W,
+                                                                  uint32_t nb, int L, uint32_t nbins1,
+                                                                  const uint32_t* __restrict__ offs, uint32_t nblocks,
+                                                                  uint64_t* __restrict__ kv) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t stage[];          // SORT_STAGE_CAP entries
+  uint16_t* sbin = reinterpret_cast<uint16_t*>(stage + SORT_STAGE_CAP);     // bin of every staged entry
+  __shared__ uint32_t gstart[1 << SORT_H1_MAX], lpre[1 << SORT_H1_MAX], lcur[1 << SORT_H1_MAX];
+  __shared__ uint32_t part[256];
+  const uint32_t t = threadIdx.x;
+  // per-bin run of this tile: global start and length
+  const uint32_t per = (nbins1 + 255) / 256;
+  uint32_t acc = 0;
+  for (uint32_t k = 0; k < per; k++) {
+    uint32_t i = t * per + k;
+    if (i < nbins1) {
+      size_t o = (size_t)i * nblocks + blockIdx.x;
+      uint32_t o0 = offs[o], o1 = offs[o + 1];
+      gstart[i] = o0;
+      lpre[i] = o1 - o0;
+      acc += o1 - o0;
+    }
+  }
+  part[t] = acc;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    uint32_t add = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  const uint32_t total = part[255];
+  uint32_t run = part[t] - acc;
+  for (uint32_t k = 0; k < per; k++) {
+    uint32_t i = t * per + k;
+    if (i < nbins1) {
+      uint32_t v = lpre[i];
+      lpre[i] = run;
+      lcur[i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  const uint32_t lmask = (1u << L) - 1;
+  for (int rep = 0; rep < SORT_SCALARS / 256; rep++) {
+    size_t i = (size_t)blockIdx.x * SORT_SCALARS + rep * 256 + t;
+    if (i < n && !(inf && inf[offset + i])) {
+      DigitIter it = load_scalar<FrP>(scalars, i, montgomery);
+      for (int w = 0; w < W; w++) {
+        uint32_t key, neg;
+        it.next(w, c, nb, key, neg);
+        if (key < nb) {
+          const uint32_t bin = key >> L;
+          uint32_t slot = atomicAdd(&lcur[bin], 1u);
+          uint32_t val = (uint32_t)((size_t)w * ntab + offset + i) | (neg << 31);
+          stage[slot] = ((uint64_t)(key & lmask) << 32) | val;
+          sbin[slot] = (uint16_t)bin;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t sidx = t; sidx < total; sidx += 256) {
+    const uint32_t bin = sbin[sidx];
+    kv[gstart[bin] + (sidx - lpre[bin])] = stage[sidx];
+  }
+}
+
+constexpr uint32_t SORT_BIN_THREADS = 1024;
+constexpr uint32_t SORT_BIN_STAGE = 20480;      // values staged in LDS (80 KiB) so the output is written fully coalesced
+__global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64_t* __restrict__ kv,
+                                                                    const uint32_t* __restrict__ offs,
+                                                                    uint32_t nblocks, int L,
+                                                                    uint32_t* __restrict__ vout,
+                                                                    uint32_t* __restrict__ start,
+                                                                    uint32_t* __restrict__ end) {
+  extern __shared__ uint32_t sm[];                     // [nk] counters / cursors, then [SORT_BIN_STAGE] staged values
+  __shared__ uint32_t pre[SORT_BIN_THREADS];
   const uint32_t nk = 1u << L;
-  const uint32_t b = blockIdx.x;
+  uint32_t* cnt = sm;
+  uint32_t* stage = sm + nk;
+  const uint32_t b = blockIdx.x, T = SORT_BIN_THREADS, t = threadIdx.x;
   const uint32_t lo = offs[(size_t)b * nblocks], hi = offs[(size_t)(b + 1) * nblocks];
-  for (uint32_t i = threadIdx.x; i < nk; i += 256) cnt[i] = 0;
+  const bool staged = hi - lo <= SORT_BIN_STAGE;       // block-uniform
+  for (uint32_t i = t; i < nk; i += T) cnt[i] = 0;
   __syncthreads();
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&cnt[(uint32_t)(kv[i] >> 32)], 1u);
+  for (uint32_t i = lo + t; i < hi; i += T) atomicAdd(&cnt[(uint32_t)(kv[i] >> 32)], 1u);
   __syncthreads();
-  // exclusive scan of the nk counters: `per` consecutive counters per thread + Hillis-Steele over 256 partials
+  // exclusive scan of the nk counters: `per` consecutive counters per thread + Hillis-Steele over the partials
   {
-    const uint32_t per = (nk + 255) / 256;
+    const uint32_t per = (nk + T - 1) / T;
     uint32_t acc = 0;
     for (uint32_t k = 0; k < per; k++) {
-      uint32_t idx = threadIdx.x * per + k;
+      uint32_t idx = t * per + k;
       if (idx < nk) acc += cnt[idx];
     }
-    pre[threadIdx.x] = acc;
+    pre[t] = acc;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-      uint32_t add = (int)threadIdx.x >= d ? pre[threadIdx.x - d] : 0;
+    for (uint32_t d = 1; d < T; d <<= 1) {
+      uint32_t add = t >= d ? pre[t - d] : 0;
       __syncthreads();
-      pre[threadIdx.x] += add;
+      pre[t] += add;
       __syncthreads();
     }
-    uint32_t run = pre[threadIdx.x] - acc;
+    uint32_t run = pre[t] - acc;
     for (uint32_t k = 0; k < per; k++) {
-      uint32_t idx = threadIdx.x * per + k;
+      uint32_t idx = t * per + k;
       if (idx < nk) {
         uint32_t v = cnt[idx];
         start[((size_t)b << L) + idx] = lo + run;
         end[((size_t)b << L) + idx] = lo + run + v;
-        cnt[idx] = lo + run;                            // cursor
+        cnt[idx] = run;                                 // cursor, relative to lo
         run += v;
       }
     }
   }
   __syncthreads();
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+  for (uint32_t i = lo + t; i < hi; i += T) {
     const uint64_t x = kv[i];
     uint32_t pos = atomicAdd(&cnt[(uint32_t)(x >> 32)], 1u);
-    vout[pos] = (uint32_t)x;
+    if (staged) stage[pos] = (uint32_t)x;
+    else vout[lo + pos] = (uint32_t)x;                  // oversized bin (skewed scalars): direct scatter
+  }
+  if (staged) {
+    __syncthreads();
+    for (uint32_t i = t; i < hi - lo; i += T) vout[lo + i] = stage[i];
   }
 }
 
@@ -457,20 +543,32 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     uint32_t* start = ws.offsets.as<uint32_t>(2 * (size_t)nb);
     uint32_t* end = start + nb;
     ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
+    static const bool stage_env = [] { const char* e = getenv("ZKP_SORT_STAGE"); return e && atoi(e) != 0; }();   // default off: measured 4 % slower end to end (92 KiB LDS -> 1 workgroup per CU)
+    const bool stage_ok = stage_env && (size_t)SORT_SCALARS * W <= SORT_STAGE_CAP;
+    const size_t stage_lds = (size_t)SORT_STAGE_CAP * 8 + (size_t)SORT_STAGE_CAP * 2;
     if (be->curve == ZKP_BN254) {
       hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
                          nb, LB, nbins1, hist, nblocks);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-      hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
-                         be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
+      if (stage_ok)
+        hipLaunchKernelGGL(sort_scatter_staged_kernel<Bn254Fr>, dim3(nblocks), dim3(256), stage_lds, st, sc, n, offset,
+                           be->inf, mont, be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
+      else
+        hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
+                           be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
     } else {
       hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
                          nb, LB, nbins1, hist, nblocks);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-      hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
-                         be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
+      if (stage_ok)
+        hipLaunchKernelGGL(sort_scatter_staged_kernel<Bls381Fr>, dim3(nblocks), dim3(256), stage_lds, st, sc, n, offset,
+                           be->inf, mont, be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
+      else
+        hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
+                           be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
     }
-    hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(256), ((size_t)4 << LB), st, kv, offs, nblocks, LB, vals,
+    hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(SORT_BIN_THREADS), ((size_t)4 << LB) + 4 * (size_t)SORT_BIN_STAGE, st,
+                       kv, offs, nblocks, LB, vals,
                        start, end);
     uint32_t* const sorted_vals = vals;
     // K7 scheduling: buckets -> tasks (<= CAP entries), ordered by length
