@@ -40,8 +40,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20, help="QAP domain 2^k (k=20 is the BASELINE metric config)")
     ap.add_argument("--curve", default="bn254")
     ap.add_argument("--cpu-log-n", type=int, default=16, help="size of the bounded cpu_baseline sample")
