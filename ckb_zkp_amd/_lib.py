@@ -72,6 +72,11 @@ SIGNATURES = {
     "zkp_vartime_multiscalar_mul_g2": (C.c_int32, [vp, C.c_uint64, vp, C.c_size_t, vp]),
     "zkp_msm_g1_mont_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
     "zkp_fr_vec_op_dev": (C.c_int32, [vp, C.c_int, C.c_int32, vp, vp, vp, vp, C.c_size_t]),
+    "zkp_fr_spmv_dev": (C.c_int32, [vp, C.c_int, vp, vp, vp, C.c_size_t, vp, vp]),
+    "zkp_fr_gather_dev": (C.c_int32, [vp, vp, vp, C.c_size_t, vp]),
+    "zkp_poly_divide_by_vanishing_dev": (C.c_int32, [vp, C.c_int, vp, C.c_size_t, C.c_size_t, vp, vp]),
+    "zkp_d2d": (C.c_int32, [vp, vp, vp, C.c_size_t]),
+    "zkp_dev_zero": (C.c_int32, [vp, vp, C.c_size_t]),
     "zkp_fr_batch_inverse_dev": (C.c_int32, [vp, C.c_int, vp, C.c_size_t]),
     "zkp_poly_evaluate_dev": (C.c_int32, [vp, C.c_int, vp, C.c_size_t, vp, vp]),
     "zkp_poly_div_linear_dev": (C.c_int32, [vp, C.c_int, vp, C.c_size_t, vp, vp, vp]),

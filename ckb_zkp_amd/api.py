@@ -237,3 +237,37 @@ def _bases_msm_mont_dev(self, scalars_dev: int, n: int, offset: int = 0) -> np.n
 
 
 Bases.msm_mont_dev = _bases_msm_mont_dev
+
+
+VEC_ADDC = 5
+
+
+@_ctx_method
+def fr_spmv(self, curve, row_ptr_dev: int, col_dev: int, coeff_dev: int, nrows: int, x_dev: int, out_dev: int):
+    """out = M x for a CSR matrix resident in HBM (z_a = A z, and the transposed product behind Marlin's t)."""
+    _lib.check(self.lib.zkp_fr_spmv_dev(self.h, get_curve(curve).cid, C.c_void_p(row_ptr_dev), C.c_void_p(col_dev),
+                                        C.c_void_p(coeff_dev), nrows, C.c_void_p(x_dev), C.c_void_p(out_dev)),
+               "zkp_fr_spmv_dev")
+
+
+@_ctx_method
+def fr_gather(self, in_dev: int, idx_dev: int, n: int, out_dev: int):
+    _lib.check(self.lib.zkp_fr_gather_dev(self.h, C.c_void_p(in_dev), C.c_void_p(idx_dev), n, C.c_void_p(out_dev)),
+               "zkp_fr_gather_dev")
+
+
+@_ctx_method
+def poly_divide_by_vanishing(self, curve, p_dev: int, length: int, n: int, q_dev: int | None, rem_dev: int | None):
+    _lib.check(self.lib.zkp_poly_divide_by_vanishing_dev(self.h, get_curve(curve).cid, C.c_void_p(p_dev), length, n,
+                                                         C.c_void_p(q_dev or 0), C.c_void_p(rem_dev or 0)),
+               "zkp_poly_divide_by_vanishing_dev")
+
+
+@_ctx_method
+def d2d(self, dst_dev: int, src_dev: int, nbytes: int):
+    _lib.check(self.lib.zkp_d2d(self.h, C.c_void_p(dst_dev), C.c_void_p(src_dev), nbytes), "zkp_d2d")
+
+
+@_ctx_method
+def dev_zero(self, dst_dev: int, nbytes: int):
+    _lib.check(self.lib.zkp_dev_zero(self.h, C.c_void_p(dst_dev), nbytes), "zkp_dev_zero")

@@ -262,9 +262,31 @@ int32_t zkp_msm_g1_mont_dev(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t
 int32_t zkp_fr_vec_op_dev(zkp_ctx* ctx, zkp_curve_t curve, int32_t op, const uint64_t* a, const uint64_t* b,
                           const uint64_t* k, uint64_t* out, size_t n) {
   if (n && (!a || !out)) return ZKP_ERR_BAD_ARG;
-  if (n && op != ZKP_VEC_SCALE && !b) return ZKP_ERR_BAD_ARG;
-  if ((op == ZKP_VEC_SCALE || op == ZKP_VEC_AXPY) && !k) return ZKP_ERR_BAD_ARG;
+  if (n && op != ZKP_VEC_SCALE && op != ZKP_VEC_ADDC && !b) return ZKP_ERR_BAD_ARG;
+  if ((op == ZKP_VEC_SCALE || op == ZKP_VEC_AXPY || op == ZKP_VEC_ADDC) && !k) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { fr_vec_op(ctx, curve, op, a, b, k, out, n); });
+}
+int32_t zkp_fr_spmv_dev(zkp_ctx* ctx, zkp_curve_t curve, const uint32_t* row_ptr, const uint32_t* col,
+                        const uint64_t* coeff, size_t nrows, const uint64_t* x, uint64_t* out) {
+  if (nrows && (!row_ptr || !x || !out)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { fr_spmv(ctx, curve, row_ptr, col, coeff, nrows, x, out); });
+}
+int32_t zkp_fr_gather_dev(zkp_ctx* ctx, const uint64_t* in, const int32_t* idx, size_t n, uint64_t* out) {
+  if (n && (!in || !idx || !out)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { fr_gather(ctx, in, idx, n, out); });
+}
+int32_t zkp_poly_divide_by_vanishing_dev(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* p, size_t len, size_t n,
+                                         uint64_t* q, uint64_t* rem) {
+  if ((len && !p) || n == 0) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { poly_vanishing_fold(ctx, curve, p, len, n, q, rem); });
+}
+int32_t zkp_d2d(zkp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes && (!dst || !src)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { if (bytes) ZKP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->cur->stream)); });
+}
+int32_t zkp_dev_zero(zkp_ctx* ctx, void* dst, size_t bytes) {
+  if (bytes && !dst) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { if (bytes) ZKP_HIP(hipMemsetAsync(dst, 0, bytes, ctx->cur->stream)); });
 }
 int32_t zkp_fr_batch_inverse_dev(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* v, size_t n) {
   if (n && !v) return ZKP_ERR_BAD_ARG;

@@ -12,6 +12,10 @@ void ntt_free_tables(zkp_ctx* ctx);
 void fr_vec_op(zkp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, const uint64_t* k_host,
                uint64_t* out, size_t n);
 void fr_batch_inverse(zkp_ctx* ctx, int curve, uint64_t* v, size_t n);
+void fr_spmv(zkp_ctx* ctx, int curve, const uint32_t* row_ptr, const uint32_t* col, const uint64_t* coeff, size_t nrows,
+             const uint64_t* x, uint64_t* out);
+void fr_gather(zkp_ctx* ctx, const uint64_t* in, const int32_t* idx, size_t n, uint64_t* out);
+void poly_vanishing_fold(zkp_ctx* ctx, int curve, const uint64_t* p, size_t len, size_t n, uint64_t* q, uint64_t* rem);
 void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const uint64_t* z_host, uint64_t* q,
                      uint64_t* eval_out_host);
 

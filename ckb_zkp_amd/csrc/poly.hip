@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void vec_op_kernel(const uint32_t* __restrict_
     case 1: r = x + F::load(b + i * 8); break;                       // add
     case 2: r = x - F::load(b + i * 8); break;                       // sub
     case 3: r = x * F::load(k); break;                               // scale by constant
+    case 5: r = x + F::load(k); break;                               // add constant
     default: r = x + F::load(b + i * 8) * F::load(k); break;         // axpy: a + k*b
   }
   r.store(out + i * 8);
@@ -163,7 +164,7 @@ static void poly_div_linear_t(zkp_ctx* ctx, const uint32_t* p, size_t n, const u
 
 void fr_vec_op(zkp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, const uint64_t* k_host,
                uint64_t* out, size_t n) {
-  ZKP_REQUIRE(op >= 0 && op <= 4, ZKP_ERR_BAD_ARG);
+  ZKP_REQUIRE(op >= 0 && op <= 5, ZKP_ERR_BAD_ARG);
   uint32_t* kd = ctx->poly_consts.as<uint32_t>(64);
   if (k_host) ZKP_HIP(hipMemcpyAsync(kd, k_host, 32, hipMemcpyHostToDevice, ctx->cur->stream));
   if (n == 0) return;
@@ -172,6 +173,84 @@ void fr_vec_op(zkp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_
     hipLaunchKernelGGL(vec_op_kernel<P>, dim3((n + 255) / 256), dim3(256), 0, ctx->cur->stream,
                        reinterpret_cast<const uint32_t*>(a), reinterpret_cast<const uint32_t*>(b), kd,
                        reinterpret_cast<uint32_t*>(out), n, op);
+  };
+  if (curve == ZKP_BN254) launch(Bn254Fr{});
+  else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});
+  else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+  ZKP_HIP(hipGetLastError());
+}
+
+// out[i] = sum_k coeff[k] * x[col[k]], k in [row_ptr[i], row_ptr[i+1])   (z_a = A z, t = (eta_a A + ...)^T r_alpha, ...)
+template <class P>
+__global__ __launch_bounds__(256) void spmv_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                   const uint32_t* __restrict__ coeff, const uint32_t* __restrict__ x,
+                                                   size_t nrows, uint32_t* __restrict__ out) {
+  using F = Fp<P>;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows) return;
+  F acc = F::zero();
+  const F one = F::one();
+  for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; k++) {
+    F v = F::load(x + (size_t)col[k] * 8), cf = F::load(coeff + (size_t)k * 8);
+    acc = cf == one ? acc + v : acc + v * cf;
+  }
+  acc.store(out + i * 8);
+}
+// out[i] = idx[i] < 0 ? 0 : in[idx[i]]
+__global__ __launch_bounds__(256) void gather_kernel(const uint4* __restrict__ in, const int32_t* __restrict__ idx, size_t n,
+                                                     uint4* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t j = idx[i];
+  uint4 z = make_uint4(0, 0, 0, 0);
+  out[2 * i] = j < 0 ? z : in[2 * (size_t)j];
+  out[2 * i + 1] = j < 0 ? z : in[2 * (size_t)j + 1];
+}
+// p = q (X^n - 1) + rem:  q[i] = sum_{k>=1} p[i + k n] (i < len - n),  rem[i] = p[i] + q[i] (i < n)
+template <class P>
+__global__ __launch_bounds__(256) void vanishing_fold_kernel(const uint32_t* __restrict__ p, size_t len, size_t n,
+                                                             uint32_t* __restrict__ q, uint32_t* __restrict__ rem) {
+  using F = Fp<P>;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t qlen = len > n ? len - n : 0;
+  if (i >= (qlen > n ? qlen : n)) return;
+  F acc = F::zero();
+  for (size_t j = i + n; j < len; j += n) acc = acc + F::load(p + j * 8);
+  if (i < qlen && q) acc.store(q + i * 8);
+  if (i < n && rem) {
+    F lo = i < len ? F::load(p + i * 8) : F::zero();
+    (lo + (i < qlen ? acc : F::zero())).store(rem + i * 8);
+  }
+}
+
+void fr_spmv(zkp_ctx* ctx, int curve, const uint32_t* row_ptr, const uint32_t* col, const uint64_t* coeff, size_t nrows,
+             const uint64_t* x, uint64_t* out) {
+  if (nrows == 0) return;
+  auto launch = [&](auto tag) {
+    using P = decltype(tag);
+    hipLaunchKernelGGL(spmv_kernel<P>, dim3((nrows + 255) / 256), dim3(256), 0, ctx->cur->stream, row_ptr, col,
+                       reinterpret_cast<const uint32_t*>(coeff), reinterpret_cast<const uint32_t*>(x), nrows,
+                       reinterpret_cast<uint32_t*>(out));
+  };
+  if (curve == ZKP_BN254) launch(Bn254Fr{});
+  else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});
+  else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+  ZKP_HIP(hipGetLastError());
+}
+void fr_gather(zkp_ctx* ctx, const uint64_t* in, const int32_t* idx, size_t n, uint64_t* out) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->cur->stream,
+                     reinterpret_cast<const uint4*>(in), idx, n, reinterpret_cast<uint4*>(out));
+  ZKP_HIP(hipGetLastError());
+}
+void poly_vanishing_fold(zkp_ctx* ctx, int curve, const uint64_t* p, size_t len, size_t n, uint64_t* q, uint64_t* rem) {
+  ZKP_REQUIRE(n > 0, ZKP_ERR_BAD_ARG);
+  size_t qlen = len > n ? len - n : 0, work = std::max(qlen, n);
+  auto launch = [&](auto tag) {
+    using P = decltype(tag);
+    hipLaunchKernelGGL(vanishing_fold_kernel<P>, dim3((work + 255) / 256), dim3(256), 0, ctx->cur->stream,
+                       reinterpret_cast<const uint32_t*>(p), len, n, reinterpret_cast<uint32_t*>(q),
+                       reinterpret_cast<uint32_t*>(rem));
   };
   if (curve == ZKP_BN254) launch(Bn254Fr{});
   else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});

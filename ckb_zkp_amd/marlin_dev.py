@@ -1,0 +1,386 @@
+"""Device-resident Marlin prover: the same algorithm as `marlin.create_proof` (reference: marlin/src/lib.rs:97-181,
+ahp/prover.rs:86-427, pc/mod.rs:34-160) but every vector stays in HBM from the witness to the opening proofs — NTTs,
+element-wise arithmetic, batch inversions, sparse products (z_a = A z, the transposed product behind `t`), gathers,
+vanishing-polynomial folds, evaluations, witness division and the KZG10 MSMs are all C-ABI calls on device pointers;
+the host only handles scalars (challenges, the handful of mask coefficients) and 32-byte read-backs.
+
+`DeviceIndex` is the prover-side image of `Index` / `IndexProverKey` (ahp/indexer.rs:36-68): matrices as CSR, their
+reindexed transposes for `t`, the arithmetization polynomials and their evaluations on K and B.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, api, codec, kzg10
+from .api import Context
+from .marlin import INDEX_LABELS, LABELS_1, LABELS_2, LABELS_3, ZK_BOUND, MarlinCS, _next_pow2, reindex_by_subdomain
+from .params import get_curve
+
+
+class DVec:
+    """n Fr elements (Montgomery) in device memory.  Slices are non-owning views."""
+
+    def __init__(self, be, ptr: int, n: int, owner: bool = True):
+        self.be, self.ptr, self.n, self.owner = be, ptr, n, owner
+
+    def __len__(self):
+        return self.n
+
+    def view(self, a: int, b: int | None = None) -> "DVec":
+        b = self.n if b is None else b
+        assert 0 <= a <= b <= self.n
+        return DVec(self.be, self.ptr + 32 * a, b - a, owner=False)
+
+
+class DeviceBackend:
+    def __init__(self, ctx: Context, curve):
+        self.ctx, self.c = ctx, get_curve(curve)
+        self.lib, self.h, self.cid = ctx.lib, ctx.h, self.c.cid
+        self._live = []
+
+    # ---- memory
+    def alloc(self, n: int) -> DVec:
+        v = DVec(self, self.ctx.dev_alloc(max(n, 1) * 32), n)
+        self._live.append(v)
+        return v
+
+    def zeros(self, n: int) -> DVec:
+        v = self.alloc(n)
+        _lib.check(self.lib.zkp_dev_zero(self.h, C.c_void_p(v.ptr), n * 32), "zkp_dev_zero")
+        return v
+
+    def upload(self, ints) -> DVec:
+        a = codec.fr_to_mont(ints, self.c).reshape(-1, 4)
+        v = self.alloc(len(ints))
+        if len(ints):
+            self.ctx.h2d(v.ptr, a)
+        return v
+
+    def upload_mont(self, a: np.ndarray) -> DVec:
+        v = self.alloc(a.shape[0])
+        if a.shape[0]:
+            self.ctx.h2d(v.ptr, a)
+        return v
+
+    def upload_raw(self, a: np.ndarray) -> int:
+        p = self.ctx.to_device(np.ascontiguousarray(a))
+        self._live.append(DVec(self, p, 0))
+        return p
+
+    def download(self, v: DVec) -> list:
+        out = np.zeros((v.n, 4), dtype=np.uint64)
+        if v.n:
+            self.ctx.d2h(out, v.ptr)
+        return codec.fr_from_mont(out, self.c)
+
+    def copy_into(self, dst: DVec, src: DVec):
+        assert dst.n >= src.n
+        _lib.check(self.lib.zkp_d2d(self.h, C.c_void_p(dst.ptr), C.c_void_p(src.ptr), src.n * 32), "zkp_d2d")
+
+    def pad(self, v: DVec, n: int) -> DVec:
+        """copy of v zero-extended (or truncated) to n elements"""
+        out = self.zeros(n)
+        self.copy_into(out, v.view(0, min(v.n, n)))
+        return out
+
+    def shift(self, v: DVec, s: int) -> DVec:
+        out = self.zeros(v.n + s)
+        self.copy_into(out.view(s), v)
+        return out
+
+    def release_all(self):
+        for v in self._live:
+            if v.owner and v.ptr:
+                self.ctx.dev_free(v.ptr)
+                v.ptr = 0
+        self._live = []
+
+    # ---- arithmetic
+    def _k(self, k):
+        return None if k is None else api._ptr(codec.fr_to_mont([k % self.c.r], self.c)[0])
+
+    def _op(self, op, a: DVec, b: DVec | None, out: DVec, n: int, k=None):
+        _lib.check(self.lib.zkp_fr_vec_op_dev(self.h, self.cid, op, C.c_void_p(a.ptr), C.c_void_p(b.ptr if b else 0),
+                                              self._k(k), C.c_void_p(out.ptr), n), "zkp_fr_vec_op_dev")
+
+    def mul(self, a: DVec, b: DVec) -> DVec:
+        assert a.n == b.n
+        out = self.alloc(a.n)
+        self._op(api.VEC_MUL, a, b, out, a.n)
+        return out
+
+    def scale(self, a: DVec, k: int) -> DVec:
+        out = self.alloc(a.n)
+        self._op(api.VEC_SCALE, a, None, out, a.n, k)
+        return out
+
+    def addc(self, a: DVec, k: int) -> DVec:
+        out = self.alloc(a.n)
+        self._op(5, a, None, out, a.n, k)
+        return out
+
+    def axpy(self, a: DVec, b: DVec, k: int) -> DVec:
+        """a + k*b with zero extension to max(len)"""
+        n = max(a.n, b.n)
+        out = self.pad(a, n)
+        self._op(api.VEC_AXPY, out.view(0, b.n), b, out.view(0, b.n), b.n, k)
+        return out
+
+    def axpy_into(self, acc: DVec, b: DVec, k: int, at: int = 0):
+        """acc[at : at + len(b)] += k * b"""
+        tgt = acc.view(at, at + b.n)
+        self._op(api.VEC_AXPY, tgt, b, tgt, b.n, k)
+
+    def add_at(self, v: DVec, i: int, k: int):
+        e = v.view(i, i + 1)
+        self._op(5, e, None, e, 1, k)
+
+    def sub(self, a: DVec, b: DVec) -> DVec:
+        return self.axpy(a, b, -1)
+
+    def binv(self, a: DVec) -> DVec:
+        out = self.pad(a, a.n)
+        _lib.check(self.lib.zkp_fr_batch_inverse_dev(self.h, self.cid, C.c_void_p(out.ptr), out.n), "zkp_fr_batch_inverse_dev")
+        return out
+
+    def ntt(self, v: DVec, size: int, op: int) -> DVec:
+        out = self.pad(v, size)
+        self.ctx.ntt_dev(self.c, out.ptr, size.bit_length() - 1, op)
+        return out
+
+    def fft(self, v, size):
+        return self.ntt(v, size, api.NTT_FFT)
+
+    def ifft(self, v, size=None):
+        return self.ntt(v, size or _next_pow2(v.n), api.NTT_IFFT)
+
+    def pmul(self, a: DVec, b: DVec) -> DVec:
+        size = _next_pow2(a.n + b.n - 1)
+        return self.ifft(self.mul(self.fft(a, size), self.fft(b, size))).view(0, a.n + b.n - 1)
+
+    def evaluate(self, v: DVec, z: int) -> int:
+        if v.n == 0:
+            return 0
+        out = self.ctx.poly_evaluate(self.c, v.ptr, v.n, codec.fr_to_mont([z], self.c)[0])
+        return codec.fr_from_mont(out.reshape(1, 4), self.c)[0]
+
+    def fold(self, v: DVec, n: int):
+        """divide_by_vanishing_poly: -> (q [len - n], rem [n])"""
+        q = self.alloc(max(v.n - n, 0))
+        rem = self.alloc(n)
+        _lib.check(self.lib.zkp_poly_divide_by_vanishing_dev(self.h, self.cid, C.c_void_p(v.ptr), v.n, n,
+                                                             C.c_void_p(q.ptr if q.n else 0), C.c_void_p(rem.ptr)),
+                   "zkp_poly_divide_by_vanishing_dev")
+        return q, rem
+
+    def element(self, v: DVec, i: int) -> int:
+        return self.download(v.view(i, i + 1))[0]
+
+    def spmv(self, csr, x: DVec, nrows: int) -> DVec:
+        out = self.alloc(nrows)
+        _lib.check(self.lib.zkp_fr_spmv_dev(self.h, self.cid, C.c_void_p(csr[0]), C.c_void_p(csr[1]), C.c_void_p(csr[2]),
+                                            nrows, C.c_void_p(x.ptr), C.c_void_p(out.ptr)), "zkp_fr_spmv_dev")
+        return out
+
+    def gather(self, v: DVec, idx_dev: int, n: int) -> DVec:
+        out = self.alloc(n)
+        _lib.check(self.lib.zkp_fr_gather_dev(self.h, C.c_void_p(v.ptr), C.c_void_p(idx_dev), n, C.c_void_p(out.ptr)),
+                   "zkp_fr_gather_dev")
+        return out
+
+    def msm(self, bases, v: DVec, offset: int = 0) -> np.ndarray:
+        return bases.msm_mont_dev(v.ptr, v.n, offset=offset)
+
+
+def _csr_dev(be: DeviceBackend, rows, ncols_unused=None):
+    """list of rows [(coeff, col)] -> device (row_ptr, col, coeff) pointers"""
+    rp = np.zeros(len(rows) + 1, dtype=np.uint32)
+    cols, cfs = [], []
+    for i, row in enumerate(rows):
+        for cf, j in row:
+            cols.append(j)
+            cfs.append(cf)
+        rp[i + 1] = len(cols)
+    cf = codec.fr_to_mont(cfs, be.c).reshape(-1, 4) if cfs else np.zeros((1, 4), dtype=np.uint64)
+    cl = np.asarray(cols if cols else [0], dtype=np.uint32)
+    return (be.upload_raw(rp), be.upload_raw(cl), be.upload_raw(cf))
+
+
+class DeviceIndex:
+    """Upload of a host index (marlin.index) — the prover key's polynomial data, resident in HBM."""
+
+    def __init__(self, ctx: Context, idx):
+        self.idx = idx
+        c = self.curve = idx["curve"]
+        be = self.be = DeviceBackend(ctx, c)
+        hs, xs = idx["hs"], idx["xs"]
+        self.csr = {m: _csr_dev(be, idx[m]) for m in "abc"}
+        # transposed, re-indexed matrices: t_on_h[k] = sum_{(i, j): reindex(j) = k} coeff * r_alpha[i]  (prover.rs:259-269)
+        self.csr_t = {}
+        for m in "abc":
+            rows = [[] for _ in range(hs)]
+            for i, row in enumerate(idx[m]):
+                for cf, j in row:
+                    rows[reindex_by_subdomain(hs, xs, j)].append((cf, i))
+            self.csr_t[m] = _csr_dev(be, rows)
+        self.h_el = be.upload(idx["h_el"])
+        S = idx["star"]
+        self.on_k = {m: {k: be.upload(S[m]["on_k"][k]) for k in ("row", "col", "val")} for m in "abc"}
+        self.on_b = {m: {k: be.upload(S[m]["on_b"][k]) for k in ("row", "col", "val", "row_col")} for m in "abc"}
+        self.polys = {f"{m}_{k}": be.upload(S[m]["polys"][k]) for m in "abc" for k in ("row", "col", "val", "row_col")}
+        ratio = hs // xs
+        # w_evals_on_h[i] = 0 if i % ratio == 0 else w_ext[i - i/ratio - 1] - x_evals_on_h[i]   (prover.rs:176-186)
+        self.w_idx = be.upload_raw(np.asarray([-1 if i % ratio == 0 else i - i // ratio - 1 for i in range(hs)], dtype=np.int32))
+        self.x_idx = be.upload_raw(np.asarray([-1 if i % ratio == 0 else i for i in range(hs)], dtype=np.int32))
+        be._live = []          # index data stays resident: hand ownership to the index
+
+    def free(self):
+        pass                    # released with the context (test/bench lifetime)
+
+
+def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circuit, rnd, ch, timing: dict | None = None):
+    """Device-resident `create_random_proof` with explicit randomness / challenges (same dictionaries as
+    marlin.create_proof).  Returns commitments, evaluations (query order) and opening proofs as canonical integers."""
+    import time
+    idx = didx.idx
+    c = idx["curve"]
+    r = c.r
+    be = DeviceBackend(ctx, c)
+    xs, hs, ks, bs = idx["xs"], idx["hs"], idx["ks"], idx["bs"]
+    D = idx["max_degree"]
+    t_start = time.perf_counter()
+    try:
+        # ---- prover_init: synthesis on the host, everything else on the device
+        cs = MarlinCS(c, assign=True)
+        circuit.generate_constraints(cs)
+        cs.make_matrices_square()
+        x, w = cs.input_assignment, cs.aux_assignment
+        z = be.upload(x + w)
+        ctx.sync()
+        t0 = time.perf_counter()
+        z_a_ev = be.spmv(didx.csr["a"], z, len(idx["a"]))
+        z_b_ev = be.spmv(didx.csr["b"], z, len(idx["b"]))
+        # ---- first round (prover.rs:150-222)
+        x_poly = be.ifft(be.upload(x), xs)
+        x_on_h = be.fft(x_poly, hs)
+        w_ext = be.pad(z.view(len(x)), hs - xs)
+        w_on_h = be.sub(be.gather(w_ext, didx.w_idx, hs), be.gather(x_on_h, didx.x_idx, hs))
+
+        def masked(ev: DVec, rand_coeff: int) -> DVec:      # interpolate(ev) + rand * v_H
+            p = be.pad(be.ifft(ev, hs), hs + 1)
+            be.add_at(p, 0, -rand_coeff)
+            be.add_at(p, hs, rand_coeff)
+            return p
+
+        w_poly, _ = be.fold(masked(w_on_h, rnd["w"][0]), xs)
+        z_a, z_b = masked(z_a_ev, rnd["z_a"][0]), masked(z_b_ev, rnd["z_b"][0])
+        mask = be.upload(rnd["mask"])
+        _, mrem = be.fold(mask, hs)
+        be.add_at(mask, 0, -be.element(mrem, 0))
+        polys = dict(didx.polys)
+        polys.update(w=w_poly, z_a=z_a, z_b=z_b, mask=mask)
+        # ---- second round (prover.rs:230-321)
+        alpha, ea, eb, ec, beta, gamma = ch["alpha"], ch["eta_a"], ch["eta_b"], ch["eta_c"], ch["beta"], ch["gamma"]
+        m_poly = be.axpy(be.axpy(be.scale(be.pmul(z_a, z_b), ec), z_a, ea), z_b, eb)
+        v_alpha = (pow(alpha, hs, r) - 1) % r
+        r_alpha_on_h = be.scale(be.binv(be.addc(be.scale(didx.h_el, r - 1), alpha)), v_alpha)
+        r_alpha = be.ifft(r_alpha_on_h, hs)
+        t_on_h = be.zeros(hs)
+        for m, eta in (("a", ea), ("b", eb), ("c", ec)):
+            be.axpy_into(t_on_h, be.spmv(didx.csr_t[m], r_alpha_on_h, hs), eta)
+        t_poly = be.ifft(t_on_h, hs)
+        z_poly = be.sub(be.shift(w_poly, xs), w_poly)          # w * v_X
+        z_poly = be.axpy(z_poly, x_poly, 1)
+        size = _next_pow2(max(mask.n, r_alpha.n + m_poly.n, t_poly.n + z_poly.n))
+        prod = be.sub(be.mul(be.fft(r_alpha, size), be.fft(m_poly, size)), be.mul(be.fft(t_poly, size), be.fft(z_poly, size)))
+        q1 = be.axpy(be.ifft(prod, size), mask, 1)
+        h1, xg1 = be.fold(q1, hs)
+        polys.update(t=t_poly, g_1=xg1.view(1, hs), h_1=h1.view(0, 2 * hs))
+        # ---- third round (prover.rs:331-427)
+        va, vb = v_alpha, (pow(beta, hs, r) - 1) % r
+        acc = be.zeros(ks)
+        for m, eta in (("a", ea), ("b", eb), ("c", ec)):
+            ok = didx.on_k[m]
+            inv = be.binv(be.mul(be.addc(be.scale(ok["row"], r - 1), beta), be.addc(be.scale(ok["col"], r - 1), alpha)))
+            be.axpy_into(acc, be.mul(ok["val"], inv), eta)
+        t3 = be.ifft(be.scale(acc, va * vb % r), ks)
+        den = {}
+        for m in "abc":
+            ob = didx.on_b[m]
+            d = be.axpy(be.axpy(ob["row_col"], ob["row"], -alpha), ob["col"], -beta)
+            den[m] = be.addc(d, alpha * beta % r)
+        a_on_b = be.zeros(bs)
+        for m, eta, o1_, o2_ in (("a", ea, "b", "c"), ("b", eb, "c", "a"), ("c", ec, "a", "b")):
+            be.axpy_into(a_on_b, be.mul(be.mul(didx.on_b[m]["val"], den[o1_]), den[o2_]), eta)
+        a_poly = be.ifft(be.scale(a_on_b, va * vb % r), bs)
+        b_poly = be.ifft(be.mul(be.mul(den["a"], den["b"]), den["c"]), bs)
+        # degrees: a, b <= 3|K| - 3; t3 < |K|
+        h2, _ = be.fold(be.sub(a_poly.view(0, 3 * ks - 2), be.pmul(b_poly.view(0, 3 * ks - 2), t3)), ks)
+        polys.update(g_2=t3.view(1, ks), h_2=h2.view(0, 3 * ks - 3))
+        ctx.sync()
+        t_rounds = time.perf_counter()
+        # ---- PC::commit (pc/mod.rs:34-71): MSMs against the resident powers
+        bounds = {"g_1": hs - 2, "g_2": ks - 2}
+        hide = lambda l: l in ("w", "z_a", "z_b", "g_1")
+        blind_dev = {l: be.upload(rnd["blind"][l]) for l in ("w", "z_a", "z_b", "g_1")}
+        blind_s_dev = {"g_1": be.upload(rnd["blind_shifted"]["g_1"])}
+
+        def to_affine(jac):
+            xy, inf = ctx.into_affine(c, 1, jac)
+            return codec.g1_from_mont(xy, [inf], c)[0]
+
+        def commit(l, power_offset=0, blind=None):
+            jac = be.msm(ck.powers_of_g, polys[l], offset=power_offset)
+            if blind is not None:
+                jac = ctx.fold(c, 1, np.concatenate([jac, be.msm(ck.powers_of_gamma_g, blind)]))
+            return to_affine(jac)
+
+        comms = {}
+        for l in LABELS_1 + LABELS_2 + LABELS_3:
+            comm = commit(l, 0, blind_dev[l] if hide(l) else None)
+            shifted = None
+            if l in bounds:
+                shifted = commit(l, D - bounds[l], blind_s_dev[l] if hide(l) else None)
+            comms[l] = (comm, shifted)
+        ctx.sync()
+        t_commit = time.perf_counter()
+        # ---- evaluations + batch_open (lib.rs:147-165, pc/mod.rs:73-160)
+        query = sorted([(l, beta) for l in LABELS_1 + LABELS_2] + [(l, gamma) for l in LABELS_3 + INDEX_LABELS])
+        evals = [be.evaluate(polys[l], pt) for l, pt in query]
+        xi = ch["xi"]
+        proofs = []
+        for pt in sorted({pt for _, pt in query}):
+            p = be.zeros(D + 1)
+            rb, chal = [0, 0], 1
+            for l in sorted(l for l, q in query if q == pt):
+                be.axpy_into(p, polys[l], chal)
+                if hide(l):
+                    rb = [(rb[i] + chal * rnd["blind"][l][i]) % r for i in range(2)]
+                if l in bounds:
+                    sc = chal * xi % r
+                    be.axpy_into(p, polys[l], sc, at=D - bounds[l])
+                    if hide(l):
+                        rb = [(rb[i] + sc * rnd["blind_shifted"][l][i]) % r for i in range(2)]
+                chal = chal * xi % r * xi % r
+            zm = codec.fr_to_mont([pt], c)[0]
+            q = be.alloc(D)
+            ctx.poly_div_linear(c, p.ptr, D + 1, zm, q.ptr)
+            w_jac = be.msm(ck.powers_of_g, q)
+            rand_v = None
+            if any(rb):
+                rbd = be.upload(rb)
+                qb = be.alloc(1)
+                ev = ctx.poly_div_linear(c, rbd.ptr, 2, zm, qb.ptr)
+                w_jac = ctx.fold(c, 1, np.concatenate([w_jac, be.msm(ck.powers_of_gamma_g, qb)]))
+                rand_v = codec.fr_from_mont(ev.reshape(1, 4), c)[0]
+            proofs.append((to_affine(w_jac), rand_v))
+        ctx.sync()
+        t_open = time.perf_counter()
+        if timing is not None:
+            timing.update(synthesis_upload_s=t0 - t_start, rounds_s=t_rounds - t0, commit_s=t_commit - t_rounds,
+                          eval_open_s=t_open - t_commit, total_s=t_open - t0)
+        return dict(commitments=comms, evaluations=evals, opening_proofs=proofs, query=query)
+    finally:
+        be.release_all()

@@ -67,11 +67,25 @@ int32_t zkp_ntt_dev(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* data_dev, uint32_
 
 /* ---- Fr vector / polynomial primitives around the Marlin prover's NTTs and KZG10 MSMs (device pointers) -----
  * vectors: Fr Montgomery, 4 x u64 per element.  k / z: one Fr element in HOST memory. */
-typedef enum { ZKP_VEC_MUL = 0, ZKP_VEC_ADD = 1, ZKP_VEC_SUB = 2, ZKP_VEC_SCALE = 3, ZKP_VEC_AXPY = 4 } zkp_vec_op;
-/* out[i] = a[i]*b[i] | a[i]+b[i] | a[i]-b[i] | k*a[i] | a[i]+k*b[i]   (marlin/src/ahp/prover.rs:248-252,298-305,399-411);
+typedef enum { ZKP_VEC_MUL = 0, ZKP_VEC_ADD = 1, ZKP_VEC_SUB = 2, ZKP_VEC_SCALE = 3, ZKP_VEC_AXPY = 4,
+               ZKP_VEC_ADDC = 5 } zkp_vec_op;
+/* out[i] = a[i]*b[i] | a[i]+b[i] | a[i]-b[i] | k*a[i] | a[i]+k*b[i] | a[i]+k   (marlin/src/ahp/prover.rs:248-252,298-305,399-411);
  * out may alias a or b */
 int32_t zkp_fr_vec_op_dev(zkp_ctx* ctx, zkp_curve_t curve, int32_t op, const uint64_t* a, const uint64_t* b,
                           const uint64_t* k_host, uint64_t* out, size_t n);
+/* sparse matrix-vector product, CSR on the device: out[i] = sum_k coeff[k] * x[col[k]]  (z_a = A z of
+ * marlin/src/ahp/prover.rs:110-123; the `t` accumulation of :259-269 as a transposed product) */
+int32_t zkp_fr_spmv_dev(zkp_ctx* ctx, zkp_curve_t curve, const uint32_t* row_ptr_dev, const uint32_t* col_dev,
+                        const uint64_t* coeff_dev, size_t nrows, const uint64_t* x_dev, uint64_t* out_dev);
+/* out[i] = idx[i] < 0 ? 0 : in[idx[i]]   (interleaving of inputs/witness over H, prover.rs:176-186) */
+int32_t zkp_fr_gather_dev(zkp_ctx* ctx, const uint64_t* in_dev, const int32_t* idx_dev, size_t n, uint64_t* out_dev);
+/* DensePolynomial::divide_by_vanishing_poly (prover.rs:191,204,307,415): p = q (X^n - 1) + rem;
+ * q_dev: len - n coefficients (or NULL), rem_dev: n coefficients (or NULL) */
+int32_t zkp_poly_divide_by_vanishing_dev(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* p_dev, size_t len, size_t n,
+                                         uint64_t* q_dev, uint64_t* rem_dev);
+/* stream-ordered device-to-device copy / zero fill (polynomial shifts, paddings) */
+int32_t zkp_d2d(zkp_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+int32_t zkp_dev_zero(zkp_ctx* ctx, void* dst_dev, size_t bytes);
 /* ark_ff::fields::batch_inversion, in place; zeros stay zero (marlin/src/ahp/prover.rs:357-367) */
 int32_t zkp_fr_batch_inverse_dev(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* v, size_t n);
 /* DensePolynomial::evaluate (marlin/src/lib.rs:147-156): eval_out_host = sum_i p[i] z^i */

@@ -67,3 +67,71 @@ def test_marlin_prover_matches_oracle_and_verifies(ctx, curve, kind):
     finally:
         ck.powers_of_g.free()
         ck.powers_of_gamma_g.free()
+
+
+def test_device_vector_primitives(ctx):
+    """spmv / gather / divide_by_vanishing / add-constant against plain big-int arithmetic."""
+    from ckb_zkp_amd import marlin_dev
+    c = get_curve("bn254")
+    rnd = random.Random(3)
+    be = marlin_dev.DeviceBackend(ctx, c)
+    try:
+        n, ncols = 300, 257
+        x = [rnd.randrange(c.r) for _ in range(ncols)]
+        rows = [[(rnd.choice([1, c.r - 1, rnd.randrange(c.r)]), rnd.randrange(ncols)) for _ in range(rnd.choice([0, 1, 3, 40]))]
+                for _ in range(n)]
+        got = be.download(be.spmv(marlin_dev._csr_dev(be, rows), be.upload(x), n))
+        assert got == [sum(cf * x[j] for cf, j in row) % c.r for row in rows]
+        idx = [rnd.choice([-1, rnd.randrange(ncols)]) for _ in range(500)]
+        import numpy as np
+        got = be.download(be.gather(be.upload(x), be.upload_raw(np.asarray(idx, dtype=np.int32)), len(idx)))
+        assert got == [0 if j < 0 else x[j] for j in idx]
+        for plen, dn in ((1000, 64), (64, 64), (50, 64), (129, 64), (777, 1)):
+            p = [rnd.randrange(c.r) for _ in range(plen)]
+            q, rem = be.fold(be.upload(p), dn)
+            eq, er = marlin.divide_by_vanishing(p, dn, c.r)
+            assert marlin._trim(be.download(q)) == eq and marlin._trim(be.download(rem)) == er, (plen, dn)
+        v = be.upload(x)
+        assert be.download(be.addc(v, 12345)) == [(a + 12345) % c.r for a in x]
+        be.add_at(v, 7, c.r - 5)
+        assert be.element(v, 7) == (x[7] - 5) % c.r
+        assert be.download(be.shift(v.view(0, 5), 3)) == [0, 0, 0] + x[:5]
+    finally:
+        be.release_all()
+
+
+@pytest.mark.parametrize("curve,kind", [("bn254", "mimc"), ("bls12_381", "mimc"), ("bn254", "mini")])
+def test_device_resident_marlin_matches_oracle_and_verifies(ctx, curve, kind):
+    """marlin_dev.create_proof (all vectors resident in HBM) == the oracle prover, and the proof verifies."""
+    from ckb_zkp_amd import marlin_dev
+    c = get_curve(curve)
+    rnd = random.Random(15)
+    if kind == "mimc":
+        consts = [rnd.randrange(c.r) for _ in range(7)]
+        pre = [(rnd.randrange(c.r), rnd.randrange(c.r)) for _ in range(3)]
+        pcirc, pcirc_w = MimcChain(curve, consts, [(None, None)] * 3), MimcChain(curve, consts, pre)
+        ocirc, public = og.MimcChain(OC[curve], consts, pre), []
+    else:
+        pcirc, pcirc_w = Mini(num=10), Mini(2, 3, 10, 10)
+        ocirc, public = og.MiniCircuit(2, 3, 10, 10), [10]
+    oidx = om.index(OC[curve], ocirc)
+    idx = marlin.index(ctx, curve, pcirc)
+    didx = marlin_dev.DeviceIndex(ctx, idx)
+    beta_srs = 0xFEDCBA987654321
+    pp = okzg.setup(OC[curve], idx["max_degree"], beta_srs)
+    ck = kzg10.setup(ctx, curve, idx["max_degree"], beta_srs)
+    try:
+        R, ch = _rand_inputs(c, idx["hs"], seed=21)
+        timing = {}
+        proof = marlin_dev.create_proof(ctx, didx, ck, pcirc_w, R, ch, timing)
+        oproof = om.create_proof(oidx, pp, ocirc, R, ch)
+        for l in marlin.LABELS_1 + marlin.LABELS_2 + marlin.LABELS_3:
+            assert proof["commitments"][l] == oproof["commitments"][l], l
+        assert proof["query"] == oproof["query"] and proof["evaluations"] == oproof["evaluations"]
+        assert proof["opening_proofs"] == oproof["opening_proofs"]
+        ic = om.index_commitments(oidx, pp)
+        assert om.verify_proof(oidx, pp, ic, proof, public, ch)
+        assert timing["total_s"] > 0
+    finally:
+        ck.powers_of_g.free()
+        ck.powers_of_gamma_g.free()
