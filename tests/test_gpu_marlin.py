@@ -107,7 +107,7 @@ def test_device_resident_marlin_matches_oracle_and_verifies(ctx, curve, kind):
     c = get_curve(curve)
     rnd = random.Random(15)
     if kind == "mimc":
-        consts = [rnd.randrange(c.r) for _ in range(7)]
+        consts = [rnd.randrange(c.r) for _ in range(5)]
         pre = [(rnd.randrange(c.r), rnd.randrange(c.r)) for _ in range(3)]
         pcirc, pcirc_w = MimcChain(curve, consts, [(None, None)] * 3), MimcChain(curve, consts, pre)
         ocirc, public = og.MimcChain(OC[curve], consts, pre), []
