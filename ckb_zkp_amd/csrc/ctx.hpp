@@ -119,7 +119,7 @@ struct zkp_ctx {
   hipEvent_t ev2 = nullptr, ev3 = nullptr;   // internal per-kernel timing
   bool profiling = false;
   std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)
-  zkp::DevBuf ntt_io, poly_tmp, poly_consts;
+  zkp::DevBuf ntt_io, poly_tmp, poly_consts, spmv_list;
   // MSM scratch
   zkp::DevBuf msm_scalars, msm_misc;
   std::unordered_map<uint64_t, std::shared_ptr<zkp::BasesEntry>> bases;

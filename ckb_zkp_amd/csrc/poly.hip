@@ -181,20 +181,60 @@ void fr_vec_op(zkp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_
 }
 
 // out[i] = sum_k coeff[k] * x[col[k]], k in [row_ptr[i], row_ptr[i+1])   (z_a = A z, t = (eta_a A + ...)^T r_alpha, ...)
+// One lane per row; rows longer than SPMV_LONG (the column of the constant `one` in a transposed R1CS matrix holds a
+// constant fraction of all entries) are queued in long_list = [count, row ids...] and reduced by a whole block each.
+constexpr uint32_t SPMV_LONG = 128, SPMV_LIST_CAP = 1u << 16;
+template <class P>
+__device__ __forceinline__ Fp<P> spmv_term(const uint32_t* __restrict__ col, const uint32_t* __restrict__ coeff,
+                                           const uint32_t* __restrict__ x, uint32_t k, const Fp<P>& one) {
+  using F = Fp<P>;
+  F v = F::load(x + (size_t)col[k] * 8), cf = F::load(coeff + (size_t)k * 8);
+  return cf == one ? v : v * cf;
+}
 template <class P>
 __global__ __launch_bounds__(256) void spmv_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                    const uint32_t* __restrict__ coeff, const uint32_t* __restrict__ x,
-                                                   size_t nrows, uint32_t* __restrict__ out) {
+                                                   size_t nrows, uint32_t* __restrict__ out, uint32_t* __restrict__ long_list) {
   using F = Fp<P>;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrows) return;
+  const uint32_t b = row_ptr[i], e = row_ptr[i + 1];
+  if (e - b > SPMV_LONG) {
+    uint32_t slot = atomicAdd(long_list, 1u);
+    if (slot < SPMV_LIST_CAP) {
+      long_list[1 + slot] = (uint32_t)i;
+      return;
+    }
+  }
   F acc = F::zero();
   const F one = F::one();
-  for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; k++) {
-    F v = F::load(x + (size_t)col[k] * 8), cf = F::load(coeff + (size_t)k * 8);
-    acc = cf == one ? acc + v : acc + v * cf;
-  }
+  for (uint32_t k = b; k < e; k++) acc = acc + spmv_term<P>(col, coeff, x, k, one);
   acc.store(out + i * 8);
+}
+template <class P>
+__global__ __launch_bounds__(256) void spmv_long_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                        const uint32_t* __restrict__ coeff, const uint32_t* __restrict__ x,
+                                                        uint32_t* __restrict__ out, const uint32_t* __restrict__ long_list) {
+  using F = Fp<P>;
+  __shared__ uint32_t red[256 * 8];
+  const uint32_t count = min(long_list[0], SPMV_LIST_CAP), tid = threadIdx.x;
+  const F one = F::one();
+  for (uint32_t r = blockIdx.x; r < count; r += gridDim.x) {
+    const uint32_t i = long_list[1 + r], b = row_ptr[i], e = row_ptr[i + 1];
+    F acc = F::zero();
+    for (uint32_t k = b + tid; k < e; k += 256) acc = acc + spmv_term<P>(col, coeff, x, k, one);
+    acc.store(red + tid * 8);
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        acc = acc + F::load(red + (tid + s) * 8);
+        acc.store(red + tid * 8);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) acc.store(out + (size_t)i * 8);
+    __syncthreads();
+  }
 }
 // out[i] = idx[i] < 0 ? 0 : in[idx[i]]
 __global__ __launch_bounds__(256) void gather_kernel(const uint4* __restrict__ in, const int32_t* __restrict__ idx, size_t n,
@@ -226,11 +266,17 @@ __global__ __launch_bounds__(256) void vanishing_fold_kernel(const uint32_t* __r
 void fr_spmv(zkp_ctx* ctx, int curve, const uint32_t* row_ptr, const uint32_t* col, const uint64_t* coeff, size_t nrows,
              const uint64_t* x, uint64_t* out) {
   if (nrows == 0) return;
+  hipStream_t st = ctx->cur->stream;
+  uint32_t* list = ctx->spmv_list.as<uint32_t>(1 + SPMV_LIST_CAP);
+  ZKP_HIP(hipMemsetAsync(list, 0, sizeof(uint32_t), st));
   auto launch = [&](auto tag) {
     using P = decltype(tag);
-    hipLaunchKernelGGL(spmv_kernel<P>, dim3((nrows + 255) / 256), dim3(256), 0, ctx->cur->stream, row_ptr, col,
+    hipLaunchKernelGGL(spmv_kernel<P>, dim3((nrows + 255) / 256), dim3(256), 0, st, row_ptr, col,
                        reinterpret_cast<const uint32_t*>(coeff), reinterpret_cast<const uint32_t*>(x), nrows,
-                       reinterpret_cast<uint32_t*>(out));
+                       reinterpret_cast<uint32_t*>(out), list);
+    hipLaunchKernelGGL(spmv_long_kernel<P>, dim3(512), dim3(256), 0, st, row_ptr, col,
+                       reinterpret_cast<const uint32_t*>(coeff), reinterpret_cast<const uint32_t*>(x),
+                       reinterpret_cast<uint32_t*>(out), list);
   };
   if (curve == ZKP_BN254) launch(Bn254Fr{});
   else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});

@@ -208,13 +208,45 @@ def _csr_dev(be: DeviceBackend, rows, ncols_unused=None):
     return (be.upload_raw(rp), be.upload_raw(cl), be.upload_raw(cf))
 
 
-class DeviceIndex:
-    """Upload of a host index (marlin.index) — the prover key's polynomial data, resident in HBM."""
+def _np_reindex(hs: int, xs: int, j: np.ndarray) -> np.ndarray:
+    """vectorised reindex_by_subdomain (ahp/constraint_systems.rs `reindex_by_subdomain`)"""
+    period = hs // xs
+    j = j.astype(np.int64)
+    i = j - xs
+    return np.where(j < xs, j * period, i + i // max(period - 1, 1) + 1)
 
-    def __init__(self, ctx: Context, idx):
-        self.idx = idx
-        c = self.curve = idx["curve"]
-        be = self.be = DeviceBackend(ctx, c)
+
+def _csr_upload(be: DeviceBackend, ptr, col, cf_mont):
+    cf = cf_mont if len(cf_mont) else np.zeros((1, 4), dtype=np.uint64)
+    cl = col if len(col) else np.zeros(1, dtype=np.uint32)
+    return (be.upload_raw(np.asarray(ptr, dtype=np.uint32)), be.upload_raw(np.asarray(cl, dtype=np.uint32)),
+            be.upload_raw(np.ascontiguousarray(cf, dtype=np.uint64)))
+
+
+class DeviceIndex:
+    """Prover-side index resident in HBM.  Built either from a host index (`marlin.index`, small circuits / tests) or
+    directly from array-form matrices (`from_instance`), in which case the arithmetization itself — row/col/val over K,
+    their interpolations and the evaluations over B (arithmetic.rs:98-172) — is computed on the device."""
+
+    def __init__(self, ctx: Context, curve):
+        self.curve = get_curve(curve)
+        self.be = DeviceBackend(ctx, self.curve)
+
+    def _finish(self, xs, hs, ks, bs, nrows):
+        self.xs, self.hs, self.ks, self.bs, self.nrows = xs, hs, ks, bs, nrows
+        self.max_degree = max(3 * hs + 2 * ZK_BOUND - 1, 3 * ks - 3)
+        ratio = hs // xs
+        i = np.arange(hs, dtype=np.int64)
+        # w_evals_on_h[i] = 0 if i % ratio == 0 else w_ext[i - i/ratio - 1] - x_evals_on_h[i]   (prover.rs:176-186)
+        self.w_idx = self.be.upload_raw(np.where(i % ratio == 0, -1, i - i // ratio - 1).astype(np.int32))
+        self.x_idx = self.be.upload_raw(np.where(i % ratio == 0, -1, i).astype(np.int32))
+        self.be.ctx.sync()
+        self.be._live = []          # index data stays resident for the lifetime of the context
+
+    @classmethod
+    def from_host_index(cls, ctx: Context, idx):
+        self = cls(ctx, idx["curve"])
+        be = self.be
         hs, xs = idx["hs"], idx["xs"]
         self.csr = {m: _csr_dev(be, idx[m]) for m in "abc"}
         # transposed, re-indexed matrices: t_on_h[k] = sum_{(i, j): reindex(j) = k} coeff * r_alpha[i]  (prover.rs:259-269)
@@ -230,38 +262,120 @@ class DeviceIndex:
         self.on_k = {m: {k: be.upload(S[m]["on_k"][k]) for k in ("row", "col", "val")} for m in "abc"}
         self.on_b = {m: {k: be.upload(S[m]["on_b"][k]) for k in ("row", "col", "val", "row_col")} for m in "abc"}
         self.polys = {f"{m}_{k}": be.upload(S[m]["polys"][k]) for m in "abc" for k in ("row", "col", "val", "row_col")}
-        ratio = hs // xs
-        # w_evals_on_h[i] = 0 if i % ratio == 0 else w_ext[i - i/ratio - 1] - x_evals_on_h[i]   (prover.rs:176-186)
-        self.w_idx = be.upload_raw(np.asarray([-1 if i % ratio == 0 else i - i // ratio - 1 for i in range(hs)], dtype=np.int32))
-        self.x_idx = be.upload_raw(np.asarray([-1 if i % ratio == 0 else i for i in range(hs)], dtype=np.int32))
-        be._live = []          # index data stays resident: hand ownership to the index
+        self._finish(xs, hs, idx["ks"], idx["bs"], len(idx["a"]))
+        return self
 
-    def free(self):
-        pass                    # released with the context (test/bench lifetime)
+    @classmethod
+    def from_instance(cls, ctx: Context, inst):
+        """AHP::index (indexer.rs:70-117) on array-form matrices: make_matrices_square, balance_matrices, per-row
+        column sort, then compose_matrix_polynomials on the device.  inst: r1cs.R1csInstance (CSR, Montgomery coeffs)."""
+        self = cls(ctx, inst.curve)
+        be, c = self.be, self.curve
+        ni, nv, nc = inst.num_inputs, inst.num_inputs + inst.num_aux, inst.num_constraints()
+        self.pad_aux = max(nc - nv, 0)              # make_matrices_square: dummy variables (value one) ...
+        n = max(nv, nc)                             # ... or empty constraints
+        mats = []
+        for ptr, col, cf in (inst.csr("a"), inst.csr("b"), inst.csr("c")):
+            ptr = np.asarray(ptr, dtype=np.int64)
+            ptr = np.concatenate([ptr, np.full(n - nc, ptr[-1], dtype=np.int64)])
+            mats.append((ptr, np.asarray(col, dtype=np.int64), np.asarray(cf, dtype=np.uint64).reshape(-1, 4)))
+        # balance_matrices (constraint_systems.rs): greedy row swaps while A is the denser matrix
+        la, lb = np.diff(mats[0][0]).tolist(), np.diff(mats[1][0]).tolist()
+        da, db_ = sum(la), sum(lb)
+        swap = np.zeros(n, dtype=bool)
+        denser = da > db_
+        for i in range(n):
+            if not denser:
+                break
+            swap[i] = True
+            da += lb[i] - la[i]
+            db_ += la[i] - lb[i]
+            denser = da > db_
+
+        def select(mask, P, Q):
+            lp, lq = np.diff(P[0]), np.diff(Q[0])
+            ln = np.where(mask, lp, lq)
+            ptr = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+            start = np.where(mask, P[0][:-1], Q[0][:-1] + len(P[1]))
+            src = np.repeat(start, ln) + (np.arange(ptr[-1]) - np.repeat(ptr[:-1], ln))
+            return ptr, np.concatenate([P[1], Q[1]])[src], np.concatenate([P[2], Q[2]])[src]
+
+        if swap.any():
+            mats[0], mats[1] = select(swap, mats[1], mats[0]), select(swap, mats[0], mats[1])
+        sorted_mats = []
+        for ptr, col, cf in mats:
+            rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ptr))
+            order = np.lexsort((col, rows))         # stable: by row, then by column (`row.sort_by_key(col)`)
+            sorted_mats.append((ptr, col[order], cf[order], rows))
+        nnz = max(int(m[0][-1]) for m in sorted_mats)
+        xs, hs, ks = _next_pow2(ni), _next_pow2(n), _next_pow2(nnz)
+        bs = _next_pow2(3 * ks - 3)
+        # H as a device vector: the evaluations of X over the domain
+        xpoly = be.zeros(hs)
+        be.add_at(xpoly, 1, 1)
+        self.h_el = be.fft(xpoly, hs)
+        diag_inv = be.scale(self.h_el, pow(hs, -1, c.r))          # 1 / (|H| u^-1) = u / |H|
+        self.csr, self.csr_t, self.on_k, self.on_b, self.polys = {}, {}, {}, {}, {}
+        for m, (ptr, col, cf, rows) in zip("abc", sorted_mats):
+            self.csr[m] = _csr_upload(be, ptr, col, cf)
+            jj = _np_reindex(hs, xs, col)
+            order = np.argsort(jj, kind="stable")
+            tptr = np.concatenate([[0], np.cumsum(np.bincount(jj, minlength=hs))])
+            self.csr_t[m] = _csr_upload(be, tptr, rows[order], cf[order])
+            k = len(col)
+            pad0 = lambda a, fill: np.concatenate([a, np.full(ks - k, fill, dtype=np.int64)]).astype(np.int32)
+            row = be.gather(self.h_el, be.upload_raw(pad0(jj, 0)), ks)
+            colv = be.gather(self.h_el, be.upload_raw(pad0(rows, 0)), ks)
+            vcf = be.upload_mont(np.concatenate([cf, np.zeros((ks - k, 4), dtype=np.uint64)]))
+            val = be.mul(vcf, be.gather(diag_inv, be.upload_raw(pad0(jj, -1)), ks))
+            rc = be.mul(row, colv)
+            self.on_k[m] = dict(row=row, col=colv, val=val)
+            self.on_b[m] = {}
+            for name, ev in (("row", row), ("col", colv), ("val", val), ("row_col", rc)):
+                p = be.ifft(ev, ks)
+                self.polys[f"{m}_{name}"] = p
+                self.on_b[m][name] = be.fft(p, bs)
+        self.num_non_zeros = nnz
+        self._finish(xs, hs, ks, bs, n)
+        return self
+
+    def commit_index(self, ctx: Context, ck: kzg10.CommitterKey):
+        """index commitments (the verifier key's half of AHP::index, lib.rs:69-86) -> {label: (affine, None)}"""
+        out = {}
+        for l, p in self.polys.items():
+            xy, inf = ctx.into_affine(self.curve, 1, ck.powers_of_g.msm_mont_dev(p.ptr, p.n))
+            out[l] = (codec.g1_from_mont(xy, [inf], self.curve)[0], None)
+        return out
 
 
 def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circuit, rnd, ch, timing: dict | None = None):
     """Device-resident `create_random_proof` with explicit randomness / challenges (same dictionaries as
     marlin.create_proof).  Returns commitments, evaluations (query order) and opening proofs as canonical integers."""
     import time
-    idx = didx.idx
-    c = idx["curve"]
+    c = didx.curve
     r = c.r
     be = DeviceBackend(ctx, c)
-    xs, hs, ks, bs = idx["xs"], idx["hs"], idx["ks"], idx["bs"]
-    D = idx["max_degree"]
+    xs, hs, ks, bs = didx.xs, didx.hs, didx.ks, didx.bs
+    D = didx.max_degree
     t_start = time.perf_counter()
     try:
         # ---- prover_init: synthesis on the host, everything else on the device
-        cs = MarlinCS(c, assign=True)
-        circuit.generate_constraints(cs)
-        cs.make_matrices_square()
-        x, w = cs.input_assignment, cs.aux_assignment
-        z = be.upload(x + w)
+        if hasattr(circuit, "generate_constraints"):
+            cs = MarlinCS(c, assign=True)
+            circuit.generate_constraints(cs)
+            cs.make_matrices_square()
+            x, w = cs.input_assignment, cs.aux_assignment
+            z = be.upload(x + w)
+        else:                                   # (formatted inputs, witness) as canonical integers or Montgomery rows
+            x, w = circuit
+            x = list(x)
+            wm = w if isinstance(w, np.ndarray) else codec.fr_to_mont(list(w), c).reshape(-1, 4)
+            pad = codec.fr_to_mont([1] * getattr(didx, "pad_aux", 0), c).reshape(-1, 4)
+            z = be.upload_mont(np.concatenate([codec.fr_to_mont(x, c).reshape(-1, 4), wm, pad]))
         ctx.sync()
         t0 = time.perf_counter()
-        z_a_ev = be.spmv(didx.csr["a"], z, len(idx["a"]))
-        z_b_ev = be.spmv(didx.csr["b"], z, len(idx["b"]))
+        z_a_ev = be.spmv(didx.csr["a"], z, didx.nrows)
+        z_b_ev = be.spmv(didx.csr["b"], z, didx.nrows)
         # ---- first round (prover.rs:150-222)
         x_poly = be.ifft(be.upload(x), xs)
         x_on_h = be.fft(x_poly, hs)

@@ -116,7 +116,7 @@ def test_device_resident_marlin_matches_oracle_and_verifies(ctx, curve, kind):
         ocirc, public = og.MiniCircuit(2, 3, 10, 10), [10]
     oidx = om.index(OC[curve], ocirc)
     idx = marlin.index(ctx, curve, pcirc)
-    didx = marlin_dev.DeviceIndex(ctx, idx)
+    didx = marlin_dev.DeviceIndex.from_host_index(ctx, idx)
     beta_srs = 0xFEDCBA987654321
     pp = okzg.setup(OC[curve], idx["max_degree"], beta_srs)
     ck = kzg10.setup(ctx, curve, idx["max_degree"], beta_srs)
@@ -132,6 +132,62 @@ def test_device_resident_marlin_matches_oracle_and_verifies(ctx, curve, kind):
         ic = om.index_commitments(oidx, pp)
         assert om.verify_proof(oidx, pp, ic, proof, public, ch)
         assert timing["total_s"] > 0
+    finally:
+        ck.powers_of_g.free()
+        ck.powers_of_gamma_g.free()
+
+
+class _SwapAB:
+    """the same circuit with the roles of A and B exchanged (A becomes the denser matrix: balance_matrices swaps rows)"""
+
+    def __init__(self, inner):
+        self.inner = inner
+
+    def generate_constraints(self, cs):
+        class Proxy:
+            def __getattr__(self, name):
+                return getattr(cs, name)
+
+            def enforce(self, a, b, c):
+                return cs.enforce(b, a, c)
+        self.inner.generate_constraints(Proxy())
+
+
+@pytest.mark.parametrize("curve,samples,swap", [("bn254", 3, False), ("bls12_381", 2, False), ("bn254", 40, False),
+                                                ("bn254", 7, True)])
+def test_device_index_from_arrays_matches_host_index(ctx, curve, samples, swap):
+    """DeviceIndex.from_instance (arithmetization computed on the device from CSR arrays) == marlin.index on the same
+    circuit synthesised constraint by constraint; the array-form prover input gives the same proof."""
+    from ckb_zkp_amd import marlin_dev
+    from ckb_zkp_amd.circuits import mimc_chain_instance
+    c = get_curve(curve)
+    inst = mimc_chain_instance(curve, samples, seed=77)
+    circ = MimcChain(curve, inst.constants, inst.preimages)
+    icirc = MimcChain(curve, inst.constants, [(None, None)] * samples)
+    if swap:
+        from ckb_zkp_amd.r1cs import R1csInstance
+        inst = R1csInstance(curve, inst.num_inputs, inst.num_aux, inst.num_constraints(), inst.csr("b"), inst.csr("a"),
+                            inst.csr("c"), inst.z)
+        circ, icirc = _SwapAB(circ), _SwapAB(icirc)
+    idx = marlin.index(ctx, curve, icirc)
+    d_host = marlin_dev.DeviceIndex.from_host_index(ctx, idx)
+    d_arr = marlin_dev.DeviceIndex.from_instance(ctx, inst)
+    assert (d_arr.xs, d_arr.hs, d_arr.ks, d_arr.bs, d_arr.max_degree, d_arr.nrows) == \
+        (idx["xs"], idx["hs"], idx["ks"], idx["bs"], idx["max_degree"], len(idx["a"]))
+    be = d_arr.be
+    for l in marlin.INDEX_LABELS:
+        m, k = l.split("_", 1)
+        assert be.download(d_arr.polys[l]) == idx["star"][m]["polys"][k], l
+        assert be.download(d_arr.on_b[m][k]) == idx["star"][m]["on_b"][k], l
+    ck = kzg10.setup(ctx, curve, idx["max_degree"], 0xABCDEF12345)
+    try:
+        R, ch = _rand_inputs(c, idx["hs"], seed=33)
+        p_host = marlin_dev.create_proof(ctx, d_host, ck, circ, R, ch)
+        p_arr = marlin_dev.create_proof(ctx, d_arr, ck, (inst.z[:1], inst.z[1:]), R, ch)
+        assert p_host == p_arr
+        p_ref = marlin.create_proof(ctx, idx, ck, circ, R, ch)
+        assert p_ref["commitments"] == p_arr["commitments"] and p_ref["evaluations"] == p_arr["evaluations"]
+        assert p_ref["opening_proofs"] == p_arr["opening_proofs"]
     finally:
         ck.powers_of_g.free()
         ck.powers_of_gamma_g.free()
