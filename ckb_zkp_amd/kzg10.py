@@ -31,16 +31,32 @@ class CommitterKey:
     host_gamma_g: tuple = None
 
 
+def _device_powers(ctx: Context, c, n: int, beta: int, k: int) -> np.ndarray:
+    """canonical limbs of k * beta^i, i < n, generated in HBM by log2(n) doubling steps (v[len..2len) = beta^len * v[0..len))"""
+    buf = ctx.dev_alloc(n * 32)
+    try:
+        ctx.h2d(buf, codec.fr_to_mont([1], c).reshape(1, 4))
+        ln = 1
+        while ln < n:
+            m = min(ln, n - ln)
+            ctx.fr_vec_op(c, 3, buf, None, buf + ln * 32, m, codec.fr_to_mont([pow(beta, ln, c.r)], c)[0])
+            ln += m
+        # scaling by k / R leaves the canonical (non-Montgomery) representation of k * beta^i in memory
+        r_inv = pow(1 << (64 * c.fr_limbs), -1, c.r)
+        ctx.fr_vec_op(c, 3, buf, None, buf, n, codec.fr_to_mont([k * r_inv % c.r], c)[0])
+        out = np.zeros((n, c.fr_limbs), dtype=np.uint64)
+        ctx.d2h(out, buf)
+    finally:
+        ctx.dev_free(buf)
+    return out
+
+
 def setup(ctx: Context, curve, max_degree: int, beta: int, g_k: int = 1, gamma_k: int = 7) -> CommitterKey:
     """KZG10::setup + trim with explicit toxic waste: powers_of_g[i] = beta^i * (g_k G), powers_of_gamma_g likewise."""
     c = get_curve(curve)
-    pw, p = [], 1
-    for _ in range(max_degree + 1):
-        pw.append(p)
-        p = p * beta % c.r
     base, _ = codec.g1_to_mont([c.g1], c)
-    g = ctx.fixed_base_mul(c, 1, base, codec.fr_canonical([x * g_k % c.r for x in pw], c))
-    gg = ctx.fixed_base_mul(c, 1, base, codec.fr_canonical([x * gamma_k % c.r for x in pw], c))
+    g = ctx.fixed_base_mul(c, 1, base, _device_powers(ctx, c, max_degree + 1, beta, g_k))
+    gg = ctx.fixed_base_mul(c, 1, base, _device_powers(ctx, c, max_degree + 1, beta, gamma_k))
     return CommitterKey(c, ctx.upload_bases(c, 1, *g), ctx.upload_bases(c, 1, *gg), max_degree, g, gg)
 
 
