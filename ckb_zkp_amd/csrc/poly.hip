@@ -246,20 +246,53 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint4* __restrict__ i
   out[2 * i] = j < 0 ? z : in[2 * (size_t)j];
   out[2 * i + 1] = j < 0 ? z : in[2 * (size_t)j + 1];
 }
-// p = q (X^n - 1) + rem:  q[i] = sum_{k>=1} p[i + k n] (i < len - n),  rem[i] = p[i] + q[i] (i < n)
+// p = q (X^n - 1) + rem.  With s[i] = sum_{k>=0} p[i + k n] (strided suffix sums): q[i] = s[i + n], rem[i] = s[i].
+// View p as R = ceil(len/n) rows of n residues; rows are cut into chunks of C rows.  Pass 1 sums each (chunk, residue),
+// pass 2 turns the chunk sums into exclusive suffix carries per residue, pass 3 replays each chunk top-down from its
+// carry and writes q / rem.  When a residue has few rows (the folds by |H|, |K|: R <= 4) only pass 3 runs.
 template <class P>
-__global__ __launch_bounds__(256) void vanishing_fold_kernel(const uint32_t* __restrict__ p, size_t len, size_t n,
-                                                             uint32_t* __restrict__ q, uint32_t* __restrict__ rem) {
+__global__ __launch_bounds__(256) void vfold_sum_kernel(const uint32_t* __restrict__ p, size_t len, size_t n, size_t C,
+                                                        size_t T, uint32_t* __restrict__ part) {
   using F = Fp<P>;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t qlen = len > n ? len - n : 0;
-  if (i >= (qlen > n ? qlen : n)) return;
+  size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= T * n) return;
+  const size_t t = id / n, j = id % n;
   F acc = F::zero();
-  for (size_t j = i + n; j < len; j += n) acc = acc + F::load(p + j * 8);
-  if (i < qlen && q) acc.store(q + i * 8);
-  if (i < n && rem) {
-    F lo = i < len ? F::load(p + i * 8) : F::zero();
-    (lo + (i < qlen ? acc : F::zero())).store(rem + i * 8);
+  for (size_t k = t * C; k < (t + 1) * C; k++) {
+    size_t e = k * n + j;
+    if (e < len) acc = acc + F::load(p + e * 8);
+  }
+  acc.store(part + id * 8);
+}
+template <class P>
+__global__ __launch_bounds__(256) void vfold_carry_kernel(uint32_t* __restrict__ part, size_t n, size_t T) {
+  using F = Fp<P>;
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  F acc = F::zero();
+  for (size_t t = T; t-- > 0;) {
+    F v = F::load(part + (t * n + j) * 8);
+    acc.store(part + (t * n + j) * 8);
+    acc = acc + v;
+  }
+}
+template <class P>
+__global__ __launch_bounds__(256) void vfold_replay_kernel(const uint32_t* __restrict__ p, size_t len, size_t n, size_t C,
+                                                           size_t T, const uint32_t* __restrict__ carry,
+                                                           uint32_t* __restrict__ q, uint32_t* __restrict__ rem) {
+  using F = Fp<P>;
+  size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= T * n) return;
+  const size_t t = id / n, j = id % n;
+  F acc = carry ? F::load(carry + id * 8) : F::zero();
+  for (size_t k = (t + 1) * C; k-- > t * C;) {
+    size_t e = k * n + j;
+    if (e < len) acc = acc + F::load(p + e * 8);
+    if (k == 0) {
+      if (rem) acc.store(rem + j * 8);
+    } else if (q && e < len) {
+      acc.store(q + (e - n) * 8);
+    }
   }
 }
 
@@ -291,12 +324,25 @@ void fr_gather(zkp_ctx* ctx, const uint64_t* in, const int32_t* idx, size_t n, u
 }
 void poly_vanishing_fold(zkp_ctx* ctx, int curve, const uint64_t* p, size_t len, size_t n, uint64_t* q, uint64_t* rem) {
   ZKP_REQUIRE(n > 0, ZKP_ERR_BAD_ARG);
-  size_t qlen = len > n ? len - n : 0, work = std::max(qlen, n);
+  hipStream_t st = ctx->cur->stream;
+  const size_t R = std::max<size_t>((len + n - 1) / n, 1);
+  size_t C = R;
+  if (R > 8) {
+    C = 8;
+    while (C * C < R) C++;
+  }
+  const size_t T = (R + C - 1) / C, work = T * n;
   auto launch = [&](auto tag) {
     using P = decltype(tag);
-    hipLaunchKernelGGL(vanishing_fold_kernel<P>, dim3((work + 255) / 256), dim3(256), 0, ctx->cur->stream,
-                       reinterpret_cast<const uint32_t*>(p), len, n, reinterpret_cast<uint32_t*>(q),
-                       reinterpret_cast<uint32_t*>(rem));
+    const uint32_t* pp = reinterpret_cast<const uint32_t*>(p);
+    uint32_t* carry = nullptr;
+    if (T > 1) {
+      carry = ctx->poly_tmp.as<uint32_t>(work * 8);
+      hipLaunchKernelGGL(vfold_sum_kernel<P>, dim3((work + 255) / 256), dim3(256), 0, st, pp, len, n, C, T, carry);
+      hipLaunchKernelGGL(vfold_carry_kernel<P>, dim3((n + 255) / 256), dim3(256), 0, st, carry, n, T);
+    }
+    hipLaunchKernelGGL(vfold_replay_kernel<P>, dim3((work + 255) / 256), dim3(256), 0, st, pp, len, n, C, T,
+                       (const uint32_t*)carry, reinterpret_cast<uint32_t*>(q), reinterpret_cast<uint32_t*>(rem));
   };
   if (curve == ZKP_BN254) launch(Bn254Fr{});
   else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});

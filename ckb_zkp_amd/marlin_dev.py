@@ -390,7 +390,7 @@ def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circui
 
         w_poly, _ = be.fold(masked(w_on_h, rnd["w"][0]), xs)
         z_a, z_b = masked(z_a_ev, rnd["z_a"][0]), masked(z_b_ev, rnd["z_b"][0])
-        mask = be.upload(rnd["mask"])
+        mask = be.upload_mont(rnd["mask"]) if isinstance(rnd["mask"], np.ndarray) else be.upload(rnd["mask"])
         _, mrem = be.fold(mask, hs)
         be.add_at(mask, 0, -be.element(mrem, 0))
         polys = dict(didx.polys)

