@@ -79,57 +79,89 @@ __global__ __launch_bounds__(256) void horner_chunk_kernel(const uint32_t* __res
   acc.store(head + c * 8);
 }
 
-// phase 2 (one block): suffix scan over chunk heads: S[c] = head[c] + zc * S[c+1], zc = z^CHUNK.  Hillis-Steele on
-// (value, multiplier) pairs in LDS, processed in tiles of 256 from the top with a running carry.
+// phase 2: suffix scan over chunk heads, S[c] = head[c] + zc * S[c+1] with zc = z^CHUNK, in three steps:
+//   (a) every block scans one tile of 256 heads locally (Hillis-Steele on affine maps x -> val + mul * x in LDS) and
+//       emits the tile's own suffix sum;  (b) one block scans the tile sums with multiplier zc^256;
+//   (c) every chunk adds zc^(distance to its tile top) * S(first chunk of the tile above).
+// scan_tile: 256 (value, multiplier) maps, element e = 0 is the HIGHEST index; returns the composed map for element e.
+template <class F>
+__device__ __forceinline__ void scan_tile(uint32_t* sv, uint32_t* sm, int t) {
+  for (int d = 1; d < 256; d <<= 1) {
+    F v2, m2;
+    const bool act = t >= d;
+    if (act) {
+      F vlo = F::load(sv + (t - d) * 8), mlo = F::load(sm + (t - d) * 8);
+      F vhi = F::load(sv + t * 8), mhi = F::load(sm + t * 8);
+      v2 = vhi + mhi * vlo;                               // apply the lower-index (higher chunk) map first
+      m2 = mhi * mlo;
+    }
+    __syncthreads();
+    if (act) {
+      v2.store(sv + t * 8);
+      m2.store(sm + t * 8);
+    }
+    __syncthreads();
+  }
+}
 template <class P>
-__global__ __launch_bounds__(256) void horner_scan_kernel(uint32_t* __restrict__ head, size_t chunks,
-                                                          const uint32_t* __restrict__ z, uint32_t* __restrict__ total) {
+__global__ __launch_bounds__(256) void horner_tile_kernel(uint32_t* __restrict__ head, size_t chunks,
+                                                          const uint32_t* __restrict__ z, uint32_t* __restrict__ tile_sum) {
   using F = Fp<P>;
   __shared__ uint32_t sv[256 * 8], sm[256 * 8];
   const int t = threadIdx.x;
   F zc = F::load(z);
   for (int i = 0; i < 5; i++) zc = zc.sqr();          // z^32 == z^POLY_CHUNK
   static_assert(POLY_CHUNK == 32, "zc exponent");
-  F carry = F::zero();                                  // S of the chunk just above the current tile
-  const size_t tiles = (chunks + 255) / 256;
+  const size_t c = (size_t)blockIdx.x * 256 + t;
+  (c < chunks ? F::load(head + c * 8) : F::zero()).store(sv + (255 - t) * 8);
+  (c < chunks ? zc : F::one()).store(sm + (255 - t) * 8);
+  __syncthreads();
+  scan_tile<F>(sv, sm, t);
+  if (c < chunks) F::load(sv + (255 - t) * 8).store(head + c * 8);     // local S (as if nothing lay above the tile)
+  if (t == 0) F::load(sv + 255 * 8).store(tile_sum + (size_t)blockIdx.x * 8);
+}
+// one block: suffix scan of `count` values with a constant multiplier z^(32 * 256) per step, tiles of 256 from the top
+template <class P>
+__global__ __launch_bounds__(256) void horner_scan_kernel(uint32_t* __restrict__ head, size_t count,
+                                                          const uint32_t* __restrict__ z, uint32_t* __restrict__ total) {
+  using F = Fp<P>;
+  __shared__ uint32_t sv[256 * 8], sm[256 * 8];
+  const int t = threadIdx.x;
+  F zc = F::load(z);
+  for (int i = 0; i < 13; i++) zc = zc.sqr();         // z^(POLY_CHUNK * 256)
+  F carry = F::zero();                                  // S of the element just above the current tile
+  const size_t tiles = (count + 255) / 256;
   for (size_t tile = tiles; tile-- > 0;) {
     size_t c = tile * 256 + t;
-    // reversed index inside the tile so that the scan runs from high chunk to low chunk
-    F val = c < chunks ? F::load(head + c * 8) : F::zero();
-    F mul = c < chunks ? zc : F::one();
-    // element e = 255 - t  (e = 0 is the highest chunk of the tile)
-    val.store(sv + (255 - t) * 8);
-    mul.store(sm + (255 - t) * 8);
+    (c < count ? F::load(head + c * 8) : F::zero()).store(sv + (255 - t) * 8);
+    (c < count ? zc : F::one()).store(sm + (255 - t) * 8);
     __syncthreads();
-    // inclusive scan of affine maps x -> val + mul * x, composed from e = 0 upwards
-    for (int d = 1; d < 256; d <<= 1) {
-      F v2, m2;
-      const int e = t;
-      bool act = e >= d;
-      if (act) {
-        F vlo = F::load(sv + (e - d) * 8), mlo = F::load(sm + (e - d) * 8);
-        F vhi = F::load(sv + e * 8), mhi = F::load(sm + e * 8);
-        v2 = vhi + mhi * vlo;                             // apply lower-index (higher chunk) map first
-        m2 = mhi * mlo;
-      }
-      __syncthreads();
-      if (act) {
-        v2.store(sv + e * 8);
-        m2.store(sm + e * 8);
-      }
-      __syncthreads();
-    }
-    // S for chunk c: element e = 255 - t
+    scan_tile<F>(sv, sm, t);
     F v = F::load(sv + (255 - t) * 8), m = F::load(sm + (255 - t) * 8);
     F s = v + m * carry;
-    if (c < chunks) s.store(head + c * 8);
+    if (c < count) s.store(head + c * 8);
     __syncthreads();
-    // carry for the next (lower) tile = S of this tile's lowest chunk (t = 0 -> e = 255)
     F v0 = F::load(sv + 255 * 8), m0 = F::load(sm + 255 * 8);
     carry = v0 + m0 * carry;
     __syncthreads();
   }
   if (t == 0 && total) carry.store(total);               // S[0] = p(z)
+}
+template <class P>
+__global__ __launch_bounds__(256) void horner_fix_kernel(uint32_t* __restrict__ head, size_t chunks,
+                                                         const uint32_t* __restrict__ z, const uint32_t* __restrict__ tile_sum,
+                                                         size_t tiles) {
+  using F = Fp<P>;
+  const size_t tile = blockIdx.x, c = tile * 256 + threadIdx.x;
+  if (tile + 1 >= tiles || c >= chunks) return;
+  F zc = F::load(z);
+  for (int i = 0; i < 5; i++) zc = zc.sqr();
+  F m = F::one();                                        // zc^(256 - t)
+  for (uint32_t e = 256 - threadIdx.x, bit = 256; bit; bit >>= 1) {
+    m = m.sqr();
+    if (e & bit) m = m * zc;
+  }
+  (F::load(head + c * 8) + m * F::load(tile_sum + (tile + 1) * 8)).store(head + c * 8);
 }
 
 // phase 3: q_{i-1} = S_i for i = 1..n-1 (quotient of p by (X - z)); S_i = local Horner from the chunk top + z^k S_top
@@ -155,9 +187,13 @@ static void poly_div_linear_t(zkp_ctx* ctx, const uint32_t* p, size_t n, const u
                               uint32_t* eval_dev) {
   hipStream_t st = ctx->cur->stream;
   size_t chunks = (n + POLY_CHUNK - 1) / POLY_CHUNK;
-  uint32_t* head = ctx->poly_tmp.as<uint32_t>((chunks + 1) * 8);
+  const size_t tiles = (chunks + 255) / 256;
+  uint32_t* head = ctx->poly_tmp.as<uint32_t>((chunks + tiles + 2) * 8);
+  uint32_t* tile_sum = head + (chunks + 1) * 8;
   hipLaunchKernelGGL(horner_chunk_kernel<P>, dim3((chunks + 255) / 256), dim3(256), 0, st, p, n, z_dev, head, chunks);
-  hipLaunchKernelGGL(horner_scan_kernel<P>, dim3(1), dim3(256), 0, st, head, chunks, z_dev, eval_dev);
+  hipLaunchKernelGGL(horner_tile_kernel<P>, dim3(tiles), dim3(256), 0, st, head, chunks, z_dev, tile_sum);
+  hipLaunchKernelGGL(horner_scan_kernel<P>, dim3(1), dim3(256), 0, st, tile_sum, tiles, z_dev, eval_dev);
+  if (q && tiles > 1) hipLaunchKernelGGL(horner_fix_kernel<P>, dim3(tiles), dim3(256), 0, st, head, chunks, z_dev, (const uint32_t*)tile_sum, tiles);
   if (q) hipLaunchKernelGGL(horner_replay_kernel<P>, dim3((chunks + 255) / 256), dim3(256), 0, st, p, n, z_dev, head, chunks, q);
   ZKP_HIP(hipGetLastError());
 }
