@@ -23,13 +23,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--curve", default="bn254")
+    ap.add_argument("--samples", type=int, default=0, help="MiMC samples S (default floor((2^k - 1)/10)); 87381 gives |H| = 2^20")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--no-verify", action="store_true")
     a = ap.parse_args()
     c = get_curve(a.curve)
     log = lambda *m: print("[marlin]", *m, file=sys.stderr, flush=True)
     t = time.perf_counter()
-    inst = mimc_chain_instance(a.curve, samples_for_domain(a.log_n), seed=0x4D41524C)
+    inst = mimc_chain_instance(a.curve, a.samples or samples_for_domain(a.log_n), seed=0x4D41524C)
     log(f"instance: constraints={inst.num_constraints()} variables={inst.num_inputs + inst.num_aux} ({time.perf_counter() - t:.1f}s)")
     ctx = Context(0)
     t = time.perf_counter()
