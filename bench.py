@@ -152,6 +152,26 @@ def main():
                     "note": "integer-VALU bound (DESIGN.md); traffic = FETCH_SIZE*2 + WRITE_SIZE per launch (rocprofv3 PMC, profiles/): "
                             "the window-table design gathers each base W=13 times at 128-B fabric granularity"}
 
+    # ---- second half of BASELINE.json's metric: one G1 MSM (uniform scalars, the H-query shape) in Mop/s
+    msm_g1 = None
+    if rank == 0 and world == 1:
+        hb = ctx.upload_bases(c, 1, *params.h_query)
+        n_msm = hb.n
+        sc = np.frombuffer(np.random.default_rng(7).bytes(32 * n_msm), dtype=np.uint64).reshape(-1, 4).copy()
+        sc[:, 3] &= (1 << (c.r.bit_length() - 64 * 3 - 1)) - 1           # < r without bias games: top bits cleared
+        sc_dev = ctx.to_device(sc)
+        for _ in range(2):
+            hb.msm_dev(sc_dev, n_msm)
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            hb.msm_dev(sc_dev, n_msm)
+        t_msm = (time.perf_counter() - t0) / reps
+        msm_g1 = {"n": n_msm, "ms": round(t_msm * 1e3, 3), "mops": round(n_msm / t_msm / 1e6, 1),
+                  "note": "zkp_msm_g1_dev, canonical scalars resident in HBM, result (Jacobian) back on the host each call"}
+        ctx.dev_free(sc_dev)
+        hb.free()
+
     # ---- CPU baseline (rank 0, N=1 only): oracle/cpu port of the reference algorithm on a bounded sample
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -192,7 +212,7 @@ def main():
                                    f"(domain 2^{args.log_n}), {inst.num_aux} aux, {c.name}, G1 x4 + G2 x1 MSM + 7 NTT",
                        "curve": c.name, "log_domain": args.log_n, "parallelism": f"independent proofs x{world}",
                        "pipelining": "none" if args.no_pipeline else "2 proofs in flight per GPU (zkp_groth16_prove_batch_dev)"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "phases_ms": phases,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "msm_g1": msm_g1, "phases_ms": phases,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
