@@ -34,6 +34,7 @@ template <class P>
 struct Fp;
 template <class P>
 ZKP_MUL_ATTR Fp<P> fp_mul(Fp<P> a, Fp<P> b);
+#include "addsub_gen.inc"
 
 template <class P>
 struct Fp {
@@ -72,52 +73,32 @@ struct Fp {
   }
   ZKP_DEV bool operator!=(const Fp& b) const { return !(*this == b); }
 
+  // modular add / sub / final reduction: 3 VALU instructions per limb as carry chains (tools/gen_addsub.py)
+  ZKP_DEV static void mod_limbs(uint32_t* m) {
+#pragma unroll
+    for (int i = 0; i < N; i++) m[i] = P::MOD[i];
+  }
   // r = a - p if a >= p else a   (input < 2p)
   ZKP_DEV static Fp reduce_once(const Fp& a) {
-    Fp s;
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t d = (uint64_t)a.v[i] - P::MOD[i] - borrow;
-      s.v[i] = (uint32_t)d;
-      borrow = (uint32_t)(d >> 63);
-    }
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < N; i++) r.v[i] = borrow ? a.v[i] : s.v[i];
+    Fp r = a;
+    uint32_t m[N];
+    mod_limbs(m);
+    ReduceAsm<N>::run(r.v, m);
     return r;
   }
-
+  // spare top bit => no carry out of the top word for a, b < p
   ZKP_DEV friend Fp operator+(const Fp& a, const Fp& b) {
-    Fp t;
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t s = (uint64_t)a.v[i] + b.v[i] + c;
-      t.v[i] = (uint32_t)s;
-      c = (uint32_t)(s >> 32);
-    }
-    // spare top bit => no carry out of the top word for a,b < p
-    return reduce_once(t);
+    Fp r;
+    uint32_t m[N];
+    mod_limbs(m);
+    AddModAsm<N>::run(r.v, a.v, b.v, m);
+    return r;
   }
   ZKP_DEV friend Fp operator-(const Fp& a, const Fp& b) {
-    Fp t;
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t d = (uint64_t)a.v[i] - b.v[i] - borrow;
-      t.v[i] = (uint32_t)d;
-      borrow = (uint32_t)(d >> 63);
-    }
-    uint32_t mask = 0u - borrow;  // add p back if we went negative
-    uint32_t c = 0;
     Fp r;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t s = (uint64_t)t.v[i] + (P::MOD[i] & mask) + c;
-      r.v[i] = (uint32_t)s;
-      c = (uint32_t)(s >> 32);
-    }
+    uint32_t m[N];
+    mod_limbs(m);
+    SubModAsm<N>::run(r.v, a.v, b.v, m);
     return r;
   }
   ZKP_DEV Fp neg() const { return is_zero() ? *this : (zero() - *this); }
