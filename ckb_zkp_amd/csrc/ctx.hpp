@@ -74,6 +74,13 @@ struct NttTables {
   uint32_t* sub_inv = nullptr;
   uint32_t* n_inv = nullptr;      // 1/N (one element)
   void* block = nullptr;
+  // full-size tables (N elements each, built lazily for log_n <= 24): the inter-pass twiddle of pass p indexed by
+  // output position, and the coset factors g^j, g^-k/N — one load + one product per element instead of two + two
+  uint32_t* full_fwd[8] = {};
+  uint32_t* full_inv[8] = {};
+  uint32_t* full_g = nullptr;
+  uint32_t* full_gi = nullptr;
+  std::vector<void*> extra;
 };
 
 struct BasesEntry;   // msm.hip

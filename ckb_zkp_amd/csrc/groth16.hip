@@ -226,9 +226,17 @@ static uint32_t* witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint32_
   for (int k = 0; k < 3; k++)
     hipLaunchKernelGGL(csr_eval_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, st, pk->m[k].row_ptr, pk->m[k].col,
                        pk->m[k].coeff, z_dev, pk->num_constraints, N, pk->num_inputs, k == 0 ? 1 : 0, bufs[k]);
-  for (int k = 0; k < 3; k++) {
-    ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_IFFT);
-    ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_COSET_FFT);
+  // One launch for a, b, c (grid.y = 3) shortens the witness map in isolation (1.49 -> 1.35 ms at 2^20) but its 3x larger
+  // launches delay the MSM streams of the other lane: 79 vs 85 proofs/s pipelined.  Off unless ZKP_NTT_BATCH=1.
+  static const bool batch = getenv("ZKP_NTT_BATCH") && atoi(getenv("ZKP_NTT_BATCH")) != 0;
+  if (batch) {
+    ntt_run_batch(ctx, pk->curve, bufs, 3, pk->log_n, ZKP_NTT_IFFT);
+    ntt_run_batch(ctx, pk->curve, bufs, 3, pk->log_n, ZKP_NTT_COSET_FFT);
+  } else {
+    for (int k = 0; k < 3; k++) {
+      ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_IFFT);
+      ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_COSET_FFT);
+    }
   }
   hipLaunchKernelGGL(qap_pointwise_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, st, a, b, c,
                      pk->consts.as<uint32_t>(64), N);

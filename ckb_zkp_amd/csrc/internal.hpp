@@ -6,6 +6,8 @@ namespace zkp {
 
 // ntt.hip
 void ntt_run(zkp_ctx* ctx, int curve, uint32_t* data_dev, int log_n, int op);
+// count <= 4 independent transforms of the same size and kind in the same launches (grid.y)
+void ntt_run_batch(zkp_ctx* ctx, int curve, uint32_t* const* data_dev, int count, int log_n, int op);
 void ntt_free_tables(zkp_ctx* ctx);
 
 // poly.hip (all pointers device memory unless *_host)

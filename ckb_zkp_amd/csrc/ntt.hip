@@ -22,6 +22,7 @@
 //
 // Arithmetic is 256-bit Montgomery on the integer VALU (v_mad_u64_u32); there is no MFMA in this path.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ctx.hpp"
 #include "field.cuh"
@@ -32,6 +33,8 @@ constexpr int NTT_SMAX = 7;            // max radix bits per pass
 constexpr int NTT_TILE_LOG = 10;       // elements per LDS tile (1024 * 32 B = 32 KiB)
 constexpr int NTT_THREADS = 256;
 constexpr int NTT_SUB_LOG = 7;         // sub-FFT twiddle table covers R <= 2^7
+constexpr int NTT_FULL_MAX_LOG = 24;   // full-size twiddle / coset tables up to this domain size (32 B * N each)
+constexpr int NTT_MAX_BATCH = 4;       // independent transforms per launch (blockIdx.y)
 
 // ------------------------------------------------------------------------------------------- tables
 template <class P>
@@ -155,12 +158,35 @@ struct NttPassArgs {
   const uint32_t* post_lo;  // optional: multiply output k likewise
   const uint32_t* post_hi;
   const uint32_t* post_const;  // optional: multiply every output by a constant (1/N)
+  const uint32_t* tw_full;     // optional full tables (indexed by output / input / output position): replace the
+  const uint32_t* pre_full;    // two-level lookups above by one load + one product
+  const uint32_t* post_full;
+  const uint32_t* in[NTT_MAX_BATCH];
+  uint32_t* out[NTT_MAX_BATCH];
 };
 
+// full tables: out[i] = hi[e >> h] * lo[e & mask] with e = i (coset factors) or the inter-pass exponent of output i
 template <class P>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* __restrict__ in,
-                                                               uint32_t* __restrict__ out, NttPassArgs a) {
+__global__ __launch_bounds__(256) void ntt_full_table_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ lo,
+                                                             const uint32_t* __restrict__ hi, int h, uint32_t n,
+                                                             int S, int logB, int twiddle) {
   using F = Fp<P>;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t e = i;
+  if (twiddle) {
+    uint32_t k1 = (i >> logB) & ((1u << S) - 1);
+    uint32_t bj = (i >> (logB + S)) << logB;
+    e = bj * k1;
+  }
+  (F::load(hi + (size_t)(e >> h) * 8) * F::load(lo + (size_t)(e & ((1u << h) - 1)) * 8)).store(out + (size_t)i * 8);
+}
+
+template <class P>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
+  using F = Fp<P>;
+  const uint32_t* __restrict__ in = a.in[blockIdx.y];
+  uint32_t* __restrict__ out = a.out[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int S = a.S, logC = a.logC;
   const int R = 1 << S, C = 1 << logC;
@@ -184,7 +210,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* _
     uint32_t j1 = e >> logC, cc = e & (C - 1);
     uint32_t gidx = j1 * ncols + c0 + cc;
     F x = F::load(in + (size_t)gidx * 8);
-    if (a.pre_lo) {
+    if (a.pre_full) {
+      x = x * F::load(a.pre_full + (size_t)gidx * 8);
+    } else if (a.pre_lo) {
       F s = F::load(a.pre_hi + (size_t)(gidx >> a.h) * 8) * F::load(a.pre_lo + (size_t)(gidx & hmask) * 8);
       x = x * s;
     }
@@ -202,15 +230,20 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* _
       int grp = u >> (S - 1 - s);
       int p0 = (((grp * 2 * half) + pos) << logC) + cc;
       int p1 = p0 + (half << logC);
-      F x0, x1, tw;
+      F x0, x1;
 #pragma unroll
       for (int l = 0; l < 8; l++) {
         x0.v[l] = lds[l * TILE + p0];
         x1.v[l] = lds[l * TILE + p1];
-        tw.v[l] = tw_l[((pos << s) << 3) + l];
       }
       F y0 = x0 + x1;
-      F y1 = (x0 - x1) * tw;
+      F y1 = x0 - x1;
+      if (s + 1 < S) {                                   // the last stage's twiddle is w^0
+        F tw;
+#pragma unroll
+        for (int l = 0; l < 8; l++) tw.v[l] = tw_l[((pos << s) << 3) + l];
+        y1 = y1 * tw;
+      }
 #pragma unroll
       for (int l = 0; l < 8; l++) {
         lds[l * TILE + p0] = y0.v[l];
@@ -237,13 +270,19 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* _
 #pragma unroll
     for (int l = 0; l < 8; l++) x.v[l] = lds[l * TILE + pos];
     if (!a.last) {
-      uint32_t e = bj * k1;                           // < N
-      if (e) {
-        F t = F::load(a.tw_hi + (size_t)(e >> a.h) * 8) * F::load(a.tw_lo + (size_t)(e & hmask) * 8);
-        x = x * t;
+      if (a.tw_full) {
+        x = x * F::load(a.tw_full + (size_t)oidx * 8);
+      } else {
+        uint32_t e = bj * k1;                           // < N
+        if (e) {
+          F t = F::load(a.tw_hi + (size_t)(e >> a.h) * 8) * F::load(a.tw_lo + (size_t)(e & hmask) * 8);
+          x = x * t;
+        }
       }
     }
-    if (a.post_lo) {
+    if (a.post_full) {
+      x = x * F::load(a.post_full + (size_t)oidx * 8);
+    } else if (a.post_lo) {
       F t = F::load(a.post_hi + (size_t)(oidx >> a.h) * 8) * F::load(a.post_lo + (size_t)(oidx & hmask) * 8);
       x = x * t;
     } else if (a.post_const) {
@@ -264,26 +303,52 @@ static void ntt_plan(int log_n, int* S, int* P) {
   *P = p;
 }
 
-// data: N elements (device).  In place from the caller's view; uses ctx->cur->ntt_scratch.
+// lazily built full table (one-time per (curve, log_n, kind)); returns nullptr above NTT_FULL_MAX_LOG
 template <class P>
-void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* data, int log_n, int op) {
+static uint32_t* full_table(zkp_ctx* ctx, NttTables& t, uint32_t** slot, const uint32_t* lo, const uint32_t* hi, int S,
+                            int logB, int twiddle) {
+  static const bool enabled = !(getenv("ZKP_NTT_FULL") && atoi(getenv("ZKP_NTT_FULL")) == 0);   // A/B switch
+  if (!enabled || t.log_n > NTT_FULL_MAX_LOG || t.log_n < 2) return nullptr;
+  if (*slot) return *slot;
+  const size_t N = (size_t)1 << t.log_n;
+  uint32_t* blk;
+  if (hipMalloc(&blk, N * 32) != hipSuccess) return nullptr;        // fall back to the two-level lookup
+  hipStream_t s = ctx->cur->stream;
+  hipLaunchKernelGGL(ntt_full_table_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, s, blk, lo, hi, t.h, (uint32_t)N, S,
+                     logB, twiddle);
+  ZKP_HIP(hipGetLastError());
+  ZKP_HIP(hipStreamSynchronize(s));       // shared by every lane / stream afterwards
+  t.extra.push_back(blk);
+  *slot = blk;
+  return blk;
+}
+
+// data[k]: N elements each (device), k < count <= NTT_MAX_BATCH independent transforms done by the same launches.
+// In place from the caller's view; uses ctx->cur->ntt_scratch.
+template <class P>
+void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* const* data, int count, int log_n, int op) {
   ZKP_REQUIRE(log_n <= P::TWO_ADICITY, ZKP_ERR_DOMAIN_TOO_LARGE);
+  ZKP_REQUIRE(count >= 1 && count <= NTT_MAX_BATCH, ZKP_ERR_BAD_ARG);
   if (log_n == 0) return;  // size-1 transform is the identity (coset scale by g^0, 1/N = 1)
   NttTables& t = get_tables<P>(ctx, curve, log_n);
   const size_t N = (size_t)1 << log_n;
-  uint32_t* scratch = ctx->cur->ntt_scratch.as<uint32_t>(N * 8);
+  uint32_t* scratch = ctx->cur->ntt_scratch.as<uint32_t>((size_t)count * N * 8);
   int S[8], np;
   ntt_plan(log_n, S, &np);
   const bool inverse = (op == ZKP_NTT_IFFT || op == ZKP_NTT_COSET_IFFT);
   // buffers alternate; pass p (0-based) writes dst if (np-1-p) even else scratch; in-place + odd np -> copy
   const bool odd = (np & 1);
-  uint32_t* cur = data;
+  bool in_scratch = false;
   int logB = 0;
   for (int p = 0; p < np; p++) {
-    uint32_t* dst;
-    if (!odd) dst = ((np - 1 - p) & 1) ? scratch : data;
-    else dst = (p & 1) ? data : scratch;              // ends in scratch
+    bool to_scratch;
+    if (!odd) to_scratch = ((np - 1 - p) & 1) != 0;
+    else to_scratch = (p & 1) == 0;                   // ends in scratch
     NttPassArgs a{};
+    for (int k = 0; k < count; k++) {
+      a.in[k] = in_scratch ? scratch + (size_t)k * N * 8 : data[k];
+      a.out[k] = to_scratch ? scratch + (size_t)k * N * 8 : data[k];
+    }
     a.log_n = log_n;
     a.S = S[p];
     a.logB = logB;
@@ -295,14 +360,18 @@ void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* data, int log_n, int op) {
     a.tw_sub = inverse ? t.sub_inv : t.sub_fwd;
     a.tw_lo = inverse ? t.wi_lo : t.w_lo;
     a.tw_hi = inverse ? t.wi_hi : t.w_hi;
+    if (!a.last)
+      a.tw_full = full_table<P>(ctx, t, inverse ? &t.full_inv[p] : &t.full_fwd[p], a.tw_lo, a.tw_hi, S[p], logB, 1);
     if (p == 0 && op == ZKP_NTT_COSET_FFT) {
       a.pre_lo = t.g_lo;
       a.pre_hi = t.g_hi;
+      a.pre_full = full_table<P>(ctx, t, &t.full_g, t.g_lo, t.g_hi, 0, 0, 0);
     }
     if (p == np - 1) {
       if (op == ZKP_NTT_COSET_IFFT) {
         a.post_lo = t.gi_lo;
         a.post_hi = t.gi_hi;                          // includes 1/N
+        a.post_full = full_table<P>(ctx, t, &t.full_gi, t.gi_lo, t.gi_hi, 0, 0, 0);
       } else if (op == ZKP_NTT_IFFT) {
         a.post_const = t.n_inv;
       }
@@ -310,24 +379,33 @@ void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* data, int log_n, int op) {
     const int tile = 1 << (S[p] + logC);
     const size_t lds_bytes = (size_t)tile * 32 + ((size_t)1 << S[p]) / 2 * 32 + 32;
     const uint32_t grid = (uint32_t)(N >> (S[p] + logC));
-    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid), dim3(NTT_THREADS), lds_bytes, ctx->cur->stream, cur, dst, a);
-    cur = dst;
+    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid, count), dim3(NTT_THREADS), lds_bytes, ctx->cur->stream, a);
+    in_scratch = to_scratch;
     logB += S[p];
   }
   ZKP_HIP(hipGetLastError());
-  if (cur != data) ZKP_HIP(hipMemcpyAsync(data, cur, N * 32, hipMemcpyDeviceToDevice, ctx->cur->stream));
+  if (in_scratch)
+    for (int k = 0; k < count; k++)
+      ZKP_HIP(hipMemcpyAsync(data[k], scratch + (size_t)k * N * 8, N * 32, hipMemcpyDeviceToDevice, ctx->cur->stream));
 }
 
-void ntt_run(zkp_ctx* ctx, int curve, uint32_t* data, int log_n, int op) {
+void ntt_run_batch(zkp_ctx* ctx, int curve, uint32_t* const* data, int count, int log_n, int op) {
   ZKP_REQUIRE(op >= 0 && op <= 3, ZKP_ERR_BAD_ARG);
-  if (curve == ZKP_BN254) ntt_run_t<Bn254Fr>(ctx, curve, data, log_n, op);
-  else if (curve == ZKP_BLS12_381) ntt_run_t<Bls381Fr>(ctx, curve, data, log_n, op);
+  if (curve == ZKP_BN254) ntt_run_t<Bn254Fr>(ctx, curve, data, count, log_n, op);
+  else if (curve == ZKP_BLS12_381) ntt_run_t<Bls381Fr>(ctx, curve, data, count, log_n, op);
   else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
 }
 
+void ntt_run(zkp_ctx* ctx, int curve, uint32_t* data, int log_n, int op) {
+  uint32_t* one[1] = {data};
+  ntt_run_batch(ctx, curve, one, 1, log_n, op);
+}
+
 void ntt_free_tables(zkp_ctx* ctx) {
-  for (auto& kv : ctx->ntt_tables)
+  for (auto& kv : ctx->ntt_tables) {
     if (kv.second.block) (void)hipFree(kv.second.block);
+    for (void* e : kv.second.extra) (void)hipFree(e);
+  }
   ctx->ntt_tables.clear();
 }
 
