@@ -239,6 +239,25 @@ def _bases_msm_mont_dev(self, scalars_dev: int, n: int, offset: int = 0) -> np.n
 Bases.msm_mont_dev = _bases_msm_mont_dev
 
 
+def _bases_msm_mont_batch_dev(self, jobs) -> np.ndarray:
+    """PC::commit over a list: jobs = [(scalars_dev, n, offset)] -> (len(jobs), 3 * fq_limbs) Jacobian results; the MSMs
+    run three at a time on the context's MSM streams."""
+    assert self.group == 1
+    k = len(jobs)
+    out = np.zeros((k, 3 * self.curve.fq_limbs), dtype=np.uint64)
+    if k == 0:
+        return out
+    ptrs = (C.c_void_p * k)(*[j[0] for j in jobs])
+    ns = (C.c_size_t * k)(*[j[1] for j in jobs])
+    offs = (C.c_size_t * k)(*[j[2] for j in jobs])
+    _lib.check(self.ctx.lib.zkp_msm_g1_mont_batch_dev(self.ctx.h, self.handle, k, offs, ptrs, ns, _ptr(out)),
+               "zkp_msm_g1_mont_batch_dev")
+    return out
+
+
+Bases.msm_mont_batch_dev = _bases_msm_mont_batch_dev
+
+
 VEC_ADDC = 5
 
 

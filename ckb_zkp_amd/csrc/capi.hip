@@ -74,6 +74,7 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
       ZKP_HIP(hipHostMalloc(reinterpret_cast<void**>(&L.host_proof), 1100));
       for (int i = 0; i < zkp_lane::N_WS; i++) {
         ZKP_HIP(hipEventCreateWithFlags(&L.ws[i].done, hipEventDisableTiming));
+        ZKP_HIP(hipEventCreateWithFlags(&L.ws[i].sorted, hipEventDisableTiming));
         if (i > 0) {
           ZKP_HIP(hipStreamCreateWithFlags(&L.ws[i].stream, hipStreamNonBlocking));
           L.ws[i].own_stream = true;
@@ -104,10 +105,12 @@ int32_t zkp_ctx_destroy(zkp_ctx* ctx) {
     if (L.host_proof) (void)hipHostFree(L.host_proof);
     for (int i = 0; i < zkp_lane::N_WS; i++) {
       if (L.ws[i].done) (void)hipEventDestroy(L.ws[i].done);
+      if (L.ws[i].sorted) (void)hipEventDestroy(L.ws[i].sorted);
       if (L.ws[i].own_stream && L.ws[i].stream) (void)hipStreamDestroy(L.ws[i].stream);
     }
     if (L.own_stream && L.stream) (void)hipStreamDestroy(L.stream);
   }
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
   return ZKP_OK;
 }
@@ -256,6 +259,15 @@ int32_t zkp_vartime_multiscalar_mul_g2(zkp_ctx* ctx, uint64_t h, const uint64_t*
 
 int32_t zkp_msm_g1_mont_dev(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t* s, size_t n, uint64_t* out) {
   return msm_common(ctx, 1, h, off, s, n, out, true, true);
+}
+
+int32_t zkp_msm_g1_mont_batch_dev(zkp_ctx* ctx, uint64_t h, size_t count, const size_t* offsets,
+                                  const uint64_t* const* scalars_dev, const size_t* ns, uint64_t* out_xyz) {
+  if (count && (!offsets || !scalars_dev || !ns || !out_xyz)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    ZKP_REQUIRE(bases_group(ctx, h) == 1, ZKP_ERR_BAD_HANDLE);
+    msm_run_batch(ctx, h, count, offsets, scalars_dev, ns, true, out_xyz);
+  });
 }
 
 // ------------------------------------------------------------------------------------------- Fr vectors / polynomials

@@ -92,6 +92,7 @@ struct MsmWorkspace {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t done = nullptr;
+  hipEvent_t sorted = nullptr;     // recorded when the bucket sort + task schedule of the current MSM are complete
   DevBuf keys, vals, keys2, vals2, sort_tmp, offsets, buckets, tmp, out, sched, scan_tmp, scan_tmp2, partial;
 };
 struct Groth16Timing {
@@ -129,6 +130,8 @@ struct zkp_ctx {
   zkp::DevBuf ntt_io, poly_tmp, poly_consts, spmv_list;
   // MSM scratch
   zkp::DevBuf msm_scalars, msm_misc;
+  uint32_t* pinned = nullptr;      // pinned host landing zone for batched MSM results
+  size_t pinned_cap = 0;
   std::unordered_map<uint64_t, std::shared_ptr<zkp::BasesEntry>> bases;
   uint64_t next_handle = 1;
   zkp_groth16_timing last_timing{};

@@ -48,6 +48,7 @@ struct zkp_groth16_pk {
   size_t N = 0, nz = 0;
   DevCsr m[3];
   uint64_t hA = 0, hB1 = 0, hB2 = 0, hH = 0, hL = 0;
+  bool share_b_sort = false;     // b_g1_query / b_g2_query: same length, window configuration and identity pattern
   struct PerLane {   // per in-flight proof (zkp_ctx lanes)
     DevBuf abc;      // 3 * N Fr
     DevBuf S;        // nz + 4 Fr
@@ -183,6 +184,14 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d) {
     pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA);
     pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1);
     pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2);
+    {
+      // measured: reusing B2's bucket sort for B1 removes 0.55 ms of (memory-bound) sort kernels per proof but the
+      // pipelined rate drops 84.7 -> 83.0 proofs/s (the sorts hide under VALU-bound kernels anyway) — opt-in only
+      static const bool on = getenv("ZKP_SHARE_B_SORT") && atoi(getenv("ZKP_SHARE_B_SORT")) != 0;
+      const bool same_inf = (!d->b_g1_inf && !d->b_g2_inf) ||
+                            (d->b_g1_inf && d->b_g2_inf && memcmp(d->b_g1_inf, d->b_g2_inf, d->b_g1_len) == 0);
+      pk->share_b_sort = on && same_inf && bases_same_shape(ctx, pk->hB1, pk->hB2);
+    }
     pk->hH = bases_upload(ctx, d->curve, 1, d->h_query, d->h_inf, d->h_len);
     pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL);
   }
@@ -300,11 +309,12 @@ static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, b
   uint64_t ent = 0;
   // Schedule.  profiling: everything on the main stream, one MSM at a time, with per-phase events.
   // otherwise: three streams —  main: witness_map -> H ;  ws1: A -> L ;  ws2: B1 -> B2  — joined before assembly.
-  auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n, int w) {
+  auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n, int w, int sort_src = -1) {
     float ms = 0.f;
     uint64_t e = 0;
     tic();
-    msm_run(ctx, handle, 0, sc, n, true, nullptr, res + idx * slot, prof ? &ms : nullptr, &e, prof ? 0 : w);
+    msm_run(ctx, handle, 0, sc, n, true, nullptr, res + idx * slot, prof ? &ms : nullptr, &e, prof ? 0 : w,
+            prof ? -1 : sort_src);
     toc(&tm.ms_msm[idx]);
     acc_ms += ms;
     ent += e;
@@ -316,7 +326,7 @@ static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, b
     // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H -> L | ws3: part 1 after A, B1
     run(2, pk->hB2, Sd, pk->nz + 4, 2);                                            // prover.rs:182-184
     run(0, pk->hA, Sd, pk->nz + 4, 1);                                             // prover.rs:164-167
-    run(1, pk->hB1, Sd, pk->nz + 4, 1);                                            // prover.rs:170-177
+    run(1, pk->hB1, Sd, pk->nz + 4, 1, pk->share_b_sort ? 2 : -1);                 // prover.rs:170-177 (B2's bucket sort reused)
     ZKP_HIP(hipEventRecord(ctx->cur->ev_b1, ctx->cur->ws[1].stream));
     // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~4 ms single-wave chain: start them as soon as
     // A and B1 exist so they hide under the remaining MSMs

@@ -30,7 +30,12 @@ int bases_group(zkp_ctx* ctx, uint64_t handle);
 // runs on workspace `ws` (its stream + scratch); does not synchronise unless out_xyz_host != nullptr
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
              uint64_t* out_xyz_host, void* out_dev_xyzz = nullptr, float* ms_accumulate = nullptr,
-             uint64_t* n_entries = nullptr, int ws = 0);
+             uint64_t* n_entries = nullptr, int ws = 0, int sort_src = -1);
+// sort_src >= 0: reuse the bucket sort + task schedule that workspace `sort_src` of the same lane computed for the SAME
+// scalars, length, window configuration and identity flags (Groth16: b_g1_query / b_g2_query) instead of redoing it
+bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2);
+void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* offsets, const uint64_t* const* scalars_dev,
+                   const size_t* ns, bool montgomery, uint64_t* out_xyz_host);
 void msm_free_all(zkp_ctx* ctx);
 void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz_host);
 void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, uint64_t* xy_out, uint8_t* inf_out);

@@ -117,6 +117,10 @@ void bases_free(zkp_ctx* ctx, uint64_t handle) {
 size_t bases_len(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->n; }
 int bases_group(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->group; }
 void msm_free_all(zkp_ctx* ctx) { ctx->bases.clear(); }
+bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2) {
+  auto a = get_bases(ctx, h1), b = get_bases(ctx, h2);
+  return a->curve == b->curve && a->n == b->n && a->c == b->c && a->W == b->W;
+}
 
 // ------------------------------------------------------------------------------------------- K5 digit scan
 // Signed c-bit digits of one scalar, produced on the fly inside BOTH level-1 sort passes (histogram and scatter):
@@ -509,10 +513,13 @@ __global__ __launch_bounds__(256) void task_order_kernel(const uint32_t* __restr
 }
 
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
-             uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries, int ws_idx) {
+             uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries, int ws_idx,
+             int sort_src) {
   auto be = get_bases(ctx, handle);
   const MsmVtbl* vt = be->vt;
   MsmWorkspace& ws = ctx->cur->ws[ws_idx];
+  const bool reuse = sort_src >= 0 && sort_src != ws_idx;
+  MsmWorkspace& sw = reuse ? ctx->cur->ws[sort_src] : ws;          // owner of the sorted entries and the task schedule
   hipStream_t st = ws_idx == 0 ? ctx->cur->stream : ws.stream;
   const size_t XB = vt->xyzz_bytes;
   const size_t jac_words = 3 * (size_t)vt->fN;
@@ -526,8 +533,8 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     const uint32_t nb = 1u << (c - 1);
     const size_t E = n * (size_t)W;
     ZKP_REQUIRE(E < 2147483000ull, ZKP_ERR_BAD_ARG);
-    uint32_t* vals = ws.vals.as<uint32_t>(E);                        // values grouped by bucket (level-2 output)
-    uint64_t* kv = ws.keys2.as<uint64_t>(E);                         // level-1 output: (low key, val) pairs
+    uint32_t* vals = sw.vals.as<uint32_t>(E);                        // values grouped by bucket (level-2 output)
+    uint64_t* kv = sw.keys2.as<uint64_t>(E);                         // level-1 output: (low key, val) pairs
     const uint32_t* sc = reinterpret_cast<const uint32_t*>(scalars_dev);
     const int mont = montgomery ? 1 : 0;
     // K6: group entries by bucket (two-level counting sort); sorted values land back in `vals`
@@ -538,15 +545,17 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     const uint32_t nbins1 = 1u << H1;
     const uint32_t nblocks = (uint32_t)((n + SORT_SCALARS - 1) / SORT_SCALARS);
     const size_t hist_n = (size_t)nbins1 * nblocks + 1;                // + total (== number of non-zero digits)
-    uint32_t* hist = ws.sort_tmp.as<uint32_t>(2 * hist_n);
+    uint32_t* hist = sw.sort_tmp.as<uint32_t>(2 * hist_n);
     uint32_t* offs = hist + hist_n;
-    uint32_t* start = ws.offsets.as<uint32_t>(2 * (size_t)nb);
+    uint32_t* start = sw.offsets.as<uint32_t>(2 * (size_t)nb);
     uint32_t* end = start + nb;
-    ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
+    if (reuse) ZKP_HIP(hipStreamWaitEvent(st, sw.sorted, 0));
+    else ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
     static const bool stage_env = [] { const char* e = getenv("ZKP_SORT_STAGE"); return e && atoi(e) != 0; }();   // default off: measured 4 % slower end to end (92 KiB LDS -> 1 workgroup per CU)
     const bool stage_ok = stage_env && (size_t)SORT_SCALARS * W <= SORT_STAGE_CAP;
     const size_t stage_lds = (size_t)SORT_STAGE_CAP * 8 + (size_t)SORT_STAGE_CAP * 2;
-    if (be->curve == ZKP_BN254) {
+    if (reuse) {
+    } else if (be->curve == ZKP_BN254) {
       hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
                          nb, LB, nbins1, hist, nblocks);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
@@ -567,13 +576,13 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
         hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
                            be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
     }
-    hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(SORT_BIN_THREADS), ((size_t)4 << LB) + 4 * (size_t)SORT_BIN_STAGE, st,
-                       kv, offs, nblocks, LB, vals,
-                       start, end);
+    if (!reuse)
+      hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(SORT_BIN_THREADS), ((size_t)4 << LB) + 4 * (size_t)SORT_BIN_STAGE, st,
+                         kv, offs, nblocks, LB, vals, start, end);
     uint32_t* const sorted_vals = vals;
     // K7 scheduling: buckets -> tasks (<= CAP entries), ordered by length
     const uint32_t max_tasks = nb + (uint32_t)(E / MSM_TASK_CAP) + 1;
-    uint32_t* sched = ws.sched.as<uint32_t>((size_t)2 * (nb + 2) + (size_t)5 * max_tasks + TM_WORDS);
+    uint32_t* sched = sw.sched.as<uint32_t>((size_t)2 * (nb + 2) + (size_t)5 * max_tasks + TM_WORDS);
     uint32_t* tcount = sched;                       // nb + 1
     uint32_t* toff = tcount + (nb + 2);             // nb + 1  (toff[nb] = number of tasks)
     uint32_t* task_start = toff + (nb + 2);
@@ -582,14 +591,17 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     uint32_t* order = task_dst + max_tasks;
     uint32_t* long_list = order + max_tasks;
     uint32_t* tmeta = long_list + max_tasks;
-    ZKP_HIP(hipMemsetAsync(tmeta, 0, TM_WORDS * 4, st));
-    hipLaunchKernelGGL(task_count_kernel, dim3((nb + 256) / 256), dim3(256), 0, st, start, end, nb, tcount);
-    exclusive_scan_u32(st, tcount, toff, (size_t)nb + 1, ws.scan_tmp2);
-    hipLaunchKernelGGL(task_fill_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, start, end, toff, nb, task_start,
-                       task_len, task_dst, long_list, tmeta);
-    hipLaunchKernelGGL(task_cursor_kernel, dim3(1), dim3(64), 0, st, tmeta);
-    hipLaunchKernelGGL(task_order_kernel, dim3((max_tasks + 255) / 256), dim3(256), 0, st, task_len, toff + nb, tmeta,
-                       order);
+    if (!reuse) {
+      ZKP_HIP(hipMemsetAsync(tmeta, 0, TM_WORDS * 4, st));
+      hipLaunchKernelGGL(task_count_kernel, dim3((nb + 256) / 256), dim3(256), 0, st, start, end, nb, tcount);
+      exclusive_scan_u32(st, tcount, toff, (size_t)nb + 1, ws.scan_tmp2);
+      hipLaunchKernelGGL(task_fill_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, start, end, toff, nb, task_start,
+                         task_len, task_dst, long_list, tmeta);
+      hipLaunchKernelGGL(task_cursor_kernel, dim3(1), dim3(64), 0, st, tmeta);
+      hipLaunchKernelGGL(task_order_kernel, dim3((max_tasks + 255) / 256), dim3(256), 0, st, task_len, toff + nb, tmeta,
+                         order);
+      ZKP_HIP(hipEventRecord(ws.sorted, st));
+    }
     // level l of the reduction pyramid lives at element offset lvl_off[l] of `buckets` (level 0 = buckets);
     // all-zero bytes are a valid identity (zz == 0), so empty buckets need no kernel
     char* buckets = reinterpret_cast<char*>(ws.buckets.get((size_t)2 * nb * XB + XB));
@@ -647,6 +659,41 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     ZKP_HIP(hipMemcpyAsync(out_xyz_host, out_jac, jac_words * 4, hipMemcpyDeviceToHost, st));
     ZKP_HIP(hipStreamSynchronize(st));
   }
+}
+
+// `count` MSMs against ONE resident base vector (different offsets / lengths / scalar vectors), three in flight at a
+// time: one per MSM workspace (stream + scratch) of the current lane, so that the latency-bound bucket-reduction tail
+// of one overlaps the throughput-bound kernels of the next.  Results (Jacobian) land in out_xyz_host[k * 3 * fN u64].
+void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* offsets, const uint64_t* const* scalars_dev,
+                   const size_t* ns, bool montgomery, uint64_t* out_xyz_host) {
+  if (count == 0) return;
+  auto be = get_bases(ctx, handle);
+  const size_t jw = 3 * (size_t)be->vt->fN;                       // 32-bit words per Jacobian result
+  zkp_lane* L = ctx->cur;
+  if (ctx->pinned_cap < count * jw * 4) {
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    ctx->pinned_cap = 0;
+    ZKP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), count * jw * 4 + 4096));
+    ctx->pinned_cap = count * jw * 4 + 4096;
+  }
+  constexpr int NW = 3;
+  ZKP_HIP(hipEventRecord(L->ev_fork, L->stream));                  // scalars are complete on the main stream
+  for (int w = 1; w < NW; w++) ZKP_HIP(hipStreamWaitEvent(L->ws[w].stream, L->ev_fork, 0));
+  for (size_t k = 0; k < count; k++) {
+    const int w = (int)(k % NW);
+    ZKP_REQUIRE(offsets[k] <= be->n, ZKP_ERR_BAD_ARG);
+    const size_t n = std::min(ns[k], be->n - offsets[k]);        // ark min(len) truncation
+    msm_run(ctx, handle, offsets[k], scalars_dev[k], n, montgomery, nullptr, nullptr, nullptr, nullptr, w);
+    hipStream_t st = w == 0 ? L->stream : L->ws[w].stream;
+    ZKP_HIP(hipMemcpyAsync(ctx->pinned + k * jw, L->ws[w].out.p, jw * 4, hipMemcpyDeviceToHost, st));
+  }
+  for (int w = 1; w < NW; w++) {
+    ZKP_HIP(hipEventRecord(L->ws[w].done, L->ws[w].stream));
+    ZKP_HIP(hipStreamWaitEvent(L->stream, L->ws[w].done, 0));
+  }
+  ZKP_HIP(hipStreamSynchronize(L->stream));
+  memcpy(out_xyz_host, ctx->pinned, count * jw * 4);
 }
 
 void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz, size_t k, uint64_t* out) {

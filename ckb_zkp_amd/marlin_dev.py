@@ -445,27 +445,42 @@ def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circui
             xy, inf = ctx.into_affine(c, 1, jac)
             return codec.g1_from_mont(xy, [inf], c)[0]
 
-        def commit(l, power_offset=0, blind=None):
-            jac = be.msm(ck.powers_of_g, polys[l], offset=power_offset)
-            if blind is not None:
-                jac = ctx.fold(c, 1, np.concatenate([jac, be.msm(ck.powers_of_gamma_g, blind)]))
-            return to_affine(jac)
+        # one batched call per base vector: the MSMs overlap three at a time on the context's MSM streams
+        labels = LABELS_1 + LABELS_2 + LABELS_3
+        jobs, slot = [], {}
+        for l in labels:
+            slot[(l, False)] = len(jobs)
+            jobs.append((polys[l].ptr, polys[l].n, 0))
+            if l in bounds:                                  # shifted_powers(bound) = powers[D - bound ..]
+                slot[(l, True)] = len(jobs)
+                jobs.append((polys[l].ptr, polys[l].n, D - bounds[l]))
+        jac = ck.powers_of_g.msm_mont_batch_dev(jobs)
+        bjobs, bslot = [], {}
+        for l in labels:
+            if hide(l):
+                bslot[(l, False)] = len(bjobs)
+                bjobs.append((blind_dev[l].ptr, 2, 0))
+                if l in bounds:
+                    bslot[(l, True)] = len(bjobs)
+                    bjobs.append((blind_s_dev[l].ptr, 2, 0))
+        bjac = ck.powers_of_gamma_g.msm_mont_batch_dev(bjobs)
 
-        comms = {}
-        for l in LABELS_1 + LABELS_2 + LABELS_3:
-            comm = commit(l, 0, blind_dev[l] if hide(l) else None)
-            shifted = None
-            if l in bounds:
-                shifted = commit(l, D - bounds[l], blind_s_dev[l] if hide(l) else None)
-            comms[l] = (comm, shifted)
+        def point(l, shifted):
+            j = jac[slot[(l, shifted)]]
+            if (l, shifted) in bslot:
+                j = ctx.fold(c, 1, np.concatenate([j, bjac[bslot[(l, shifted)]]]))
+            return to_affine(j)
+
+        comms = {l: (point(l, False), point(l, True) if l in bounds else None) for l in labels}
         ctx.sync()
         t_commit = time.perf_counter()
         # ---- evaluations + batch_open (lib.rs:147-165, pc/mod.rs:73-160)
         query = sorted([(l, beta) for l in LABELS_1 + LABELS_2] + [(l, gamma) for l in LABELS_3 + INDEX_LABELS])
         evals = [be.evaluate(polys[l], pt) for l, pt in query]
         xi = ch["xi"]
-        proofs = []
-        for pt in sorted({pt for _, pt in query}):
+        points = sorted({pt for _, pt in query})
+        wjobs, rbs = [], []
+        for pt in points:
             p = be.zeros(D + 1)
             rb, chal = [0, 0], 1
             for l in sorted(l for l, q in query if q == pt):
@@ -478,15 +493,18 @@ def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circui
                     if hide(l):
                         rb = [(rb[i] + sc * rnd["blind_shifted"][l][i]) % r for i in range(2)]
                 chal = chal * xi % r * xi % r
-            zm = codec.fr_to_mont([pt], c)[0]
             q = be.alloc(D)
-            ctx.poly_div_linear(c, p.ptr, D + 1, zm, q.ptr)
-            w_jac = be.msm(ck.powers_of_g, q)
+            ctx.poly_div_linear(c, p.ptr, D + 1, codec.fr_to_mont([pt], c)[0], q.ptr)
+            wjobs.append((q.ptr, D, 0))
+            rbs.append(rb)
+        wjac = ck.powers_of_g.msm_mont_batch_dev(wjobs)          # both witness MSMs in flight together
+        proofs = []
+        for pt, w_jac, rb in zip(points, wjac, rbs):
             rand_v = None
             if any(rb):
                 rbd = be.upload(rb)
                 qb = be.alloc(1)
-                ev = ctx.poly_div_linear(c, rbd.ptr, 2, zm, qb.ptr)
+                ev = ctx.poly_div_linear(c, rbd.ptr, 2, codec.fr_to_mont([pt], c)[0], qb.ptr)
                 w_jac = ctx.fold(c, 1, np.concatenate([w_jac, be.msm(ck.powers_of_gamma_g, qb)]))
                 rand_v = codec.fr_from_mont(ev.reshape(1, 4), c)[0]
             proofs.append((to_affine(w_jac), rand_v))

@@ -98,3 +98,29 @@ def test_kzg10_commit_open_check(ctx, curve):
     finally:
         ck.powers_of_g.free()
         ck.powers_of_gamma_g.free()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_batched_commit_msms_equal_individual_ones(ctx, curve):
+    """zkp_msm_g1_mont_batch_dev (PC::commit over a list: concurrent MSMs on the context's streams) returns, job by job,
+    the same group element as zkp_msm_g1_mont_dev — including offsets, truncation at the end of the powers and n = 0."""
+    c = get_curve(curve)
+    rnd = random.Random(17)
+    ck = kzg10.setup(ctx, curve, 700, 0x5EED5EED)
+    try:
+        jobs, ptrs = [], []
+        for n, off in ((701, 0), (300, 401), (2, 0), (0, 5), (650, 100), (1, 700), (257, 13), (64, 0)):
+            coeffs = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(max(n, 1))], c).reshape(-1, 4)
+            d = ctx.to_device(coeffs)
+            ptrs.append(d)
+            jobs.append((d, n, off))
+        got = ck.powers_of_g.msm_mont_batch_dev(jobs)
+        for k, (d, n, off) in enumerate(jobs):
+            want = ck.powers_of_g.msm_mont_dev(d, n, offset=off)
+            assert ctx.into_affine(c, 1, got[k])[0].tolist() == ctx.into_affine(c, 1, want)[0].tolist(), (k, n, off)
+            assert int(ctx.into_affine(c, 1, got[k])[1]) == int(ctx.into_affine(c, 1, want)[1])
+        for d in ptrs:
+            ctx.dev_free(d)
+    finally:
+        ck.powers_of_g.free()
+        ck.powers_of_gamma_g.free()
