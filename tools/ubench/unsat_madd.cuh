@@ -1,0 +1,281 @@
+// EXPERIMENT (not built into the library): unsaturated-limb field arithmetic for the bucket-accumulation kernel.
+// Result on MI355X: the multiplier alone is 1.26-1.5x faster (tools/ubench/unsat.hip: 160 vs 107-128 G products/s),
+// but the complete mixed addition below — normalising subtractions (4 VALU per limb instead of 3), limb conversions of
+// every gathered point, 174 VGPRs (2 waves/SIMD instead of 3) and the accumulator forced into scratch by the
+// out-of-line exceptional path — made the accumulate kernel 20 % SLOWER (2.58 -> 3.07 ms for the 1.26 M-point A query;
+// results bit-identical, all MSM / Groth16 parity tests green).  Kept as a record of the attempt; see DESIGN.md.
+//
+//
+// field.cuh multiplies on saturated 32-bit limbs: every 32x32 partial product is a v_mad_u64_u32 PLUS a v_addc_co_u32
+// that banks the carry, and every column of the product scan costs two v_mov.  Here a field element is L limbs of B bits
+// (9 x 29 for the 254-bit BN254 fields, 14 x 28 for the 381-bit BLS12-381 base field): a whole column (<= 2L partial
+// products < 2^(2B)) fits the 64-bit accumulator, so a partial product is ONE instruction and the column hand-over is a
+// shift — (L/N)^2 more products, but 0.6x the VALU instructions (measured: tools/ubench/unsat.hip, profiles/).
+//
+// Montgomery radix R' = 2^(L*B) (2^261 / 2^392), so p/R' <= 2^-7: a product of inputs < X*p and < Y*p is
+// < (X*Y*p/R' + 1) * p < 2p for X*Y <= 128 WITHOUT a final subtraction, and additions / subtractions can stay
+// unreduced ("value < K*p" bookkeeping is done by hand in xyzz_madd_u below).  A saturated Montgomery value
+// X = x*2^(32N) (what the window tables and buckets hold in HBM) enters this form by a pure bit shift:
+// (X << (L*B - 32N)) = x * R' (mod p), < 32p (< 256p); it leaves by one product with 2^(32N) mod p.
+#pragma once
+#include "ec.cuh"
+#include "field.cuh"
+
+namespace zkp {
+
+template <class P>
+struct UnsatCfg;
+template <>
+struct UnsatCfg<Bn254Fq> {
+  static constexpr int L = 9, B = 29;
+};
+template <>
+struct UnsatCfg<Bls381Fq> {
+  static constexpr int L = 14, B = 28;
+};
+
+template <class P>
+struct Fu {
+  static constexpr int L = UnsatCfg<P>::L, B = UnsatCfg<P>::B, N = P::N;
+  static constexpr uint32_t MASK = (1u << B) - 1;
+  static constexpr int SHIFT = L * B - 32 * N;              // R' / R
+  uint32_t v[L];
+
+  static constexpr int KMAX = 10;                           // multiples of p kept as limb tables
+  struct Tab {
+    uint32_t mp[KMAX + 1][L];                               // limbs of M * p (top limb unmasked)
+    uint32_t one[L];                                        // R' mod p = canonical "1" of this representation
+    uint32_t ninv;                                          // -p^-1 mod 2^B
+  };
+  static constexpr uint32_t limb_of(const uint32_t* w, int nw, int i) {
+    int bit = i * B, wi = bit >> 5, o = bit & 31;
+    uint64_t lo = wi < nw ? w[wi] : 0, hi = wi + 1 < nw ? w[wi + 1] : 0;
+    uint64_t x = (lo | (hi << 32)) >> o;
+    return i == L - 1 ? (uint32_t)x : (uint32_t)(x & MASK);
+  }
+  static constexpr Tab make_tab() {
+    Tab t{};
+    for (int M = 0; M <= KMAX; M++) {
+      uint32_t w[N + 2] = {};
+      uint64_t c = 0;
+      for (int k = 0; k < N; k++) {
+        c += (uint64_t)P::MOD[k] * (uint32_t)M;
+        w[k] = (uint32_t)c;
+        c >>= 32;
+      }
+      w[N] = (uint32_t)c;
+      for (int i = 0; i < L; i++) t.mp[M][i] = limb_of(w, N + 2, i);
+    }
+    // one = (2^(32N) mod p) * 2^SHIFT mod p, by SHIFT modular doublings
+    uint32_t w[N + 2] = {};
+    for (int k = 0; k < N; k++) w[k] = P::ONE[k];
+    for (int s = 0; s < SHIFT; s++) {
+      uint32_t carry = 0;
+      for (int k = 0; k <= N; k++) {
+        uint32_t nx = w[k] >> 31;
+        w[k] = (w[k] << 1) | carry;
+        carry = nx;
+      }
+      bool ge = true;                                       // w >= p ?
+      for (int k = N; k >= 0; k--) {
+        uint32_t pk = k < N ? P::MOD[k] : 0;
+        if (w[k] != pk) {
+          ge = w[k] > pk;
+          break;
+        }
+      }
+      if (ge) {
+        uint64_t borrow = 0;
+        for (int k = 0; k <= N; k++) {
+          uint64_t pk = k < N ? P::MOD[k] : 0;
+          uint64_t d = (uint64_t)w[k] - pk - borrow;
+          w[k] = (uint32_t)d;
+          borrow = (d >> 63) & 1;
+        }
+      }
+    }
+    for (int i = 0; i < L; i++) t.one[i] = limb_of(w, N + 2, i);
+    uint32_t p0 = P::MOD[0], x = 1;
+    for (int i = 0; i < 6; i++) x *= 2u - p0 * x;
+    t.ninv = (0u - x) & MASK;
+    return t;
+  }
+  static constexpr Tab TAB = make_tab();
+  static constexpr uint32_t mp_limb(int M, int i) { return TAB.mp[M][i]; }
+  static constexpr uint32_t ninv() { return TAB.ninv; }
+  ZKP_DEV static Fu one() {
+    Fu r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.v[i] = TAB.one[i];
+    return r;
+  }
+
+  // saturated words (value < 2^(32N)) -> limbs, shifted left by `sh` bits
+  ZKP_DEV static Fu from_words(const uint32_t* a, int sh) {
+    Fu r;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int bit = i * B - sh;
+      int wi = bit >> 5, o = bit & 31;                      // arithmetic shift: wi = -1 for the bits shifted in
+      uint32_t lo = (wi >= 0 && wi < N) ? a[wi] : 0, hi = (wi + 1 >= 0 && wi + 1 < N) ? a[wi + 1] : 0;
+      uint64_t w = ((uint64_t)hi << 32) | lo;
+      r.v[i] = (uint32_t)(w >> o) & MASK;
+    }
+    return r;
+  }
+  // x * 2^(32N) (saturated Montgomery, canonical) -> x * R' as the integer 2^SHIFT * X (< 2^SHIFT * p): usable as ONE
+  // factor of a product whose other factor is < 4p
+  ZKP_DEV static Fu from_sat(const Fp<P>& a) { return from_words(a.v, SHIFT); }
+  // the same, brought below 2p by a product with one()
+  ZKP_DEV static Fu from_sat_reduced(const Fp<P>& a) { return mul(from_sat(a), one()); }
+  // normalised limbs, value < 2^(32N) -> saturated words
+  ZKP_DEV void to_words(uint32_t* out) const {
+#pragma unroll
+    for (int w = 0; w < N; w++) {
+      uint64_t acc = 0;
+#pragma unroll
+      for (int i = 0; i < L; i++) {
+        int sh = i * B - 32 * w;
+        if (sh > -B && sh < 32) acc |= sh >= 0 ? ((uint64_t)v[i] << sh) : ((uint64_t)v[i] >> (-sh));
+      }
+      out[w] = (uint32_t)acc;
+    }
+  }
+  // x * R' (any value < 128p) -> canonical saturated Montgomery x * 2^(32N)
+  ZKP_DEV Fp<P> to_sat() const {
+    Fp<P> one = Fp<P>::one();                               // 2^(32N) mod p
+    Fu t = mul(*this, from_words(one.v, 0));                // * 2^(32N) / R', < 2p
+    Fp<P> r;
+    t.to_words(r.v);
+    return Fp<P>::reduce_once(r);
+  }
+
+  // Montgomery product, one 64-bit accumulator per column, no carry bank.  Limbs of a, b < 2^30.
+  ZKP_DEV static Fu mul(const Fu& a, const Fu& b) {
+    uint32_t m[L];
+    Fu r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; k++) {
+#pragma unroll
+      for (int i = 0; i < L; i++) {
+        int j = k - i;
+        if (j >= 0 && j < L) acc += (uint64_t)a.v[i] * b.v[j];
+      }
+#pragma unroll
+      for (int i = 0; i < L; i++) {
+        int j = k - i;
+        if (j >= 0 && j < L && i < k) acc += (uint64_t)m[i] * mp_limb(1, j);
+      }
+      if (k < L) {
+        m[k] = ((uint32_t)acc * ninv()) & MASK;
+        acc += (uint64_t)m[k] * mp_limb(1, 0);
+      } else {
+        r.v[k - L] = (uint32_t)acc & MASK;
+      }
+      acc >>= B;
+    }
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
+  }
+  ZKP_DEV Fu sqr() const { return mul(*this, *this); }
+
+  // a - b + M*p with normalised limbs; requires b < M*p (value) — result in (0, a + M*p)
+  template <int M>
+  ZKP_DEV static Fu sub(const Fu& a, const Fu& b) {
+    Fu r;
+    int32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int32_t t = (int32_t)a.v[i] + (int32_t)(mp_limb(M, i) - b.v[i]) + carry;
+      if (i < L - 1) {
+        r.v[i] = (uint32_t)t & MASK;
+        carry = t >> B;
+      } else {
+        r.v[i] = (uint32_t)t;
+      }
+    }
+    return r;
+  }
+  // 2a, normalised
+  ZKP_DEV Fu dbl() const {
+    Fu r;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      uint32_t t = (v[i] << 1) + carry;
+      if (i < L - 1) {
+        r.v[i] = t & MASK;
+        carry = t >> B;
+      } else {
+        r.v[i] = t;
+      }
+    }
+    return r;
+  }
+  // cheap necessary condition for "value is a multiple of p" when 0 < value < KMAX*p: the low limb matches k*p
+  template <int KMAX>
+  ZKP_DEV bool maybe_multiple_of_p() const {
+    bool hit = false;
+#pragma unroll
+    for (int k = 1; k < KMAX; k++) hit |= (v[0] == (mp_limb(k, 0) & MASK));
+    return hit;
+  }
+};
+
+// Bucket accumulator in unsaturated form.  Value bounds maintained by madd: x < 8p, y < 4p, zz, zzz < 2p.
+template <class P>
+struct XYZZu {
+  Fu<P> x, y, zz, zzz;
+  bool inf;
+};
+
+// exceptional cases (operand equal to +-accumulator: one in 2^29 false alarms plus the real ones): exact arithmetic on
+// the saturated path
+template <class P>
+__device__ __noinline__ void xyzz_madd_u_slow(XYZZu<P>* acc, const Fp<P>* px, const Fp<P>* py) {
+  using F = Fp<P>;
+  XYZZ<F> a{acc->x.to_sat(), acc->y.to_sat(), acc->zz.to_sat(), acc->zzz.to_sat()};
+  a.madd(Affine<F>{*px, *py});
+  acc->inf = a.is_inf();
+  acc->x = Fu<P>::from_sat_reduced(a.x);
+  acc->y = Fu<P>::from_sat_reduced(a.y);
+  acc->zz = Fu<P>::from_sat_reduced(a.zz);
+  acc->zzz = Fu<P>::from_sat_reduced(a.zzz);
+}
+
+// acc += (px, py)  — madd-2008-s (8M + 2S) with hand-tracked bounds; px, py canonical saturated Montgomery, not the
+// identity
+template <class P>
+ZKP_DEV void xyzz_madd_u(XYZZu<P>& acc, const Fp<P>& px, const Fp<P>& py) {
+  using U = Fu<P>;
+  const U ux = U::from_sat(px), uy = U::from_sat(py);      // < 2^SHIFT * p as integers; fine as ONE mul operand
+  if (acc.inf) {
+    acc.x = U::mul(ux, U::one());                          // < 2p
+    acc.y = U::mul(uy, U::one());
+    acc.zz = U::one();
+    acc.zzz = U::one();
+    acc.inf = false;
+    return;
+  }
+  U u2 = U::mul(ux, acc.zz);                               // < 2p
+  U s2 = U::mul(uy, acc.zzz);                              // < 2p
+  U pd = U::template sub<8>(u2, acc.x);                    // (0, 10p)
+  U rd = U::template sub<4>(s2, acc.y);                    // (0, 6p)
+  if (pd.template maybe_multiple_of_p<10>()) {
+    xyzz_madd_u_slow<P>(&acc, &px, &py);
+    return;
+  }
+  U pp = pd.sqr();                                         // < 2p
+  U ppp = U::mul(pd, pp);                                  // < 2p
+  U q = U::mul(acc.x, pp);                                 // < 2p
+  U t = U::template sub<2>(rd.sqr(), ppp);                 // (0, 4p)
+  U x3 = U::template sub<4>(t, q.dbl());                   // (0, 8p)
+  U y3 = U::template sub<2>(U::mul(rd, U::template sub<8>(q, x3)), U::mul(acc.y, ppp));   // (0, 4p)
+  acc.zz = U::mul(acc.zz, pp);
+  acc.zzz = U::mul(acc.zzz, ppp);
+  acc.x = x3;
+  acc.y = y3;
+}
+
+}  // namespace zkp
