@@ -6,7 +6,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "lib" / "libzkp_accel.so"
+LIB_PATH = Path(os.environ.get("ZKP_ACCEL_LIB") or Path(__file__).resolve().parent / "lib" / "libzkp_accel.so")   # override: A/B builds
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)

@@ -25,8 +25,8 @@ UNITS = [("ntt.hip", "ntt.o", ["-DZKP_INLINE_MUL"]),
          ("capi.hip", "capi.o", [])]
 for _c, _g in CONFIGS:
     _d = [f"-DZKP_CFG_CURVE={_c}", f"-DZKP_CFG_GROUP={_g}"]
-    UNITS.append(("msm_group.hip", f"msm_group_c{_c}{_g}.o", _d + (["-DZKP_INLINE_MUL"] if (_c, _g) == (0, 1) else [])))
-    UNITS.append(("msm_acc.hip", f"msm_acc_c{_c}{_g}.o", _d + (["-DZKP_INLINE_MUL"] if (_c, _g) != (1, 2) else [])))   # BLS12-381 G2: inlining spills 2.5 KB/lane
+    UNITS.append(("msm_group.hip", f"msm_group_c{_c}{_g}.o", _d + (["-DZKP_INLINE_MUL"] if (_c, _g) in ((0, 1), (0, 2), (1, 1)) else [])))
+    UNITS.append(("msm_acc.hip", f"msm_acc_c{_c}{_g}.o", _d + ["-DZKP_INLINE_MUL"]))
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed",
          "-ffp-contract=off"]
 
