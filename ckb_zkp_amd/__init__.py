@@ -8,3 +8,9 @@ without a gfx950 device, raises.
 from .params import BN254, BLS12_381, get_curve  # noqa: F401
 
 __all__ = ["BN254", "BLS12_381", "get_curve"]
+
+import os as _os
+
+# The prover keeps ~20 HIP streams busy; ROCm maps them onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams
+# sharing a queue serialise.  Must be set before the HIP runtime initialises (i.e. before the first torch.cuda / HIP call).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

@@ -1,5 +1,6 @@
 // extern "C" boundary (include/zkp_accel.h): argument checking, exception -> status mapping, host<->device
 // staging for the host-pointer variants.  No arithmetic lives here.
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx.hpp"
@@ -57,6 +58,10 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
             device_id);
     return ZKP_ERR_DEVICE;
   }
+  // The proof pipeline keeps ~20 streams busy (5 lanes x 4).  ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES
+  // hardware queues (default 4) and streams that share a queue serialise; 16 queues measured best on MI355X
+  // (84 -> 95 proofs/s at 2^20).  Only effective if the HIP runtime has not been initialised by the host yet.
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
   zkp_ctx* ctx = new (std::nothrow) zkp_ctx();
   if (!ctx) return ZKP_ERR_OOM;
   ctx->device = device_id;

@@ -199,7 +199,8 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d) {
   if (d->curve == ZKP_BN254) hipLaunchKernelGGL(qap_consts_kernel<Bn254Fr>, dim3(1), dim3(64), 0, ctx->cur->stream, consts, lg);
   else hipLaunchKernelGGL(qap_consts_kernel<Bls381Fr>, dim3(1), dim3(64), 0, ctx->cur->stream, consts, lg);
   ZKP_HIP(hipGetLastError());
-  for (auto& L : pk->lane) {
+  for (int l = 0; l < 2; l++) {                     // further lanes allocate on first use
+    auto& L = pk->lane[l];
     L.abc.get(3 * pk->N * 32);
     L.S.get((pk->nz + 4) * 32);
     L.results.get(6 * 16 * 24 * 4 + 64);
@@ -309,18 +310,21 @@ static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, b
   uint64_t ent = 0;
   // Schedule.  profiling: everything on the main stream, one MSM at a time, with per-phase events.
   // otherwise: three streams —  main: witness_map -> H ;  ws1: A -> L ;  ws2: B1 -> B2  — joined before assembly.
+  // ZKP_SINGLE_STREAM=1: one stream per proof (no fan-out inside a proof); concurrency then comes from the lanes only
+  static const bool single_stream = getenv("ZKP_SINGLE_STREAM") && atoi(getenv("ZKP_SINGLE_STREAM")) != 0;
+  const bool fan = !prof && !single_stream;
   auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n, int w, int sort_src = -1) {
     float ms = 0.f;
     uint64_t e = 0;
     tic();
-    msm_run(ctx, handle, 0, sc, n, true, nullptr, res + idx * slot, prof ? &ms : nullptr, &e, prof ? 0 : w,
-            prof ? -1 : sort_src);
+    msm_run(ctx, handle, 0, sc, n, true, nullptr, res + idx * slot, prof ? &ms : nullptr, &e, fan ? w : 0,
+            fan ? sort_src : -1);
     toc(&tm.ms_msm[idx]);
     acc_ms += ms;
     ent += e;
     tm.msm_accumulate_launches += 1;
   };
-  if (!prof) {
+  if (fan) {
     ZKP_HIP(hipEventRecord(ctx->cur->ev_fork, st));                       // S is complete
     for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[w].stream, ctx->cur->ev_fork, 0));
     // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H -> L | ws3: part 1 after A, B1
@@ -336,14 +340,14 @@ static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, b
   tic();
   uint32_t* h = witness_map_dev<FrP>(ctx, pk, S);
   toc(&tm.ms_witness_map);
-  if (prof) {
+  if (!fan) {
     run(0, pk->hA, Sd, pk->nz + 4, 0);
     run(1, pk->hB1, Sd, pk->nz + 4, 0);
     run(2, pk->hB2, Sd, pk->nz + 4, 0);
   }
   run(3, pk->hH, reinterpret_cast<const uint64_t*>(h), std::min(pk->N, bases_len(ctx, pk->hH)), 0);  // :186-187
   run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 0);                        // :189-190
-  if (!prof) {
+  if (fan) {
     for (int w = 1; w < zkp_ctx::N_WS; w++) {
       ZKP_HIP(hipEventRecord(ctx->cur->ws[w].done, ctx->cur->ws[w].stream));
       ZKP_HIP(hipStreamWaitEvent(st, ctx->cur->ws[w].done, 0));
@@ -354,7 +358,7 @@ static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, b
 
   tic();
   // proof layout (32-bit words): A = 2*fN1 | B = 2*fN2 | C = 2*fN1
-  if (prof) v1->assemble_g1_part1(st, res, slot, rs, proof_dev, flags_dev);
+  if (!fan) v1->assemble_g1_part1(st, res, slot, rs, proof_dev, flags_dev);
   v1->assemble_g1_part2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN + 2 * v2->fN);
   v2->assemble_g2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN);
   ZKP_HIP(hipGetLastError());
@@ -434,7 +438,7 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
   const size_t pw64 = (4 * (size_t)v1->fN + 2 * (size_t)v2->fN) / 2;
   const bool prof = ctx->profiling;
   size_t pending[zkp_ctx::N_LANES] = {};
-  static const int lanes_env = [] { const char* e = getenv("ZKP_LANES"); return e ? atoi(e) : 2; }();
+  static const int lanes_env = [] { const char* e = getenv("ZKP_LANES"); return e ? atoi(e) : 5; }();
   const int nl = std::max(1, std::min(lanes_env, (int)zkp_ctx::N_LANES));
   auto select = [&](int l) {
     ctx->cur = &ctx->lanes[l];
