@@ -185,9 +185,10 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d) {
     pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1);
     pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2);
     {
-      // measured: reusing B2's bucket sort for B1 removes 0.55 ms of (memory-bound) sort kernels per proof but the
-      // pipelined rate drops 84.7 -> 83.0 proofs/s (the sorts hide under VALU-bound kernels anyway) — opt-in only
-      static const bool on = getenv("ZKP_SHARE_B_SORT") && atoi(getenv("ZKP_SHARE_B_SORT")) != 0;
+      // B1 reuses B2's bucket sort + task schedule (same scalars, window configuration and identity pattern): -0.55 ms of
+      // memory-bound sort kernels per proof.  With 4 hardware queues this LOST 2 % (84.7 -> 83.0 proofs/s: the wait on
+      // B2's stream idled a queue); with 16 queues it gains 1-2 % (97.9 -> 99.3).  ZKP_SHARE_B_SORT=0 disables it.
+      static const bool on = !(getenv("ZKP_SHARE_B_SORT") && atoi(getenv("ZKP_SHARE_B_SORT")) == 0);
       const bool same_inf = (!d->b_g1_inf && !d->b_g2_inf) ||
                             (d->b_g1_inf && d->b_g2_inf && memcmp(d->b_g1_inf, d->b_g2_inf, d->b_g1_len) == 0);
       pk->share_b_sort = on && same_inf && bases_same_shape(ctx, pk->hB1, pk->hB2);

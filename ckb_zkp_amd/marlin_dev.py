@@ -39,10 +39,19 @@ class DeviceBackend:
         self.ctx, self.c = ctx, get_curve(curve)
         self.lib, self.h, self.cid = ctx.lib, ctx.h, self.c.cid
         self._live = []
+        # size-keyed free lists shared by every backend of this context: a proof allocates the same ~120 vectors every
+        # time, so after the first proof no hipMalloc / hipFree (each a device-wide synchronisation) is left in the path
+        if not hasattr(ctx, "_fr_pool"):
+            ctx._fr_pool = {}
+        self._pool = ctx._fr_pool
 
     # ---- memory
     def alloc(self, n: int) -> DVec:
-        v = DVec(self, self.ctx.dev_alloc(max(n, 1) * 32), n)
+        nbytes = max(n, 1) * 32
+        free = self._pool.get(nbytes)
+        ptr = free.pop() if free else self.ctx.dev_alloc(nbytes)
+        v = DVec(self, ptr, n)
+        v.nbytes = nbytes
         self._live.append(v)
         return v
 
@@ -66,7 +75,9 @@ class DeviceBackend:
 
     def upload_raw(self, a: np.ndarray) -> int:
         p = self.ctx.to_device(np.ascontiguousarray(a))
-        self._live.append(DVec(self, p, 0))
+        v = DVec(self, p, 0)
+        v.nbytes = None                                      # not pooled
+        self._live.append(v)
         return p
 
     def download(self, v: DVec) -> list:
@@ -91,11 +102,23 @@ class DeviceBackend:
         return out
 
     def release_all(self):
+        """hand every vector of this backend back to the context's pool (stream-ordered reuse: all work is enqueued on
+        the context's stream, so the next user of a buffer runs after its last reader)"""
         for v in self._live:
             if v.owner and v.ptr:
-                self.ctx.dev_free(v.ptr)
+                if getattr(v, "nbytes", None):
+                    self._pool.setdefault(v.nbytes, []).append(v.ptr)
+                else:
+                    self.ctx.dev_free(v.ptr)
                 v.ptr = 0
         self._live = []
+
+    @staticmethod
+    def trim_pool(ctx: Context):
+        for lst in getattr(ctx, "_fr_pool", {}).values():
+            for p in lst:
+                ctx.dev_free(p)
+        ctx._fr_pool = {}
 
     # ---- arithmetic
     def _k(self, k):
