@@ -328,10 +328,13 @@ static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, b
   if (fan) {
     ZKP_HIP(hipEventRecord(ctx->cur->ev_fork, st));                       // S is complete
     for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[w].stream, ctx->cur->ev_fork, 0));
-    // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H -> L | ws3: part 1 after A, B1
+    // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H | ws3: L, then part 1 after A, B1
+    // (4 lanes x 4 streams = 16 streams = one hardware queue each under GPU_MAX_HW_QUEUES=16)
     run(2, pk->hB2, Sd, pk->nz + 4, 2);                                            // prover.rs:182-184
     run(0, pk->hA, Sd, pk->nz + 4, 1);                                             // prover.rs:164-167
     run(1, pk->hB1, Sd, pk->nz + 4, 1, pk->share_b_sort ? 2 : -1);                 // prover.rs:170-177 (B2's bucket sort reused)
+    static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
+    if (l_own) run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 3);
     ZKP_HIP(hipEventRecord(ctx->cur->ev_b1, ctx->cur->ws[1].stream));
     // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~4 ms single-wave chain: start them as soon as
     // A and B1 exist so they hide under the remaining MSMs
@@ -347,7 +350,10 @@ static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, b
     run(2, pk->hB2, Sd, pk->nz + 4, 0);
   }
   run(3, pk->hH, reinterpret_cast<const uint64_t*>(h), std::min(pk->N, bases_len(ctx, pk->hH)), 0);  // :186-187
-  run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 0);                        // :189-190
+  {
+    static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
+    if (!(fan && l_own)) run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 0);               // :189-190
+  }
   if (fan) {
     for (int w = 1; w < zkp_ctx::N_WS; w++) {
       ZKP_HIP(hipEventRecord(ctx->cur->ws[w].done, ctx->cur->ws[w].stream));
@@ -439,7 +445,7 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
   const size_t pw64 = (4 * (size_t)v1->fN + 2 * (size_t)v2->fN) / 2;
   const bool prof = ctx->profiling;
   size_t pending[zkp_ctx::N_LANES] = {};
-  static const int lanes_env = [] { const char* e = getenv("ZKP_LANES"); return e ? atoi(e) : 5; }();
+  static const int lanes_env = [] { const char* e = getenv("ZKP_LANES"); return e ? atoi(e) : 4; }();
   const int nl = std::max(1, std::min(lanes_env, (int)zkp_ctx::N_LANES));
   auto select = [&](int l) {
     ctx->cur = &ctx->lanes[l];
