@@ -135,3 +135,45 @@ def test_batch_prove_equals_sequential(ctx):
             ctx.dev_free(d)
     finally:
         pk.free()
+
+
+@pytest.mark.parametrize("curve,k", [("bn254", 20), ("bls12_381", 20)])
+def test_full_size_proof_trapdoor_and_pipeline(ctx, curve, k):
+    """BASELINE.json configs[1] at FULL size (1 048 570 constraints, domain 2^20, BN254) and the same instance over
+    BLS12-381: the device proof equals the proof computed in the exponent from the toxic waste (size-independent check,
+    SURVEY §8(c).3), and the pipelined batch path (several proofs in flight on the context's lanes) returns the same
+    proof as the blocking call."""
+    from ckb_zkp_amd.circuits import samples_for_domain
+    from oracle.pyref.curves import Group
+    inst = mimc_chain_instance(curve, samples_for_domain(k))
+    params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    pk = groth16.ProvingKey(ctx, params, inst)
+    try:
+        assert pk.domain_size == 1 << k
+        c = params.curve
+        z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+        h = codec.fr_from_mont(pk.witness_map(z), c)
+        assert h[-1] == 0
+        r_, s_ = 0x1F2E3D4C5B6A7988, 0x8899AABBCCDDEEFF
+        rm, sm = codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0]
+        out, inf = pk.prove_raw(z, rm, sm)
+        proof = pk.decode_proof(out, inf)
+        t, r, ni = params.toxic, c.r, inst.num_inputs
+        A = (t["alpha"] + sum(zi * ai for zi, ai in zip(inst.z, t["a"])) + r_ * t["delta"]) % r
+        B = (t["beta"] + sum(zi * bi for zi, bi in zip(inst.z, t["b"])) + s_ * t["delta"]) % r
+        L = sum(zi * li for zi, li in zip(inst.z[ni:], t["l"][ni:])) % r
+        H = sum(hi * qi for hi, qi in zip(h, t["h"])) % r
+        Cc = (s_ * A + r_ * B - r_ * s_ % r * t["delta"] + L + H) % r
+        G1, G2 = Group(OC[curve], 1), Group(OC[curve], 2)
+        assert proof.a == G1.mul(G1.gen, A)
+        assert proof.b == G2.mul(G2.gen, B)
+        assert proof.c == G1.mul(G1.gen, Cc)
+        # 7 proofs through the lanes, same (r, s): every one must be bit-identical to the blocking result
+        zd = ctx.to_device(z)
+        import numpy as np
+        outs, infs = pk.prove_batch_raw([zd] * 7, np.stack([rm] * 7), np.stack([sm] * 7))
+        for i in range(7):
+            assert np.array_equal(outs[i], out) and np.array_equal(infs[i], inf), i
+        ctx.dev_free(zd)
+    finally:
+        pk.free()
