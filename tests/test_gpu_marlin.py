@@ -191,3 +191,38 @@ def test_device_index_from_arrays_matches_host_index(ctx, curve, samples, swap):
     finally:
         ck.powers_of_g.free()
         ck.powers_of_gamma_g.free()
+
+
+def test_marlin_config4_full_size_verifies(ctx):
+    """BASELINE.json configs[3] at full size (|H| = 2^20, |K| = 2^21, |B| = 2^23, SRS degree 6.29 M): the device-resident
+    prover's proof passes the reference's verifier (AHP equality checks + KZG10 pairing checks, lib.rs:184-250) against
+    index commitments computed on the device, and a tampered evaluation is rejected — the size-independent acceptance
+    test the reference itself uses (marlin/tests/mini.rs:81-87)."""
+    from ckb_zkp_amd import codec, marlin_dev
+    from ckb_zkp_amd.circuits import mimc_chain_instance
+    from oracle.pyref.curves import Group
+    from oracle.pyref.ntt import Domain
+    curve = "bn254"
+    c = get_curve(curve)
+    inst = mimc_chain_instance(curve, 87381, seed=0x4D41)
+    didx = marlin_dev.DeviceIndex.from_instance(ctx, inst)
+    assert (didx.hs, didx.ks, didx.bs) == (1 << 20, 1 << 21, 1 << 23)
+    beta_srs = 0x0F1E2D3C4B5A69788796A5B4C3D2E1F0
+    ck = kzg10.setup(ctx, curve, didx.max_degree, beta_srs)
+    try:
+        rnd = random.Random(44)
+        R, ch = _rand_inputs(c, 1, seed=45)
+        R["mask"] = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(3 * didx.hs)], c).reshape(-1, 4)
+        proof = marlin_dev.create_proof(ctx, didx, ck, (inst.z[:1], inst.z[1:]), R, ch)
+        oc = OC[curve]
+        G1, G2 = Group(oc, 1), Group(oc, 2)
+        pp = dict(curve=oc, g=G1.gen, gamma_g=G1.mul(G1.gen, 7), h=G2.gen, beta_h=G2.mul(G2.gen, beta_srs))
+        oidx = dict(curve=oc, dh=Domain(oc, didx.hs), dk=Domain(oc, didx.ks), max_degree=didx.max_degree)
+        ic = didx.commit_index(ctx, ck)
+        assert om.verify_proof(oidx, pp, ic, proof, [], ch)
+        bad = dict(proof, evaluations=proof["evaluations"][:3] + [(proof["evaluations"][3] + 1) % c.r] + proof["evaluations"][4:])
+        assert not om.verify_proof(oidx, pp, ic, bad, [], ch)
+    finally:
+        ck.powers_of_g.free()
+        ck.powers_of_gamma_g.free()
+        marlin_dev.DeviceBackend.trim_pool(ctx)
