@@ -1,0 +1,289 @@
+"""ark-serialize 0.2 wire format for the objects that cross the prover boundary on disk / on the wire
+(SURVEY.md §8(f)-1): `Proof`, `VerifyKey`, `Parameters` of zkp-groth16 (derives at /root/reference/groth16/src/lib.rs:51,
+59,81; written by cli/src/setup.rs:41-45,76-83 and cli/src/zkp_prove.rs:45-49,116-124) and the KZG10 commitments of
+zkp-marlin.
+
+Layout (arkworks `CanonicalSerialize`, compressed form — the default `serialize`):
+  * prime-field element: the canonical (non-Montgomery) integer, little-endian, ceil(bits/8) bytes (32 for both Fr and
+    BN254 Fq, 48 for BLS12-381 Fq);
+  * Fq2: c0 then c1;
+  * short-Weierstrass affine point: x only, with two flag bits in the top of the LAST byte: bit 7 = "y is the larger of
+    {y, -y}" (Fq: as integers; Fq2: compare c1 first, then c0), bit 6 = point at infinity (x = 0);
+  * uncompressed form: x, then y, the infinity flag on y's last byte;
+  * `Vec<T>`: u64 little-endian length, then the elements; structs: their fields in declaration order.
+
+PARITY UNPINNED: the reference holds no serialized fixture and ark-serialize is not vendored (Cargo dependency "0.2"),
+so this layout is restated from the published arkworks 0.2 sources and checked here by round trips, by the curve
+equation on decompression and by the y-ordering rule; confirm against real `.pk` / proof bytes when a Rust toolchain
+exists.
+"""
+from __future__ import annotations
+
+import struct
+
+from .params import CurveParams, get_curve
+
+FLAG_POSITIVE_Y = 1 << 7
+FLAG_INFINITY = 1 << 6
+
+
+class SerializationError(Exception):
+    """ark_serialize::SerializationError (InvalidData / UnexpectedFlags / NotEnoughSpace)"""
+
+
+# ------------------------------------------------------------------ field helpers (host-side big integers)
+def _fq_bytes(c: CurveParams) -> int:
+    return (c.q.bit_length() + 2 + 7) // 8          # modulus bits + 2 flag bits
+
+
+def _fr_bytes(c: CurveParams) -> int:
+    return (c.r.bit_length() + 7) // 8
+
+
+def _sqrt_fq(a: int, q: int):
+    """q = 3 mod 4 for both base fields"""
+    a %= q
+    if a == 0:
+        return 0
+    s = pow(a, (q + 1) // 4, q)
+    return s if s * s % q == a else None
+
+
+def _fq2_mul(a, b, q):
+    return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+
+
+def _sqrt_fq2(a, q):
+    """square root in Fq[u]/(u^2 + 1) by the norm method"""
+    a0, a1 = a[0] % q, a[1] % q
+    if a1 == 0:
+        s = _sqrt_fq(a0, q)
+        if s is not None:
+            return (s, 0)
+        s = _sqrt_fq(-a0, q)                         # a0 = -(s^2) = (s u)^2
+        return None if s is None else (0, s)
+    n = _sqrt_fq(a0 * a0 + a1 * a1, q)               # norm
+    if n is None:
+        return None
+    inv2 = pow(2, -1, q)
+    for sign in (1, -1):
+        x2 = (a0 + sign * n) * inv2 % q
+        x = _sqrt_fq(x2, q)
+        if x is not None and x != 0:
+            y = a1 * pow(2 * x, -1, q) % q
+            if _fq2_mul((x, y), (x, y), q) == (a0, a1):
+                return (x, y)
+    return None
+
+
+def _g2_b(c: CurveParams):
+    """twist coefficient: BN254 3/(9+u), BLS12-381 4(1+u)"""
+    q = c.q
+    if c.name == "bn254":
+        d = pow(9 * 9 + 1, -1, q)                    # 1/(9+u) = (9-u)/82
+        return (3 * 9 * d % q, (-3 * d) % q)
+    return (4, 4)
+
+
+def _g1_b(c: CurveParams) -> int:
+    return 3 if c.name == "bn254" else 4
+
+
+# ------------------------------------------------------------------ elements
+def fr_to_bytes(x: int, curve) -> bytes:
+    c = get_curve(curve)
+    return (x % c.r).to_bytes(_fr_bytes(c), "little")
+
+
+def fr_from_bytes(b: bytes, curve) -> int:
+    c = get_curve(curve)
+    if len(b) != _fr_bytes(c):
+        raise SerializationError("NotEnoughSpace")
+    x = int.from_bytes(b, "little")
+    if x >= c.r:
+        raise SerializationError("InvalidData")
+    return x
+
+
+def _y_is_positive_g1(y: int, q: int) -> bool:
+    return y > (q - y) % q
+
+
+def _y_is_positive_g2(y, q: int) -> bool:
+    ny = ((q - y[0]) % q, (q - y[1]) % q)
+    return (y[1], y[0]) > (ny[1], ny[0])             # QuadExtField Ord: c1 first, then c0
+
+
+def g1_to_bytes(p, curve, compressed: bool = True) -> bytes:
+    c = get_curve(curve)
+    n = _fq_bytes(c)
+    if p is None:
+        out = bytearray(n if compressed else 2 * n)
+        out[-1] |= FLAG_INFINITY
+        return bytes(out)
+    x, y = p
+    if compressed:
+        out = bytearray(x.to_bytes(n, "little"))
+        if _y_is_positive_g1(y, c.q):
+            out[-1] |= FLAG_POSITIVE_Y
+        return bytes(out)
+    return x.to_bytes(n, "little") + y.to_bytes(n, "little")
+
+
+def g1_from_bytes(b: bytes, curve, compressed: bool = True):
+    c = get_curve(curve)
+    n, q = _fq_bytes(c), c.q
+    if len(b) != (n if compressed else 2 * n):
+        raise SerializationError("NotEnoughSpace")
+    flags = b[-1] & (FLAG_POSITIVE_Y | FLAG_INFINITY)
+    if flags == (FLAG_POSITIVE_Y | FLAG_INFINITY):
+        raise SerializationError("UnexpectedFlags")
+    body = bytearray(b)
+    body[-1] &= 0x3F
+    if flags & FLAG_INFINITY:
+        return None
+    if compressed:
+        x = int.from_bytes(body, "little")
+        if x >= q:
+            raise SerializationError("InvalidData")
+        y = _sqrt_fq(x * x * x + _g1_b(c), q)
+        if y is None:
+            raise SerializationError("InvalidData")
+        if _y_is_positive_g1(y, q) != bool(flags & FLAG_POSITIVE_Y):
+            y = (q - y) % q
+        return (x, y)
+    x, y = int.from_bytes(body[:n], "little"), int.from_bytes(body[n:], "little")
+    if x >= q or y >= q or (y * y - x * x * x - _g1_b(c)) % q:
+        raise SerializationError("InvalidData")
+    return (x, y)
+
+
+def g2_to_bytes(p, curve, compressed: bool = True) -> bytes:
+    c = get_curve(curve)
+    n = _fq_bytes(c)
+    if p is None:
+        out = bytearray(2 * n if compressed else 4 * n)
+        out[-1] |= FLAG_INFINITY
+        return bytes(out)
+    (x0, x1), (y0, y1) = p
+    if compressed:
+        out = bytearray(x0.to_bytes(n, "little") + x1.to_bytes(n, "little"))
+        if _y_is_positive_g2((y0, y1), c.q):
+            out[-1] |= FLAG_POSITIVE_Y
+        return bytes(out)
+    return b"".join(v.to_bytes(n, "little") for v in (x0, x1, y0, y1))
+
+
+def g2_from_bytes(b: bytes, curve, compressed: bool = True):
+    c = get_curve(curve)
+    n, q = _fq_bytes(c), c.q
+    if len(b) != (2 * n if compressed else 4 * n):
+        raise SerializationError("NotEnoughSpace")
+    flags = b[-1] & (FLAG_POSITIVE_Y | FLAG_INFINITY)
+    if flags == (FLAG_POSITIVE_Y | FLAG_INFINITY):
+        raise SerializationError("UnexpectedFlags")
+    body = bytearray(b)
+    body[-1] &= 0x3F
+    if flags & FLAG_INFINITY:
+        return None
+    vals = [int.from_bytes(body[i * n:(i + 1) * n], "little") for i in range(len(body) // n)]
+    if any(v >= q for v in vals):
+        raise SerializationError("InvalidData")
+    x = (vals[0], vals[1])
+    x3 = _fq2_mul(_fq2_mul(x, x, q), x, q)
+    bb = _g2_b(c)
+    rhs = ((x3[0] + bb[0]) % q, (x3[1] + bb[1]) % q)
+    if compressed:
+        y = _sqrt_fq2(rhs, q)
+        if y is None:
+            raise SerializationError("InvalidData")
+        if _y_is_positive_g2(y, q) != bool(flags & FLAG_POSITIVE_Y):
+            y = ((q - y[0]) % q, (q - y[1]) % q)
+        return (x, y)
+    y = (vals[2], vals[3])
+    if _fq2_mul(y, y, q) != rhs:
+        raise SerializationError("InvalidData")
+    return (x, y)
+
+
+# ------------------------------------------------------------------ containers
+class _Reader:
+    def __init__(self, b: bytes):
+        self.b, self.o = memoryview(b), 0
+
+    def take(self, n: int) -> bytes:
+        if self.o + n > len(self.b):
+            raise SerializationError("NotEnoughSpace")
+        out = bytes(self.b[self.o:self.o + n])
+        self.o += n
+        return out
+
+    def u64(self) -> int:
+        return struct.unpack("<Q", self.take(8))[0]
+
+
+def _vec(items, enc) -> bytes:
+    return struct.pack("<Q", len(items)) + b"".join(enc(x) for x in items)
+
+
+def proof_to_bytes(proof, curve) -> bytes:
+    """Proof { a: G1Affine, b: G2Affine, c: G1Affine }  (groth16/src/lib.rs:51-56): 128 B on BN254, 192 B on BLS12-381"""
+    return g1_to_bytes(proof.a, curve) + g2_to_bytes(proof.b, curve) + g1_to_bytes(proof.c, curve)
+
+
+def proof_from_bytes(b: bytes, curve):
+    from .groth16 import Proof
+    c = get_curve(curve)
+    n = _fq_bytes(c)
+    if len(b) != 4 * n:
+        raise SerializationError("NotEnoughSpace")
+    return Proof(g1_from_bytes(b[:n], c), g2_from_bytes(b[n:3 * n], c), g1_from_bytes(b[3 * n:], c))
+
+
+def verify_key_to_bytes(alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, curve) -> bytes:
+    """VerifyKey { alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1: Vec<G1Affine> }  (lib.rs:59-66)"""
+    return (g1_to_bytes(alpha_g1, curve) + g2_to_bytes(beta_g2, curve) + g2_to_bytes(gamma_g2, curve) +
+            g2_to_bytes(delta_g2, curve) + _vec(gamma_abc_g1, lambda p: g1_to_bytes(p, curve)))
+
+
+def _read_verify_key(r: _Reader, c: CurveParams) -> dict:
+    n = _fq_bytes(c)
+    vk = dict(alpha_g1=g1_from_bytes(r.take(n), c), beta_g2=g2_from_bytes(r.take(2 * n), c),
+              gamma_g2=g2_from_bytes(r.take(2 * n), c), delta_g2=g2_from_bytes(r.take(2 * n), c))
+    vk["gamma_abc_g1"] = [g1_from_bytes(r.take(n), c) for _ in range(r.u64())]
+    return vk
+
+
+def verify_key_from_bytes(b: bytes, curve) -> dict:
+    r = _Reader(b)
+    vk = _read_verify_key(r, get_curve(curve))
+    if r.o != len(b):
+        raise SerializationError("InvalidData")
+    return vk
+
+
+def parameters_to_bytes(p: dict, curve) -> bytes:
+    """Parameters { vk, beta_g1, delta_g1, a_query, b_g1_query, b_g2_query, h_query, l_query }  (lib.rs:81-91).
+    p: dict of canonical points (None = infinity) with the reference's field names; `vk` a dict as above."""
+    g1 = lambda q: g1_to_bytes(q, curve)
+    g2 = lambda q: g2_to_bytes(q, curve)
+    vk = p["vk"]
+    return (verify_key_to_bytes(vk["alpha_g1"], vk["beta_g2"], vk["gamma_g2"], vk["delta_g2"], vk["gamma_abc_g1"], curve) +
+            g1(p["beta_g1"]) + g1(p["delta_g1"]) + _vec(p["a_query"], g1) + _vec(p["b_g1_query"], g1) +
+            _vec(p["b_g2_query"], g2) + _vec(p["h_query"], g1) + _vec(p["l_query"], g1))
+
+
+def parameters_from_bytes(b: bytes, curve) -> dict:
+    c = get_curve(curve)
+    n = _fq_bytes(c)
+    r = _Reader(b)
+    out = dict(vk=_read_verify_key(r, c))
+    out["beta_g1"] = g1_from_bytes(r.take(n), c)
+    out["delta_g1"] = g1_from_bytes(r.take(n), c)
+    for name, size, dec in (("a_query", n, g1_from_bytes), ("b_g1_query", n, g1_from_bytes),
+                            ("b_g2_query", 2 * n, g2_from_bytes), ("h_query", n, g1_from_bytes),
+                            ("l_query", n, g1_from_bytes)):
+        out[name] = [dec(r.take(size), c) for _ in range(r.u64())]
+    if r.o != len(b):
+        raise SerializationError("InvalidData")
+    return out

@@ -1,0 +1,92 @@
+"""CPU: ark-serialize 0.2 layout of proofs / keys (ckb_zkp_amd/serialize.py) — round trips, decompression against the
+curve equation, the y-ordering flag, infinity, Vec length prefixes and error cases.  (The byte layout itself is restated
+from arkworks 0.2 — the reference holds no serialized fixture: parity unpinned, see the module docstring.)"""
+import random
+
+import pytest
+
+from ckb_zkp_amd import serialize as ser
+from ckb_zkp_amd.groth16 import Proof
+from ckb_zkp_amd.params import get_curve
+from oracle.pyref.curves import Group
+from tests.util import OC
+
+
+def _pts(curve, group, n, seed):
+    G = Group(OC[curve], group)
+    rnd = random.Random(seed)
+    return [G.mul(G.gen, rnd.randrange(1, OC[curve].r)) for _ in range(n)]
+
+
+def test_twist_constant_bn254():
+    assert ser._g2_b(get_curve("bn254")) == (
+        19485874751759354771024239261021720505790618469301721065564631296452457478373,
+        266929791119991161246907387137283842545076965332900288569378510910307636690)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_point_round_trips_and_flags(curve):
+    c = get_curve(curve)
+    n = 32 if curve == "bn254" else 48
+    for p in _pts(curve, 1, 12, 1) + [c.g1, None]:
+        for comp in (True, False):
+            b = ser.g1_to_bytes(p, curve, comp)
+            assert len(b) == (n if comp else 2 * n)
+            assert ser.g1_from_bytes(b, curve, comp) == p
+        b = ser.g1_to_bytes(p, curve)
+        if p is None:
+            assert b[-1] == ser.FLAG_INFINITY and not any(b[:-1])
+        else:
+            assert bool(b[-1] & ser.FLAG_POSITIVE_Y) == (p[1] > c.q - p[1])
+            neg = (p[0], c.q - p[1])
+            bn = ser.g1_to_bytes(neg, curve)
+            assert bn[:-1] == b[:-1] and (bn[-1] ^ b[-1]) == ser.FLAG_POSITIVE_Y     # same x, opposite sign flag
+            assert ser.g1_from_bytes(bn, curve) == neg
+    for p in _pts(curve, 2, 8, 2) + [c.g2, None]:
+        for comp in (True, False):
+            b = ser.g2_to_bytes(p, curve, comp)
+            assert len(b) == (2 * n if comp else 4 * n)
+            assert ser.g2_from_bytes(b, curve, comp) == p
+        if p is not None:
+            (x, (y0, y1)) = p
+            neg = (x, ((c.q - y0) % c.q, (c.q - y1) % c.q))
+            b, bn = ser.g2_to_bytes(p, curve), ser.g2_to_bytes(neg, curve)
+            assert (bn[-1] ^ b[-1]) == ser.FLAG_POSITIVE_Y and ser.g2_from_bytes(bn, curve) == neg
+            positive = (y1, y0) > ((c.q - y1) % c.q, (c.q - y0) % c.q)               # c1 is the most significant part
+            assert bool(b[-1] & ser.FLAG_POSITIVE_Y) == positive
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_proof_and_parameters_round_trip(curve):
+    a, cc = _pts(curve, 1, 2, 3)
+    b = _pts(curve, 2, 1, 4)[0]
+    pr = Proof(a, b, cc)
+    raw = ser.proof_to_bytes(pr, curve)
+    assert len(raw) == (128 if curve == "bn254" else 192)
+    assert ser.proof_from_bytes(raw, curve) == pr
+    g1, g2 = _pts(curve, 1, 20, 5), _pts(curve, 2, 8, 6)
+    params = dict(vk=dict(alpha_g1=g1[0], beta_g2=g2[0], gamma_g2=g2[1], delta_g2=g2[2], gamma_abc_g1=g1[1:3]),
+                  beta_g1=g1[3], delta_g1=g1[4], a_query=g1[5:9] + [None], b_g1_query=[None] + g1[9:11],
+                  b_g2_query=[None] + g2[3:6], h_query=g1[11:15], l_query=g1[15:18])
+    raw = ser.parameters_to_bytes(params, curve)
+    assert ser.parameters_from_bytes(raw, curve) == params
+    vk = ser.verify_key_to_bytes(**params["vk"], curve=curve)
+    assert raw.startswith(vk) and ser.verify_key_from_bytes(vk, curve) == params["vk"]
+    n = 32 if curve == "bn254" else 48
+    assert raw[7 * n:7 * n + 8] == (2).to_bytes(8, "little")                       # Vec<G1Affine> length prefix
+
+
+def test_rejects_bad_encodings():
+    c = get_curve("bn254")
+    with pytest.raises(ser.SerializationError):
+        ser.g1_from_bytes(b"\x00" * 31, "bn254")
+    bad = bytearray(ser.g1_to_bytes(c.g1, "bn254"))
+    bad[-1] |= ser.FLAG_INFINITY | ser.FLAG_POSITIVE_Y
+    with pytest.raises(ser.SerializationError):
+        ser.g1_from_bytes(bytes(bad), "bn254")
+    with pytest.raises(ser.SerializationError):                                     # x = 4: 4^3 + 3 = 67 is not a square mod q?
+        x = next(v for v in range(2, 50) if ser._sqrt_fq(v ** 3 + 3, c.q) is None)
+        ser.g1_from_bytes(x.to_bytes(32, "little"), "bn254")
+    with pytest.raises(ser.SerializationError):
+        ser.fr_from_bytes(c.r.to_bytes(32, "little"), "bn254")
+    assert ser.fr_from_bytes(ser.fr_to_bytes(c.r - 1, "bn254"), "bn254") == c.r - 1
