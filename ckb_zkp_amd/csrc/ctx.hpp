@@ -93,7 +93,7 @@ struct MsmWorkspace {
   bool own_stream = false;
   hipEvent_t done = nullptr;
   hipEvent_t sorted = nullptr;     // recorded when the bucket sort + task schedule of the current MSM are complete
-  DevBuf keys, vals, keys2, vals2, sort_tmp, offsets, buckets, tmp, out, sched, scan_tmp, scan_tmp2, partial;
+  DevBuf keys, vals, keys2, vals2, sort_tmp, offsets, buckets, tmp, out, sched, scan_tmp, scan_tmp2, partial, redo;
 };
 struct Groth16Timing {
   zkp_groth16_timing t{};

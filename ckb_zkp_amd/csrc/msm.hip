@@ -610,7 +610,7 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     const bool timed = ms_accumulate && ctx->profiling;
     if (timed) ZKP_HIP(hipEventRecord(ctx->ev2, st));
     vt->accumulate(st, be->table, sorted_vals, order, task_start, task_len, task_dst, toff + nb, max_tasks, buckets,
-                   task_partial);
+                   task_partial, ws.redo.as<uint32_t>((size_t)max_tasks + 1));
     if (timed) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
       ZKP_HIP(hipEventSynchronize(ctx->ev3));

@@ -11,6 +11,7 @@
 
 #include "ec.cuh"
 #include "msm_vtbl.hpp"
+#include "unsat.cuh"
 
 namespace zkp {
 
@@ -41,12 +42,35 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
                                                          const uint32_t* __restrict__ task_len,
                                                          const uint32_t* __restrict__ task_dst,
                                                          const uint32_t* __restrict__ n_tasks_dev,
-                                                         char* __restrict__ buckets, char* __restrict__ partial, uint32_t idx_mask) {
+                                                         char* __restrict__ buckets, char* __restrict__ partial, uint32_t idx_mask,
+                                                         uint32_t* __restrict__ redo) {
   using F = CfgF;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *n_tasks_dev) return;
   const uint32_t id = order[t];
   const uint32_t e0 = task_start[id], e1 = e0 + task_len[id];
+  const uint32_t d = task_dst[id];
+  char* out = (d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * XYZZ<F>::BYTES : buckets + (size_t)d * XYZZ<F>::BYTES;
+#if ZKP_CFG_GROUP == 1 && defined(ZKP_ACC_UNSAT)
+  // G1: accumulate on unsaturated limbs (unsat.cuh); the window table and the buckets keep the saturated layout
+  XYZZu<CfgFq> acc;
+  acc.inf = true;
+  for (uint32_t e = e0; e < e1; e++) {
+    uint32_t v = vals[e];
+    Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
+    if (p.is_inf()) continue;
+    if (v >> 31) p.y = p.y.neg();
+    const Fu<CfgFq> ux = Fu<CfgFq>::from_sat(p.x), uy = Fu<CfgFq>::from_sat(p.y);
+    if (!xyzz_madd_u<CfgFq>(acc, ux, uy)) {
+      // the operand may equal +-accumulator (doubling / cancellation; 9 * 2^-29 false alarms): leave the whole task to
+      // the exact kernel below instead of carrying the exceptional formulas through the hot loop's register budget
+      redo[1 + atomicAdd(redo, 1u)] = id;
+      return;
+    }
+  }
+  if (acc.inf) XYZZ<F>::inf().store(out);
+  else XYZZ<F>{acc.x.to_sat(), acc.y.to_sat(), acc.zz.to_sat(), acc.zzz.to_sat()}.store(out);
+#else
   XYZZ<F> acc = XYZZ<F>::inf();
   // (a software-pipelined gather of entry e+1 was tried: +20 VGPRs -> scratch spills, no gain; 3 waves/SIMD
   //  already cover the gather latency)
@@ -56,9 +80,31 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
     if (v >> 31) p.y = p.y.neg();
     acc.madd(p);
   }
-  const uint32_t d = task_dst[id];
-  char* out = (d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * XYZZ<F>::BYTES : buckets + (size_t)d * XYZZ<F>::BYTES;
   acc.store(out);
+#endif
+}
+// exact (saturated, all exceptional cases) accumulation of the tasks listed in redo[1 .. redo[0]]
+__global__ __launch_bounds__(64) void accumulate_redo_kernel(const char* __restrict__ table, const uint32_t* __restrict__ vals,
+                                                            const uint32_t* __restrict__ task_start,
+                                                            const uint32_t* __restrict__ task_len,
+                                                            const uint32_t* __restrict__ task_dst, char* __restrict__ buckets,
+                                                            char* __restrict__ partial, uint32_t idx_mask,
+                                                            const uint32_t* __restrict__ redo) {
+  using F = CfgF;
+  const uint32_t count = redo[0];
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+    const uint32_t id = redo[1 + k];
+    const uint32_t e0 = task_start[id], e1 = e0 + task_len[id];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t e = e0; e < e1; e++) {
+      uint32_t v = vals[e];
+      Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
+      if (v >> 31) p.y = p.y.neg();
+      acc.madd(p);
+    }
+    const uint32_t d = task_dst[id];
+    acc.store((d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * XYZZ<F>::BYTES : buckets + (size_t)d * XYZZ<F>::BYTES);
+  }
 }
 }  // namespace ZKP_CFG_SYM(cfg)
 
@@ -68,21 +114,30 @@ static uint32_t dbg_mask() {   // ZKP_DEBUG_GATHER_MASK=0xffff: wrong results, c
 }
 void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint32_t* order,
                                         const uint32_t* task_start, const uint32_t* task_len, const uint32_t* task_dst,
-                                        const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial) {
+                                        const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial,
+                                        uint32_t* redo) {
   // G2: 1 wave/SIMD (VGPRs + AGPRs as spill space, default) vs 2 waves/SIMD (256 VGPRs + 704 B scratch): the latter makes
   // the kernel itself 7 % faster but the whole proof 8 % slower (it starves the concurrent streams) — ZKP_G2_ACC_OCC=1|2
   static const unsigned lds = [] { const char* e = getenv("ZKP_ACC_LDS_BYTES"); return e ? (unsigned)atoi(e) : 0u; }();
   static const int occ = [] { const char* e = getenv("ZKP_G2_ACC_OCC"); return e ? atoi(e) : 1; }();
   static const int occ1 = [] { const char* e = getenv("ZKP_G1_ACC_OCC"); return e ? atoi(e) : 3; }();
+#if ZKP_CFG_GROUP == 1 && defined(ZKP_ACC_UNSAT)
+  (void)hipMemsetAsync(redo, 0, sizeof(uint32_t), s);
+  hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
+                     task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
+  hipLaunchKernelGGL(accumulate_redo_kernel, dim3(64), dim3(64), 0, s, table, vals, task_start, task_len, task_dst, buckets,
+                     partial, dbg_mask(), redo);
+  return;
+#endif
   if (ZKP_CFG_GROUP == 1 && occ1 == 4)
     hipLaunchKernelGGL(accumulate_kernel<4>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
-                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
+                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
   else if (ZKP_CFG_GROUP == 2 && occ == 2)
     hipLaunchKernelGGL(accumulate_kernel<2>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
-                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
+                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
   else
     hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
-                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask());
+                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
 }
 
 }  // namespace zkp

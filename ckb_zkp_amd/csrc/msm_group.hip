@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void assemble_g2_kernel(const char* __restrict_
 // ------------------------------------------------------------------------------------------- launch table
 void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t, const char*, const uint32_t*, const uint32_t*, const uint32_t*,
                                         const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*,
-                                        char*);   // msm_acc.hip
+                                        char*, uint32_t*);   // msm_acc.hip
 
 namespace {
 using F = CfgF;

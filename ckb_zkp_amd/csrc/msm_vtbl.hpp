@@ -28,7 +28,9 @@ struct MsmVtbl {
   // dst < 0x80000000: bucket index (single-task bucket), else partial slot (dst & 0x7fffffff)
   void (*accumulate)(hipStream_t, const char* table, const uint32_t* vals, const uint32_t* order,
                      const uint32_t* task_start, const uint32_t* task_len, const uint32_t* task_dst,
-                     const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial);
+                     const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial, uint32_t* redo);
+  // redo: max_tasks + 1 words of scratch ([0] = count, zeroed by the launcher): tasks the fast path abandoned because an
+  // operand might equal +-accumulator are listed there and redone by an exact second kernel
   // one wave per multi-task bucket: buckets[b] = sum of its partials
   void (*combine)(hipStream_t, const uint32_t* long_list, const uint32_t* n_long_dev, const uint32_t* toff,
                   const char* partial, char* buckets);

@@ -1,10 +1,4 @@
-// EXPERIMENT (not built into the library): unsaturated-limb field arithmetic for the bucket-accumulation kernel.
-// Result on MI355X: the multiplier alone is 1.26-1.5x faster (tools/ubench/unsat.hip: 160 vs 107-128 G products/s),
-// but the complete mixed addition below — normalising subtractions (4 VALU per limb instead of 3), limb conversions of
-// every gathered point, 174 VGPRs (2 waves/SIMD instead of 3) and the accumulator forced into scratch by the
-// out-of-line exceptional path — made the accumulate kernel 20 % SLOWER (2.58 -> 3.07 ms for the 1.26 M-point A query;
-// results bit-identical, all MSM / Groth16 parity tests green).  Kept as a record of the attempt; see DESIGN.md.
-//
+// Unsaturated-limb field arithmetic for the bucket-accumulation kernel (the hot loop of the whole prover).
 //
 // field.cuh multiplies on saturated 32-bit limbs: every 32x32 partial product is a v_mad_u64_u32 PLUS a v_addc_co_u32
 // that banks the carry, and every column of the product scan costs two v_mov.  Here a field element is L limbs of B bits
@@ -178,6 +172,8 @@ struct Fu {
     r.v[L - 1] = (uint32_t)acc;
     return r;
   }
+  // (a dedicated squaring — cross terms once against a doubled operand, 45 instead of 81 products — measured no
+  //  difference in the accumulate kernel and was dropped)
   ZKP_DEV Fu sqr() const { return mul(*this, *this); }
 
   // a - b + M*p with normalised limbs; requires b < M*p (value) — result in (0, a + M*p)
@@ -230,42 +226,25 @@ struct XYZZu {
   bool inf;
 };
 
-// exceptional cases (operand equal to +-accumulator: one in 2^29 false alarms plus the real ones): exact arithmetic on
-// the saturated path
+// acc += P where (ux, uy) = from_sat of a gathered affine point (not the identity) — madd-2008-s (8M + 2S) with hand-tracked
+// bounds.  Returns false WITHOUT touching acc when P may equal +-acc (the difference of the x coordinates has the low
+// limb of a multiple of p): the caller hands the bucket to the exact saturated path.
 template <class P>
-__device__ __noinline__ void xyzz_madd_u_slow(XYZZu<P>* acc, const Fp<P>* px, const Fp<P>* py) {
-  using F = Fp<P>;
-  XYZZ<F> a{acc->x.to_sat(), acc->y.to_sat(), acc->zz.to_sat(), acc->zzz.to_sat()};
-  a.madd(Affine<F>{*px, *py});
-  acc->inf = a.is_inf();
-  acc->x = Fu<P>::from_sat_reduced(a.x);
-  acc->y = Fu<P>::from_sat_reduced(a.y);
-  acc->zz = Fu<P>::from_sat_reduced(a.zz);
-  acc->zzz = Fu<P>::from_sat_reduced(a.zzz);
-}
-
-// acc += (px, py)  — madd-2008-s (8M + 2S) with hand-tracked bounds; px, py canonical saturated Montgomery, not the
-// identity
-template <class P>
-ZKP_DEV void xyzz_madd_u(XYZZu<P>& acc, const Fp<P>& px, const Fp<P>& py) {
+ZKP_DEV bool xyzz_madd_u(XYZZu<P>& acc, const Fu<P>& ux, const Fu<P>& uy) {
   using U = Fu<P>;
-  const U ux = U::from_sat(px), uy = U::from_sat(py);      // < 2^SHIFT * p as integers; fine as ONE mul operand
   if (acc.inf) {
     acc.x = U::mul(ux, U::one());                          // < 2p
     acc.y = U::mul(uy, U::one());
     acc.zz = U::one();
     acc.zzz = U::one();
     acc.inf = false;
-    return;
+    return true;
   }
   U u2 = U::mul(ux, acc.zz);                               // < 2p
   U s2 = U::mul(uy, acc.zzz);                              // < 2p
   U pd = U::template sub<8>(u2, acc.x);                    // (0, 10p)
   U rd = U::template sub<4>(s2, acc.y);                    // (0, 6p)
-  if (pd.template maybe_multiple_of_p<10>()) {
-    xyzz_madd_u_slow<P>(&acc, &px, &py);
-    return;
-  }
+  if (pd.template maybe_multiple_of_p<10>()) return false;
   U pp = pd.sqr();                                         // < 2p
   U ppp = U::mul(pd, pp);                                  // < 2p
   U q = U::mul(acc.x, pp);                                 // < 2p
@@ -276,6 +255,7 @@ ZKP_DEV void xyzz_madd_u(XYZZu<P>& acc, const Fp<P>& px, const Fp<P>& py) {
   acc.zzz = U::mul(acc.zzz, ppp);
   acc.x = x3;
   acc.y = y3;
+  return true;
 }
 
 }  // namespace zkp
