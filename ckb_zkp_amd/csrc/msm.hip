@@ -677,21 +677,40 @@ void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* of
     ZKP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), count * jw * 4 + 4096));
     ctx->pinned_cap = count * jw * 4 + 4096;
   }
-  constexpr int NW = 3;
-  ZKP_HIP(hipEventRecord(L->ev_fork, L->stream));                  // scalars are complete on the main stream
-  for (int w = 1; w < NW; w++) ZKP_HIP(hipStreamWaitEvent(L->ws[w].stream, L->ev_fork, 0));
+  constexpr int NW = zkp_lane::N_WS;                              // MSM workspaces (stream + scratch) per lane
+  static const int NL = [] { const char* e = getenv("ZKP_BATCH_LANES"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > zkp_ctx::N_LANES ? zkp_ctx::N_LANES : v); }();
+  // job k runs on lane (k / NW) % NL, workspace k % NW: up to NL * NW MSMs in flight, one hardware queue each
+  auto stream_of = [&](int li, int w) { return w == 0 ? ctx->lanes[li].stream : ctx->lanes[li].ws[w].stream; };
+  struct Restore {                                               // msm_run may throw: always hand the context back on lane L
+    zkp_ctx* c;
+    zkp_lane* cur;
+    int idx;
+    ~Restore() {
+      c->cur = cur;
+      c->cur_idx = idx;
+    }
+  } restore{ctx, ctx->cur, ctx->cur_idx};
+  ZKP_HIP(hipEventRecord(L->ev_fork, L->stream));                  // scalars are complete on the calling lane's stream
+  for (int li = 0; li < NL; li++)
+    for (int w = 0; w < NW; w++)
+      if (stream_of(li, w) != L->stream) ZKP_HIP(hipStreamWaitEvent(stream_of(li, w), L->ev_fork, 0));
   for (size_t k = 0; k < count; k++) {
-    const int w = (int)(k % NW);
+    const int li = (int)((k / NW) % NL), w = (int)(k % NW);
     ZKP_REQUIRE(offsets[k] <= be->n, ZKP_ERR_BAD_ARG);
     const size_t n = std::min(ns[k], be->n - offsets[k]);        // ark min(len) truncation
+    ctx->cur = &ctx->lanes[li];
+    ctx->cur_idx = li;
     msm_run(ctx, handle, offsets[k], scalars_dev[k], n, montgomery, nullptr, nullptr, nullptr, nullptr, w);
-    hipStream_t st = w == 0 ? L->stream : L->ws[w].stream;
-    ZKP_HIP(hipMemcpyAsync(ctx->pinned + k * jw, L->ws[w].out.p, jw * 4, hipMemcpyDeviceToHost, st));
+    ZKP_HIP(hipMemcpyAsync(ctx->pinned + k * jw, ctx->lanes[li].ws[w].out.p, jw * 4, hipMemcpyDeviceToHost, stream_of(li, w)));
   }
-  for (int w = 1; w < NW; w++) {
-    ZKP_HIP(hipEventRecord(L->ws[w].done, L->ws[w].stream));
-    ZKP_HIP(hipStreamWaitEvent(L->stream, L->ws[w].done, 0));
-  }
+  ctx->cur = restore.cur;
+  ctx->cur_idx = restore.idx;
+  for (int li = 0; li < NL; li++)
+    for (int w = 0; w < NW; w++) {
+      if (stream_of(li, w) == L->stream) continue;
+      ZKP_HIP(hipEventRecord(ctx->lanes[li].ws[w].done, stream_of(li, w)));
+      ZKP_HIP(hipStreamWaitEvent(L->stream, ctx->lanes[li].ws[w].done, 0));
+    }
   ZKP_HIP(hipStreamSynchronize(L->stream));
   memcpy(out_xyz_host, ctx->pinned, count * jw * 4);
 }
