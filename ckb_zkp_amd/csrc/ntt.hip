@@ -219,8 +219,54 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
 #pragma unroll
     for (int l = 0; l < 8; l++) lds[l * TILE + e] = x.v[l];
   }
-  // S radix-2 DIF stages over rows
-  for (int s = 0; s < S; s++) {
+  // S radix-2 DIF stages over rows, two stages per LDS round trip: a lane holds the four rows
+  // {base, base + q, base + 2q, base + 3q} (q = quarter of the current group) and runs both butterfly layers in registers
+  // — half the LDS traffic and barriers of one stage per round trip; an odd S ends with a single radix-2 stage.
+  int s = 0;
+  for (; s + 1 < S; s += 2) {
+    __syncthreads();
+    const int half = R >> (s + 1), quarter = half >> 1;
+    for (int qd = tid; qd < (TILE >> 2); qd += NTT_THREADS) {
+      int cc = qd & (C - 1);
+      int u = qd >> logC;
+      int pos = u & (quarter - 1);
+      int grp = u >> (S - 2 - s);                          // u / quarter
+      int p0 = (((grp * 2 * half) + pos) << logC) + cc;
+      int p1 = p0 + (quarter << logC), p2 = p0 + (half << logC), p3 = p2 + (quarter << logC);
+      F x0, x1, x2, x3;
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        x0.v[l] = lds[l * TILE + p0];
+        x1.v[l] = lds[l * TILE + p1];
+        x2.v[l] = lds[l * TILE + p2];
+        x3.v[l] = lds[l * TILE + p3];
+      }
+      F ta, tb;
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        ta.v[l] = tw_l[((pos << s) << 3) + l];
+        tb.v[l] = tw_l[(((pos + quarter) << s) << 3) + l];
+      }
+      F y0 = x0 + x2, y2 = (x0 - x2) * ta;
+      F y1 = x1 + x3, y3 = (x1 - x3) * tb;
+      F z0 = y0 + y1, z1 = y0 - y1, z2 = y2 + y3, z3 = y2 - y3;
+      if (s + 2 < S) {                                     // the last stage's twiddle is w^0
+        F tc;
+#pragma unroll
+        for (int l = 0; l < 8; l++) tc.v[l] = tw_l[((pos << (s + 1)) << 3) + l];
+        z1 = z1 * tc;
+        z3 = z3 * tc;
+      }
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        lds[l * TILE + p0] = z0.v[l];
+        lds[l * TILE + p1] = z1.v[l];
+        lds[l * TILE + p2] = z2.v[l];
+        lds[l * TILE + p3] = z3.v[l];
+      }
+    }
+  }
+  for (; s < S; s++) {
     __syncthreads();
     const int half = R >> (s + 1);
     for (int bf = tid; bf < (TILE >> 1); bf += NTT_THREADS) {
