@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
     if (v >> 31) p.y = p.y.neg();
     const Fu<CfgFq> ux = Fu<CfgFq>::from_sat(p.x), uy = Fu<CfgFq>::from_sat(p.y);
     if (!xyzz_madd_u<CfgFq>(acc, ux, uy)) {
-      // the operand may equal +-accumulator (doubling / cancellation; 9 * 2^-29 false alarms): leave the whole task to
+      // the operand may equal +-accumulator (doubling / cancellation): leave the whole task to
       // the exact kernel below instead of carrying the exceptional formulas through the hot loop's register budget
       redo[1 + atomicAdd(redo, 1u)] = id;
       return;
