@@ -136,3 +136,33 @@ def test_msm_repeatability_stress(ctx, curve, group):
             assert jac_to_affine(ctx, curve, group, bases.msm(k)) == first
     finally:
         bases.free()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_msm_skewed_scalars_known_dlog(ctx, curve):
+    """SURVEY §8(d) skewed variant: half of the scalars in {0, 1} (boolean-heavy witnesses: one bucket of the first
+    window receives a quarter of all entries), a block of identical scalars, and single-window scalars — against the
+    known-discrete-log expectation at 2^18 points."""
+    c = get_curve(curve)
+    G = Group(OC[curve], 1)
+    n = (1 << 18) - 5
+    rng = np.random.default_rng(77)
+    d = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    d[:, 3] >>= np.uint64(4)
+    g_xy, _ = to_abi_points(curve, 1, [G.gen])
+    xy, inf = ctx.fixed_base_mul(c, 1, g_xy, d)
+    bases = ctx.upload_bases(c, 1, xy, inf)
+    dl = codec.limbs_to_ints(d)
+    try:
+        k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+        k[:, 3] >>= np.uint64(4)
+        m = rng.random(n) < 0.5
+        k[m] = 0
+        k[m, 0] = rng.integers(0, 2, size=int(m.sum()), dtype=np.uint64)
+        k[1000:60000] = k[999]                                  # a long run of identical scalars
+        k[70000:90000, 1:] = 0
+        k[70000:90000, 0] &= np.uint64(0xFF)                    # single-window scalars
+        e = sum(a * b for a, b in zip(dl, codec.limbs_to_ints(k))) % c.r
+        assert jac_limbs_to_affine_oracle(curve, 1, bases.msm(k)) == G.mul(G.gen, e)
+    finally:
+        bases.free()
