@@ -117,6 +117,30 @@ struct XYZZ {
     zz = zz * pp;
     zzz = zzz * ppp;
   }
+  // madd without the exceptional formulas: returns false (this untouched) when p = +-this, so that a hot loop can hand
+  // the rare case to an exact out-of-band path instead of carrying the doubling code through its register budget
+  ZKP_DEV bool madd_fast(const Affine<F>& p) {
+    if (p.is_inf()) return true;
+    if (is_inf()) {
+      *this = {p.x, p.y, F::one(), F::one()};
+      return true;
+    }
+    F u2 = p.x * zz;
+    F s2 = p.y * zzz;
+    F pp_ = u2 - x;
+    if (pp_.is_zero()) return false;
+    F r = s2 - y;
+    F pp = pp_.sqr();
+    F ppp = pp_ * pp;
+    F q = x * pp;
+    F x3 = r.sqr() - ppp - q.dbl();
+    F y3 = r * (q - x3) - y * ppp;
+    x = x3;
+    y = y3;
+    zz = zz * pp;
+    zzz = zzz * ppp;
+    return true;
+  }
   // this += o   (add-2008-s; 12M + 2S)
   ZKP_DEV void add(const XYZZ& o) {
     if (o.is_inf()) return;

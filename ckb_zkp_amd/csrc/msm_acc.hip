@@ -78,7 +78,10 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
     uint32_t v = vals[e];
     Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
     if (v >> 31) p.y = p.y.neg();
-    acc.madd(p);
+    if (!acc.madd_fast(p)) {                     // p = +-acc: the exact redo kernel takes the whole task
+      redo[1 + atomicAdd(redo, 1u)] = id;
+      return;
+    }
   }
   acc.store(out);
 #endif
@@ -121,16 +124,28 @@ void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const 
   static const unsigned lds = [] { const char* e = getenv("ZKP_ACC_LDS_BYTES"); return e ? (unsigned)atoi(e) : 0u; }();
   static const int occ = [] { const char* e = getenv("ZKP_G2_ACC_OCC"); return e ? atoi(e) : 1; }();
   static const int occ1 = [] { const char* e = getenv("ZKP_G1_ACC_OCC"); return e ? atoi(e) : 3; }();
-#if ZKP_CFG_GROUP == 1 && defined(ZKP_ACC_UNSAT)
   (void)hipMemsetAsync(redo, 0, sizeof(uint32_t), s);
+  struct Redo {                                  // every launch path below is followed by the exact redo kernel
+    hipStream_t s;
+    const char* table;
+    const uint32_t *vals, *task_start, *task_len, *task_dst;
+    char *buckets, *partial;
+    uint32_t* redo;
+    ~Redo() {
+      hipLaunchKernelGGL(accumulate_redo_kernel, dim3(64), dim3(64), 0, s, table, vals, task_start, task_len, task_dst,
+                         buckets, partial, dbg_mask(), redo);
+    }
+  } redo_after{s, table, vals, task_start, task_len, task_dst, buckets, partial, redo};
+#if ZKP_CFG_GROUP == 1 && defined(ZKP_ACC_UNSAT)
   hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
                      task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
-  hipLaunchKernelGGL(accumulate_redo_kernel, dim3(64), dim3(64), 0, s, table, vals, task_start, task_len, task_dst, buckets,
-                     partial, dbg_mask(), redo);
   return;
 #endif
   if (ZKP_CFG_GROUP == 1 && occ1 == 4)
     hipLaunchKernelGGL(accumulate_kernel<4>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
+                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
+  else if (ZKP_CFG_GROUP == 2 && occ == 3)
+    hipLaunchKernelGGL(accumulate_kernel<3>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
                        task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
   else if (ZKP_CFG_GROUP == 2 && occ == 2)
     hipLaunchKernelGGL(accumulate_kernel<2>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
