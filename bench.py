@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--cpu-log-n", type=int, default=16, help="size of the bounded cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one blocking zkp_groth16_prove_dev call per step")
+    ap.add_argument("--single-device-test", action="store_true",
+                    help="TEST ONLY: every rank uses cuda:0 and the collectives run over gloo (exercises the N>1 code path "
+                         "on a one-GPU box; the number it prints is not a multi-GPU measurement)")
     args = ap.parse_args()
 
     import torch
@@ -57,11 +60,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if args.single_device_test:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.single_device_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from ckb_zkp_amd import codec, groth16
     from ckb_zkp_amd.api import Context
@@ -119,7 +127,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.single_device_test else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
