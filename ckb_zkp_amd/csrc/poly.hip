@@ -247,29 +247,83 @@ __global__ __launch_bounds__(256) void spmv_kernel(const uint32_t* __restrict__ 
   for (uint32_t k = b; k < e; k++) acc = acc + spmv_term<P>(col, coeff, x, k, one);
   acc.store(out + i * 8);
 }
+// Long rows in two steps so that ONE huge row (the column of the constant `one` holds ~40 % of the entries of a transposed
+// R1CS matrix: 10^6 terms) is spread over the whole chip instead of one workgroup:
+//   partial: (row, chunk of SPMV_CHUNK terms) pairs are dealt round-robin to the workgroups; every workgroup walks the row
+//            list with the same running partial-slot counter, so no index structure is needed;
+//   reduce:  one workgroup per row sums that row's partials.
+// Rows whose partial slots would not fit SPMV_PART_CAP are summed whole by their reduce workgroup.
+constexpr uint32_t SPMV_CHUNK = 8192, SPMV_PART_CAP = 1u << 16;
 template <class P>
-__global__ __launch_bounds__(256) void spmv_long_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
-                                                        const uint32_t* __restrict__ coeff, const uint32_t* __restrict__ x,
-                                                        uint32_t* __restrict__ out, const uint32_t* __restrict__ long_list) {
+__device__ __forceinline__ Fp<P> block_sum(Fp<P> acc, uint32_t* red, uint32_t tid) {
+  using F = Fp<P>;
+  acc.store(red + tid * 8);
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      acc = acc + F::load(red + (tid + s) * 8);
+      acc.store(red + tid * 8);
+    }
+    __syncthreads();
+  }
+  return acc;                                              // valid in lane 0
+}
+template <class P>
+__global__ __launch_bounds__(256) void spmv_long_partial_kernel(const uint32_t* __restrict__ row_ptr,
+                                                                const uint32_t* __restrict__ col,
+                                                                const uint32_t* __restrict__ coeff,
+                                                                const uint32_t* __restrict__ x,
+                                                                const uint32_t* __restrict__ long_list,
+                                                                uint32_t* __restrict__ partial) {
   using F = Fp<P>;
   __shared__ uint32_t red[256 * 8];
   const uint32_t count = min(long_list[0], SPMV_LIST_CAP), tid = threadIdx.x;
   const F one = F::one();
-  for (uint32_t r = blockIdx.x; r < count; r += gridDim.x) {
+  uint32_t slot = 0;                                       // first partial slot of the current row
+  for (uint32_t r = 0; r < count; r++) {
     const uint32_t i = long_list[1 + r], b = row_ptr[i], e = row_ptr[i + 1];
-    F acc = F::zero();
-    for (uint32_t k = b + tid; k < e; k += 256) acc = acc + spmv_term<P>(col, coeff, x, k, one);
-    acc.store(red + tid * 8);
-    __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) {
-      if (tid < s) {
-        acc = acc + F::load(red + (tid + s) * 8);
-        acc.store(red + tid * 8);
-      }
+    const uint32_t nch = (e - b + SPMV_CHUNK - 1) / SPMV_CHUNK;
+    if (slot + nch > SPMV_PART_CAP) break;                 // the rest is summed whole in the reduce kernel
+    for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
+      const uint32_t lo = b + c * SPMV_CHUNK, hi = min(e, lo + SPMV_CHUNK);
+      F acc = F::zero();
+      for (uint32_t k = lo + tid; k < hi; k += 256) acc = acc + spmv_term<P>(col, coeff, x, k, one);
+      acc = block_sum<P>(acc, red, tid);
+      if (tid == 0) acc.store(partial + (size_t)(slot + c) * 8);
       __syncthreads();
     }
-    if (tid == 0) acc.store(out + (size_t)i * 8);
-    __syncthreads();
+    slot += nch;
+  }
+}
+template <class P>
+__global__ __launch_bounds__(256) void spmv_long_reduce_kernel(const uint32_t* __restrict__ row_ptr,
+                                                               const uint32_t* __restrict__ col,
+                                                               const uint32_t* __restrict__ coeff,
+                                                               const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
+                                                               const uint32_t* __restrict__ long_list,
+                                                               const uint32_t* __restrict__ partial) {
+  using F = Fp<P>;
+  __shared__ uint32_t red[256 * 8];
+  const uint32_t count = min(long_list[0], SPMV_LIST_CAP), tid = threadIdx.x;
+  const F one = F::one();
+  uint32_t slot = 0;
+  bool fits = true;
+  for (uint32_t r = 0; r < count; r++) {
+    const uint32_t i = long_list[1 + r], b = row_ptr[i], e = row_ptr[i + 1];
+    const uint32_t nch = (e - b + SPMV_CHUNK - 1) / SPMV_CHUNK;
+    fits = fits && (slot + nch <= SPMV_PART_CAP);
+    if (r % gridDim.x == blockIdx.x) {
+      F acc = F::zero();
+      if (fits) {
+        for (uint32_t c = tid; c < nch; c += 256) acc = acc + F::load(partial + (size_t)(slot + c) * 8);
+      } else {
+        for (uint32_t k = b + tid; k < e; k += 256) acc = acc + spmv_term<P>(col, coeff, x, k, one);
+      }
+      acc = block_sum<P>(acc, red, tid);
+      if (tid == 0) acc.store(out + (size_t)i * 8);
+      __syncthreads();
+    }
+    if (fits) slot += nch;
   }
 }
 // out[i] = idx[i] < 0 ? 0 : in[idx[i]]
@@ -336,16 +390,19 @@ void fr_spmv(zkp_ctx* ctx, int curve, const uint32_t* row_ptr, const uint32_t* c
              const uint64_t* x, uint64_t* out) {
   if (nrows == 0) return;
   hipStream_t st = ctx->cur->stream;
-  uint32_t* list = ctx->spmv_list.as<uint32_t>(1 + SPMV_LIST_CAP);
+  uint32_t* list = ctx->spmv_list.as<uint32_t>(1 + SPMV_LIST_CAP + (size_t)SPMV_PART_CAP * 8);
+  uint32_t* partial = list + 1 + SPMV_LIST_CAP;
   ZKP_HIP(hipMemsetAsync(list, 0, sizeof(uint32_t), st));
   auto launch = [&](auto tag) {
     using P = decltype(tag);
     hipLaunchKernelGGL(spmv_kernel<P>, dim3((nrows + 255) / 256), dim3(256), 0, st, row_ptr, col,
                        reinterpret_cast<const uint32_t*>(coeff), reinterpret_cast<const uint32_t*>(x), nrows,
                        reinterpret_cast<uint32_t*>(out), list);
-    hipLaunchKernelGGL(spmv_long_kernel<P>, dim3(512), dim3(256), 0, st, row_ptr, col,
+    hipLaunchKernelGGL(spmv_long_partial_kernel<P>, dim3(512), dim3(256), 0, st, row_ptr, col,
+                       reinterpret_cast<const uint32_t*>(coeff), reinterpret_cast<const uint32_t*>(x), list, partial);
+    hipLaunchKernelGGL(spmv_long_reduce_kernel<P>, dim3(256), dim3(256), 0, st, row_ptr, col,
                        reinterpret_cast<const uint32_t*>(coeff), reinterpret_cast<const uint32_t*>(x),
-                       reinterpret_cast<uint32_t*>(out), list);
+                       reinterpret_cast<uint32_t*>(out), list, partial);
   };
   if (curve == ZKP_BN254) launch(Bn254Fr{});
   else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});

@@ -80,6 +80,10 @@ def test_device_vector_primitives(ctx):
         x = [rnd.randrange(c.r) for _ in range(ncols)]
         rows = [[(rnd.choice([1, c.r - 1, rnd.randrange(c.r)]), rnd.randrange(ncols)) for _ in range(rnd.choice([0, 1, 3, 40]))]
                 for _ in range(n)]
+        # long rows: block-per-row partial sums (several 8192-term chunks) + per-row reduction
+        rows[5] = [(rnd.choice([1, rnd.randrange(c.r)]), rnd.randrange(ncols)) for _ in range(20001)]
+        rows[17] = [(rnd.randrange(c.r), rnd.randrange(ncols)) for _ in range(300)]
+        rows[n - 1] = [(1, rnd.randrange(ncols)) for _ in range(8193)]
         got = be.download(be.spmv(marlin_dev._csr_dev(be, rows), be.upload(x), n))
         assert got == [sum(cf * x[j] for cf, j in row) % c.r for row in rows]
         idx = [rnd.choice([-1, rnd.randrange(ncols)]) for _ in range(500)]
