@@ -248,19 +248,21 @@ static void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out
 //   level 2  one workgroup per bin (~16 K entries, <= 1024 distinct low keys): LDS histogram, LDS scan — which
 //            directly yields start/end of every bucket of the bin — and an LDS-atomic scatter of the values.
 // LDS atomics resolve same-bucket conflicts inside a wave in hardware; no global atomics on the data path.
-constexpr int SORT_H1_MAX = 10;        // level-1 bins <= 1024 (static LDS histogram)
+constexpr int SORT_H1_MAX = 13;        // level-1 bins <= 8192 (static LDS histogram, 32 KiB)
+constexpr uint32_t SORT_BIN_TARGET = 16384;   // entries per level-1 bin the level-2 kernel stages in LDS
 constexpr int SORT_L_MAX = 13;         // level-2 keys per bin <= 8192 (dynamic LDS)
-constexpr int SORT_SCALARS = 2048;     // scalars per workgroup in the level-1 passes (8 per lane): larger tiles = smaller (bin x tile) count matrix and longer contiguous runs per bin in the scatter (512 -> 2048: +2 % proofs/s)
+constexpr int SORT_SCALARS = 2048;    // default; larger MSMs use larger tiles (runtime `tile`) to keep the tile count ~1200
+constexpr int SORT_SCALARS_UNUSED_ = 0;     // scalars per workgroup in the level-1 passes (8 per lane): larger tiles = smaller (bin x tile) count matrix and longer contiguous runs per bin in the scatter (512 -> 2048: +2 % proofs/s)
 template <class FrP>
 __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restrict__ scalars, size_t n, size_t offset,
                                                         const uint8_t* __restrict__ inf, int montgomery, int c, int W,
                                                         uint32_t nb, int L, uint32_t nbins1,
-                                                        uint32_t* __restrict__ hist, uint32_t nblocks) {
+                                                        uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t tile) {
   __shared__ uint32_t cnt[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i <= nbins1; i += 256) cnt[i] = 0;
   __syncthreads();
-  for (int rep = 0; rep < SORT_SCALARS / 256; rep++) {
-    size_t i = (size_t)blockIdx.x * SORT_SCALARS + rep * 256 + threadIdx.x;
+  for (uint32_t rep = 0; rep < tile / 256; rep++) {
+    size_t i = (size_t)blockIdx.x * tile + rep * 256 + threadIdx.x;
     if (i < n && !(inf && inf[offset + i])) {
       DigitIter it = load_scalar<FrP>(scalars, i, montgomery);
       for (int w = 0; w < W; w++) {
@@ -278,14 +280,14 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
                                                            size_t offset, const uint8_t* __restrict__ inf,
                                                            int montgomery, size_t ntab, int c, int W, uint32_t nb,
                                                            int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
-                                                           uint32_t nblocks,
+                                                           uint32_t nblocks, uint32_t tile,
                                                            uint64_t* __restrict__ kv) {   // (low key << 32) | val
   __shared__ uint32_t cur[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i < nbins1; i += 256) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
   __syncthreads();
   const uint32_t lmask = (1u << L) - 1;
-  for (int rep = 0; rep < SORT_SCALARS / 256; rep++) {
-    size_t i = (size_t)blockIdx.x * SORT_SCALARS + rep * 256 + threadIdx.x;
+  for (uint32_t rep = 0; rep < tile / 256; rep++) {
+    size_t i = (size_t)blockIdx.x * tile + rep * 256 + threadIdx.x;
     if (i < n && !(inf && inf[offset + i])) {
       DigitIter it = load_scalar<FrP>(scalars, i, montgomery);
       for (int w = 0; w < W; w++) {
@@ -300,80 +302,8 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
     }
   }
 }
-// Level-1 scatter with LDS staging: the tile's entries are first grouped by bin in LDS (the per-(bin, tile) counts are
-// known from the scanned histogram), then written out so that the lanes of a wave store consecutive addresses
-// inside each bin run — 8-B scattered stores cost 3.2x write amplification at the HBM (rocprofv3 WRITE_SIZE).
-constexpr uint32_t SORT_STAGE_CAP = 8192;          // entries staged per tile (64 KiB)
-template <class FrP>
-__global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t* __restrict__ scalars, size_t n,
-                                                                  size_t offset, const uint8_t* __restrict__ inf,
-                                                                  int montgomery, size_t ntab, int c, int W,
-                                                                  uint32_t nb, int L, uint32_t nbins1,
-                                                                  const uint32_t* __restrict__ offs, uint32_t nblocks,
-                                                                  uint64_t* __restrict__ kv) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t stage[];          // SORT_STAGE_CAP entries
-  uint16_t* sbin = reinterpret_cast<uint16_t*>(stage + SORT_STAGE_CAP);     // bin of every staged entry
-  __shared__ uint32_t gstart[1 << SORT_H1_MAX], lpre[1 << SORT_H1_MAX], lcur[1 << SORT_H1_MAX];
-  __shared__ uint32_t part[256];
-  const uint32_t t = threadIdx.x;
-  // per-bin run of this tile: global start and length
-  const uint32_t per = (nbins1 + 255) / 256;
-  uint32_t acc = 0;
-  for (uint32_t k = 0; k < per; k++) {
-    uint32_t i = t * per + k;
-    if (i < nbins1) {
-      size_t o = (size_t)i * nblocks + blockIdx.x;
-      uint32_t o0 = offs[o], o1 = offs[o + 1];
-      gstart[i] = o0;
-      lpre[i] = o1 - o0;
-      acc += o1 - o0;
-    }
-  }
-  part[t] = acc;
-  __syncthreads();
-  for (uint32_t d = 1; d < 256; d <<= 1) {
-    uint32_t add = t >= d ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += add;
-    __syncthreads();
-  }
-  const uint32_t total = part[255];
-  uint32_t run = part[t] - acc;
-  for (uint32_t k = 0; k < per; k++) {
-    uint32_t i = t * per + k;
-    if (i < nbins1) {
-      uint32_t v = lpre[i];
-      lpre[i] = run;
-      lcur[i] = run;
-      run += v;
-    }
-  }
-  __syncthreads();
-  const uint32_t lmask = (1u << L) - 1;
-  for (int rep = 0; rep < SORT_SCALARS / 256; rep++) {
-    size_t i = (size_t)blockIdx.x * SORT_SCALARS + rep * 256 + t;
-    if (i < n && !(inf && inf[offset + i])) {
-      DigitIter it = load_scalar<FrP>(scalars, i, montgomery);
-      for (int w = 0; w < W; w++) {
-        uint32_t key, neg;
-        it.next(w, c, nb, key, neg);
-        if (key < nb) {
-          const uint32_t bin = key >> L;
-          uint32_t slot = atomicAdd(&lcur[bin], 1u);
-          uint32_t val = (uint32_t)((size_t)w * ntab + offset + i) | (neg << 31);
-          stage[slot] = ((uint64_t)(key & lmask) << 32) | val;
-          sbin[slot] = (uint16_t)bin;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (uint32_t sidx = t; sidx < total; sidx += 256) {
-    const uint32_t bin = sbin[sidx];
-    kv[gstart[bin] + (sidx - lpre[bin])] = stage[sidx];
-  }
-}
-
+// (an LDS-staged variant of the level-1 scatter — entries grouped by bin in LDS, then written in coalesced runs — lost 4 %
+//  end to end: 92 KiB of LDS left one workgroup per CU; removed)
 constexpr uint32_t SORT_BIN_THREADS = 1024;
 constexpr uint32_t SORT_BIN_STAGE = 20480;      // values staged in LDS (80 KiB) so the output is written fully coalesced
 __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64_t* __restrict__ kv,
@@ -538,12 +468,19 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     const uint32_t* sc = reinterpret_cast<const uint32_t*>(scalars_dev);
     const int mont = montgomery ? 1 : 0;
     // K6: group entries by bucket (two-level counting sort); sorted values land back in `vals`
-    static const int h1_env = [] { const char* e = getenv("ZKP_SORT_H1"); return e ? atoi(e) : 10; }();
-    int H1 = std::min(std::min(SORT_H1_MAX, h1_env), c - 1);
+    // level-1 bins: enough of them that a bin (E / bins entries on average) fits the level-2 kernel's LDS stage; tiles:
+    // 2048 scalars, more for large MSMs so that the (bin x tile) count matrix stays small
+    static const int h1_env = [] { const char* e = getenv("ZKP_SORT_H1"); return e ? atoi(e) : 0; }();
+    int H1 = 10;
+    while (H1 < SORT_H1_MAX && (E >> H1) > SORT_BIN_TARGET) H1++;
+    if (h1_env > 0) H1 = std::min(SORT_H1_MAX, h1_env);
+    H1 = std::min(H1, c - 1);
     if ((c - 1) - H1 > SORT_L_MAX) H1 = (c - 1) - SORT_L_MAX;
     const int LB = (c - 1) - H1;                                       // low bits per level-1 bin
     const uint32_t nbins1 = 1u << H1;
-    const uint32_t nblocks = (uint32_t)((n + SORT_SCALARS - 1) / SORT_SCALARS);
+    uint32_t tile = SORT_SCALARS;
+    while ((n + tile - 1) / tile > 1536) tile += 256;
+    const uint32_t nblocks = (uint32_t)((n + tile - 1) / tile);
     const size_t hist_n = (size_t)nbins1 * nblocks + 1;                // + total (== number of non-zero digits)
     uint32_t* hist = sw.sort_tmp.as<uint32_t>(2 * hist_n);
     uint32_t* offs = hist + hist_n;
@@ -551,30 +488,19 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     uint32_t* end = start + nb;
     if (reuse) ZKP_HIP(hipStreamWaitEvent(st, sw.sorted, 0));
     else ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
-    static const bool stage_env = [] { const char* e = getenv("ZKP_SORT_STAGE"); return e && atoi(e) != 0; }();   // default off: measured 4 % slower end to end (92 KiB LDS -> 1 workgroup per CU)
-    const bool stage_ok = stage_env && (size_t)SORT_SCALARS * W <= SORT_STAGE_CAP;
-    const size_t stage_lds = (size_t)SORT_STAGE_CAP * 8 + (size_t)SORT_STAGE_CAP * 2;
     if (reuse) {
     } else if (be->curve == ZKP_BN254) {
       hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
-                         nb, LB, nbins1, hist, nblocks);
+                         nb, LB, nbins1, hist, nblocks, tile);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-      if (stage_ok)
-        hipLaunchKernelGGL(sort_scatter_staged_kernel<Bn254Fr>, dim3(nblocks), dim3(256), stage_lds, st, sc, n, offset,
-                           be->inf, mont, be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
-      else
-        hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
-                           be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
+      hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
+                         be->n, c, W, nb, LB, nbins1, offs, nblocks, tile, kv);
     } else {
       hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
-                         nb, LB, nbins1, hist, nblocks);
+                         nb, LB, nbins1, hist, nblocks, tile);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-      if (stage_ok)
-        hipLaunchKernelGGL(sort_scatter_staged_kernel<Bls381Fr>, dim3(nblocks), dim3(256), stage_lds, st, sc, n, offset,
-                           be->inf, mont, be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
-      else
-        hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
-                           be->n, c, W, nb, LB, nbins1, offs, nblocks, kv);
+      hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
+                         be->n, c, W, nb, LB, nbins1, offs, nblocks, tile, kv);
     }
     if (!reuse)
       hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(SORT_BIN_THREADS), ((size_t)4 << LB) + 4 * (size_t)SORT_BIN_STAGE, st,
