@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   else XYZZ<F>{acc.x.to_sat(), acc.y.to_sat(), acc.zz.to_sat(), acc.zzz.to_sat()}.store(out);
 #else
   XYZZ<F> acc = XYZZ<F>::inf();
-  // (a software-pipelined gather of entry e+1 was tried: +20 VGPRs -> scratch spills, no gain; 3 waves/SIMD
-  //  already cover the gather latency)
+  // (a software-pipelined gather of entry e+1 was tried twice — G1: +20 VGPRs -> spills; G2 after the redo split:
+  //  276 VGPRs -> 1 wave/SIMD, or 256 with launch bounds — no gain either time: the gather latency is covered)
   for (uint32_t e = e0; e < e1; e++) {
     uint32_t v = vals[e];
     Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
