@@ -43,8 +43,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log-n", type=int, default=20, help="QAP domain 2^k (k=20 is the BASELINE metric config)")
     ap.add_argument("--curve", default="bn254")
     ap.add_argument("--cpu-log-n", type=int, default=16, help="size of the bounded cpu_baseline sample")
@@ -222,7 +222,7 @@ def main():
             "config": {"workload": f"Groth16 prove, MiMC-chain R1CS, {inst.num_constraints()} constraints "
                                    f"(domain 2^{args.log_n}), {inst.num_aux} aux, {c.name}, G1 x4 + G2 x1 MSM + 7 NTT",
                        "curve": c.name, "log_domain": args.log_n, "parallelism": f"independent proofs x{world}",
-                       "pipelining": "none" if args.no_pipeline else f"{os.environ.get('ZKP_LANES', '4')} proofs in flight per GPU (zkp_groth16_prove_batch_dev), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}"},
+                       "pipelining": "none" if args.no_pipeline else f"{os.environ.get('ZKP_LANES', '8 (4 above 2^22)')} proofs in flight per GPU (zkp_groth16_prove_batch_dev), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "msm_g1": msm_g1, "phases_ms": phases,
         }
         print(json.dumps(out), flush=True)

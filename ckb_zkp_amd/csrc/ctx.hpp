@@ -118,7 +118,7 @@ struct zkp_lane {
 
 struct zkp_ctx {
   int device = 0;
-  static constexpr int N_LANES = 8;        // allocated; zkp_groth16_prove_batch_dev uses ZKP_LANES (default 4) of them
+  static constexpr int N_LANES = 8;        // allocated; zkp_groth16_prove_batch_dev uses 8 (domains <= 2^22) or 4 of them unless ZKP_LANES says otherwise
   static constexpr int N_WS = zkp_lane::N_WS;
   zkp_lane lanes[N_LANES];
   zkp_lane* cur = &lanes[0];

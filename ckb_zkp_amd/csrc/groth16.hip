@@ -445,8 +445,11 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
   const size_t pw64 = (4 * (size_t)v1->fN + 2 * (size_t)v2->fN) / 2;
   const bool prof = ctx->profiling;
   size_t pending[zkp_ctx::N_LANES] = {};
-  static const int lanes_env = [] { const char* e = getenv("ZKP_LANES"); return e ? atoi(e) : 4; }();
-  const int nl = std::max(1, std::min(lanes_env, (int)zkp_ctx::N_LANES));
+  // proofs in flight: 8 lanes x 4 streams = 2 streams per hardware queue (measured optimum at 2^20: 4 lanes 102, 6 lanes 103,
+  // 8 lanes 108-110, 12 lanes 104 proofs/s); 4 above 2^22 where a lane's scratch is tens of GB.  ZKP_LANES overrides.
+  static const int lanes_env = [] { const char* e = getenv("ZKP_LANES"); return e ? atoi(e) : 0; }();
+  const int lanes_default = pk->log_n <= 22 ? 8 : 4;
+  const int nl = std::max(1, std::min(lanes_env > 0 ? lanes_env : lanes_default, (int)zkp_ctx::N_LANES));
   auto select = [&](int l) {
     ctx->cur = &ctx->lanes[l];
     ctx->cur_idx = l;
