@@ -62,6 +62,7 @@ SIGNATURES = {
     "zkp_ntt_dev": (C.c_int32, [vp, C.c_int, vp, C.c_uint32, C.c_int32]),
     "zkp_bases_upload_g1": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
     "zkp_bases_upload_g2": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "zkp_bases_share": (C.c_int32, [vp, vp, C.c_uint64, u64p]),
     "zkp_bases_free": (C.c_int32, [vp, C.c_uint64]),
     "zkp_bases_len": (C.c_int32, [vp, C.c_uint64, C.POINTER(C.c_size_t)]),
     "zkp_msm_g1": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),

@@ -157,6 +157,12 @@ class Bases:
             _lib.check(self.ctx.lib.zkp_bases_free(self.ctx.h, self.handle), "zkp_bases_free")
             self.handle = 0
 
+    def share_with(self, other_ctx: "Context") -> "Bases":
+        """the same resident tables, addressable through another context (one context per prover thread)"""
+        h = C.c_uint64(0)
+        _lib.check(self.ctx.lib.zkp_bases_share(other_ctx.h, self.ctx.h, self.handle, C.byref(h)), "zkp_bases_share")
+        return Bases(other_ctx, self.curve, self.group, h.value, self.n)
+
     def _out(self):
         return np.zeros(3 * self.curve.fq_limbs * (1 if self.group == 1 else 2), dtype=np.uint64)
 

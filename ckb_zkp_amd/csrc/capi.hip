@@ -217,6 +217,10 @@ int32_t zkp_bases_upload_g2(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy,
   if (!handle || (n && !xy)) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { *handle = bases_upload(ctx, curve, 2, xy, inf, n); });
 }
+int32_t zkp_bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t src_handle, uint64_t* dst_handle) {
+  if (!src || !dst_handle) return ZKP_ERR_BAD_ARG;
+  return guarded(dst, [&] { *dst_handle = bases_share(dst, src, src_handle); });
+}
 int32_t zkp_bases_free(zkp_ctx* ctx, uint64_t handle) {
   return guarded(ctx, [&] { bases_free(ctx, handle); });
 }

@@ -24,6 +24,7 @@ void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const
 // msm.hip
 uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, const uint8_t* inf_host, size_t n);
 void bases_free(zkp_ctx* ctx, uint64_t handle);
+uint64_t bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t handle);
 size_t bases_len(zkp_ctx* ctx, uint64_t handle);
 int bases_group(zkp_ctx* ctx, uint64_t handle);
 // result -> host Jacobian (out_xyz_host) ; if out_dev_xyzz != nullptr the XYZZ result is also left on device

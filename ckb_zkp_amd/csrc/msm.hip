@@ -117,6 +117,13 @@ void bases_free(zkp_ctx* ctx, uint64_t handle) {
 size_t bases_len(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->n; }
 int bases_group(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->group; }
 void msm_free_all(zkp_ctx* ctx) { ctx->bases.clear(); }
+uint64_t bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t handle) {
+  auto e = get_bases(src, handle);
+  ZKP_REQUIRE(dst->device == src->device, ZKP_ERR_BAD_ARG);
+  uint64_t h = dst->next_handle++;
+  dst->bases[h] = e;
+  return h;
+}
 bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2) {
   auto a = get_bases(ctx, h1), b = get_bases(ctx, h2);
   return a->curve == b->curve && a->n == b->n && a->c == b->c && a->W == b->W;

@@ -104,6 +104,10 @@ int32_t zkp_bases_upload_g1(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy,
 int32_t zkp_bases_upload_g2(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n,
                             uint64_t* handle);
 int32_t zkp_bases_free(zkp_ctx* ctx, uint64_t handle);
+/* Make a resident base vector of `src` usable through `dst` as well (same device, same process): the window tables are
+ * shared, not copied — one SRS / proving key serves several contexts (one per prover thread).  The entry lives until
+ * every context that holds it has freed it. */
+int32_t zkp_bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t src_handle, uint64_t* dst_handle);
 int32_t zkp_bases_len(zkp_ctx* ctx, uint64_t handle, size_t* n);
 
 /* ---- MSM: replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul ------------------------------

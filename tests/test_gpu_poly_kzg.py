@@ -124,3 +124,29 @@ def test_batched_commit_msms_equal_individual_ones(ctx, curve):
     finally:
         ck.powers_of_g.free()
         ck.powers_of_gamma_g.free()
+
+
+def test_shared_bases_between_contexts(ctx):
+    """zkp_bases_share: a second context (own streams and scratch) computes the same MSM against the first context's
+    resident window tables; freeing one handle leaves the other usable."""
+    from ckb_zkp_amd.api import Context
+    c = get_curve("bn254")
+    rnd = random.Random(23)
+    ck = kzg10.setup(ctx, "bn254", 300, 0xC0DE)
+    ctx2 = Context(0)
+    try:
+        shared = ck.powers_of_g.share_with(ctx2)
+        coeffs = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(301)], c).reshape(-1, 4)
+        d1, d2 = ctx.to_device(coeffs), ctx2.to_device(coeffs)
+        a = ck.powers_of_g.msm_mont_dev(d1, 301)
+        b = shared.msm_mont_dev(d2, 301)
+        assert ctx.into_affine(c, 1, a)[0].tolist() == ctx2.into_affine(c, 1, b)[0].tolist()
+        ck.powers_of_g.free()
+        b2 = shared.msm_mont_dev(d2, 301)                     # the tables outlive the first handle
+        assert ctx2.into_affine(c, 1, b2)[0].tolist() == ctx2.into_affine(c, 1, b)[0].tolist()
+        shared.free()
+        ctx.dev_free(d1)
+        ctx2.dev_free(d2)
+    finally:
+        ck.powers_of_gamma_g.free()
+        ctx2.close()
