@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
     }
   }
   if (acc.inf) XYZZ<F>::inf().store(out);
-  else XYZZ<F>{acc.x.to_sat(), acc.y.to_sat(), acc.zz.to_sat(), acc.zzz.to_sat()}.store(out);
+  else XYZZ<F>{acc.x.f.to_sat(), acc.y.f.to_sat(), acc.zz.f.to_sat(), acc.zzz.f.to_sat()}.store(out);
 #else
   XYZZ<F> acc = XYZZ<F>::inf();
   // (a software-pipelined gather of entry e+1 was tried twice — G1: +20 VGPRs -> spills; G2 after the redo split:

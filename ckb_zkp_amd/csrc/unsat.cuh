@@ -33,6 +33,14 @@ struct Fu {
   static constexpr int L = UnsatCfg<P>::L, B = UnsatCfg<P>::B, N = P::N;
   static constexpr uint32_t MASK = (1u << B) - 1;
   static constexpr int SHIFT = L * B - 32 * N;              // R' / R
+  static constexpr int pbits() {                            // bit length of the modulus
+    int top = N - 1;
+    while (top > 0 && P::MOD[top] == 0) top--;
+    int b = 0;
+    for (uint32_t w = P::MOD[top]; w; w >>= 1) b++;
+    return 32 * top + b;
+  }
+  static constexpr int PBITS = pbits();
   uint32_t v[L];
 
   static constexpr int KMAX = 10;                           // multiples of p kept as limb tables
@@ -220,40 +228,81 @@ struct Fu {
   }
 };
 
-// Bucket accumulator in unsaturated form.  Value bounds maintained by madd: x < 8p, y < 4p, zz, zzz < 2p.
+// ---------------------------------------------------------------------------------------------------------------------
+// Value bounds as types.  UB<P, K> wraps an element whose VALUE is known to be < K * p (limbs normalised); every operation
+// derives the bound of its result and static_asserts its precondition, so the "lazy reduction" bookkeeping of the mixed
+// addition below is checked by the compiler instead of by comments:
+//   product:   needs KA * KB <= MULCAP (p / R' <= 2^-7: the result is < (KA*KB*p/R' + 1) p < 2p)          -> K = 2
+//   a - b:     computed as a + (KB*p - b), needs the table of multiples to reach KB                        -> K = KA + KB
+//   2a:                                                                                                     -> K = 2 KA
+//   capacity:  K * p must fit L*B bits with room for one more addition (K <= CAPK)
+template <class P, int K>
+struct UB {
+  Fu<P> f;
+};
+template <class P>
+struct UBLimits {
+  // p / R' <= 2^-(L*B - bits(p)):  BN254 2^-7, BLS12-381 2^-11
+  static constexpr int MULCAP = 1 << (Fu<P>::L * Fu<P>::B - Fu<P>::PBITS);
+  static constexpr int CAPK = MULCAP;                      // K*p < 2^(L*B) with the same margin
+};
+template <class P, int KA, int KB>
+ZKP_DEV UB<P, 2> ub_mul(const UB<P, KA>& a, const UB<P, KB>& b) {
+  static_assert((long)KA * KB <= UBLimits<P>::MULCAP, "product of unreduced operands exceeds the Montgomery slack");
+  return {Fu<P>::mul(a.f, b.f)};
+}
+template <class P, int KA, int KB>
+ZKP_DEV UB<P, KA + KB> ub_sub(const UB<P, KA>& a, const UB<P, KB>& b) {
+  static_assert(KB <= Fu<P>::KMAX, "no table entry for this multiple of p");
+  static_assert(KA + KB <= UBLimits<P>::CAPK, "value would outgrow the limbs");
+  return {Fu<P>::template sub<KB>(a.f, b.f)};
+}
+template <class P, int KA>
+ZKP_DEV UB<P, 2 * KA> ub_dbl(const UB<P, KA>& a) {
+  static_assert(2 * KA <= UBLimits<P>::CAPK, "value would outgrow the limbs");
+  return {a.f.dbl()};
+}
+
+// Bucket accumulator in unsaturated form; the stored bounds are part of the type.
 template <class P>
 struct XYZZu {
-  Fu<P> x, y, zz, zzz;
+  UB<P, 8> x;
+  UB<P, 4> y;
+  UB<P, 2> zz, zzz;
   bool inf;
 };
 
-// acc += P where (ux, uy) = from_sat of a gathered affine point (not the identity) — madd-2008-s (8M + 2S) with hand-tracked
-// bounds.  Returns false WITHOUT touching acc when P may equal +-acc (the difference of the x coordinates has the low
-// limb of a multiple of p): the caller hands the bucket to the exact saturated path.
+// acc += P where (ux, uy) = from_sat of a gathered affine point (not the identity): the integers 2^SHIFT * X, i.e.
+// values < 2^SHIFT * p.  madd-2008-s (8M + 2S).  Returns false WITHOUT touching acc when P may equal +-acc (the
+// difference of the x coordinates matches a multiple of p in its two low limbs): the caller hands the bucket to the exact
+// saturated path.
 template <class P>
-ZKP_DEV bool xyzz_madd_u(XYZZu<P>& acc, const Fu<P>& ux, const Fu<P>& uy) {
+ZKP_DEV bool xyzz_madd_u(XYZZu<P>& acc, const Fu<P>& ux_, const Fu<P>& uy_) {
   using U = Fu<P>;
+  constexpr int KIN = 1 << U::SHIFT;                       // 32 (BN254) / 256 (BLS12-381)
+  const UB<P, KIN> ux{ux_}, uy{uy_};
+  const UB<P, 1> one{U::one()};
   if (acc.inf) {
-    acc.x = U::mul(ux, U::one());                          // < 2p
-    acc.y = U::mul(uy, U::one());
-    acc.zz = U::one();
-    acc.zzz = U::one();
+    acc.x = {ub_mul(ux, one).f};                           // < 2p, stored as "< 8p"
+    acc.y = {ub_mul(uy, one).f};
+    acc.zz = {one.f};
+    acc.zzz = {one.f};
     acc.inf = false;
     return true;
   }
-  U u2 = U::mul(ux, acc.zz);                               // < 2p
-  U s2 = U::mul(uy, acc.zzz);                              // < 2p
-  U pd = U::template sub<8>(u2, acc.x);                    // (0, 10p)
-  U rd = U::template sub<4>(s2, acc.y);                    // (0, 6p)
-  if (pd.template maybe_multiple_of_p<10>()) return false;
-  U pp = pd.sqr();                                         // < 2p
-  U ppp = U::mul(pd, pp);                                  // < 2p
-  U q = U::mul(acc.x, pp);                                 // < 2p
-  U t = U::template sub<2>(rd.sqr(), ppp);                 // (0, 4p)
-  U x3 = U::template sub<4>(t, q.dbl());                   // (0, 8p)
-  U y3 = U::template sub<2>(U::mul(rd, U::template sub<8>(q, x3)), U::mul(acc.y, ppp));   // (0, 4p)
-  acc.zz = U::mul(acc.zz, pp);
-  acc.zzz = U::mul(acc.zzz, ppp);
+  const auto u2 = ub_mul(ux, acc.zz);                      // < 2p
+  const auto s2 = ub_mul(uy, acc.zzz);                     // < 2p
+  const auto pd = ub_sub(u2, acc.x);                       // (0, 10p)
+  const auto rd = ub_sub(s2, acc.y);                       // (0, 6p)
+  if (pd.f.template maybe_multiple_of_p<10>()) return false;
+  const auto pp = ub_mul(pd, pd);                          // < 2p
+  const auto ppp = ub_mul(pd, pp);
+  const auto q = ub_mul(acc.x, pp);
+  const auto t = ub_sub(ub_mul(rd, rd), ppp);              // (0, 4p)
+  const UB<P, 8> x3 = ub_sub(t, ub_dbl(q));                // (0, 8p): the type of acc.x
+  const UB<P, 4> y3 = ub_sub(ub_mul(rd, ub_sub(q, x3)), ub_mul(acc.y, ppp));   // (0, 4p): the type of acc.y
+  acc.zz = ub_mul(acc.zz, pp);
+  acc.zzz = ub_mul(acc.zzz, ppp);
   acc.x = x3;
   acc.y = y3;
   return true;
