@@ -123,7 +123,7 @@ def test_batch_prove_equals_sequential(ctx):
         MimcChain(curve, insts[0].constants, [(rnd.randrange(c.r), rnd.randrange(c.r)) for _ in range(S)]).generate_constraints(cs)
         zs = [codec.fr_to_mont(insts[0].z, c).reshape(-1, 4), codec.fr_to_mont(cs.full_assignment(), c).reshape(-1, 4)]
         zd = [ctx.to_device(z) for z in zs]
-        for n in (1, 2, 5):
+        for n in (1, 2, 5, 9, 19):           # 8 lanes: 9 and 19 wrap around the lanes once and twice
             rs = [rnd.randrange(c.r) for _ in range(n)]
             ss = [rnd.randrange(c.r) for _ in range(n)]
             rm, sm = codec.fr_to_mont(rs, c), codec.fr_to_mont(ss, c)
