@@ -54,6 +54,12 @@ struct zkp_groth16_pk {
     DevBuf S;        // nz + 4 Fr
     DevBuf results;  // 6 XYZZ (G2-sized slots)
     DevBuf proof;    // [r, s] + device proof + flags
+    // hipGraph of one proof on this lane (ZKP_GRAPH=1): state 0 = never run, 1 = ran eagerly once (scratch allocated,
+    // signature recorded), 2 = captured.  `sig` = every device pointer the captured launches embed.
+    int graph_state = 0;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    std::vector<const void*> sig;
   } lane[zkp_ctx::N_LANES];
   DevBuf consts;     // zinv etc.
 };
@@ -212,7 +218,11 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d) {
 }
 
 void groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk) {
-  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
+  (void)hipDeviceSynchronize();
+  for (auto& PL : pk->lane) {
+    if (PL.graph_exec) (void)hipGraphExecDestroy(PL.graph_exec);
+    if (PL.graph) (void)hipGraphDestroy(PL.graph);
+  }
   for (uint64_t h : {pk->hA, pk->hB1, pk->hB2, pk->hH, pk->hL})
     if (h) ctx->bases.erase(h);
   for (auto& m : pk->m) {
@@ -270,18 +280,19 @@ void groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, ui
 
 // Enqueue one proof on the current lane (ctx->cur): everything is asynchronous up to and including the read-back of
 // the 3 proof points into the lane's pinned host buffer; prove_finish() synchronises the lane and hands them out.
+// part: 1 = copy the inputs (z, r, s) into the lane's buffers, 2 = everything else (the part a hipGraph captures), 3 = both
 template <class FrP>
-static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
-                          const uint64_t* s) {
+static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
+                               const uint64_t* s, int part) {
   ZKP_REQUIRE(pk->hA != 0, ZKP_ERR_BAD_ARG);             // matrices-only key: use the sharded path
   zkp_groth16_pk::PerLane& PL = pk->lane[ctx->cur_idx];
   hipStream_t st = ctx->cur->stream;
   const bool prof = ctx->profiling;
   zkp_groth16_timing tm{};
   hipEvent_t e0 = nullptr, e1 = nullptr, eT0 = nullptr, eT1 = nullptr;
-  ZKP_HIP(hipEventCreate(&eT0));
-  ZKP_HIP(hipEventCreate(&eT1));
   if (prof) {
+    ZKP_HIP(hipEventCreate(&eT0));
+    ZKP_HIP(hipEventCreate(&eT1));
     ZKP_HIP(hipEventCreate(&e0));
     ZKP_HIP(hipEventCreate(&e1));
   }
@@ -292,14 +303,17 @@ static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, b
     ZKP_HIP(hipEventSynchronize(e1));
     ZKP_HIP(hipEventElapsedTime(dst, e0, e1));
   };
-  ZKP_HIP(hipEventRecord(eT0, st));
+  if (prof) ZKP_HIP(hipEventRecord(eT0, st));
   uint32_t* S = PL.S.as<uint32_t>((pk->nz + 4) * 8);
-  ZKP_HIP(hipMemcpyAsync(S, z, pk->nz * 32, z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   uint32_t* rs = PL.proof.as<uint32_t>(1024);         // [r, s] then proof words then flags
   uint32_t* proof_dev = rs + 16;
   uint32_t* flags_dev = proof_dev + 256;
-  ZKP_HIP(hipMemcpyAsync(rs, r, 32, hipMemcpyHostToDevice, st));
-  ZKP_HIP(hipMemcpyAsync(rs + 8, s, 32, hipMemcpyHostToDevice, st));
+  if (part & 1) {
+    ZKP_HIP(hipMemcpyAsync(S, z, pk->nz * 32, z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    ZKP_HIP(hipMemcpyAsync(rs, r, 32, hipMemcpyHostToDevice, st));
+    ZKP_HIP(hipMemcpyAsync(rs + 8, s, 32, hipMemcpyHostToDevice, st));
+  }
+  if (!(part & 2)) return;
   hipLaunchKernelGGL(scalar_tail_kernel<FrP>, dim3(1), dim3(64), 0, st, S + pk->nz * 8, rs);
 
   const MsmVtbl* v1 = msm_vtbl(pk->curve, 1);
@@ -373,17 +387,83 @@ static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, b
   const size_t proof_words = 4 * (size_t)v1->fN + 2 * (size_t)v2->fN;
   ZKP_HIP(hipMemcpyAsync(ctx->cur->host_proof, proof_dev, proof_words * 4, hipMemcpyDeviceToHost, st));
   ZKP_HIP(hipMemcpyAsync(ctx->cur->host_proof + 256, flags_dev, 12, hipMemcpyDeviceToHost, st));
-  ZKP_HIP(hipEventRecord(eT1, st));
   ctx->cur->busy = true;
   if (prof) {
+    ZKP_HIP(hipEventRecord(eT1, st));
     ZKP_HIP(hipStreamSynchronize(st));
     ZKP_HIP(hipEventElapsedTime(&tm.ms_total, eT0, eT1));
     ctx->last_timing = tm;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(eT0);
+    (void)hipEventDestroy(eT1);
   }
-  (void)hipEventDestroy(eT0);
-  (void)hipEventDestroy(eT1);
+}
+
+// every device pointer a captured proof embeds: if any scratch buffer was reallocated since the capture (another, larger
+// key used the lane), the graph is stale
+static std::vector<const void*> lane_signature(zkp_ctx* ctx, zkp_groth16_pk* pk) {
+  std::vector<const void*> sig;
+  zkp_lane* L = ctx->cur;
+  zkp_groth16_pk::PerLane& PL = pk->lane[ctx->cur_idx];
+  for (DevBuf* b : {&PL.abc, &PL.S, &PL.results, &PL.proof, &L->ntt_scratch}) sig.push_back(b->p);
+  for (int w = 0; w < zkp_lane::N_WS; w++) {
+    MsmWorkspace& ws = L->ws[w];
+    for (DevBuf* b : {&ws.keys, &ws.vals, &ws.keys2, &ws.vals2, &ws.sort_tmp, &ws.offsets, &ws.buckets, &ws.tmp, &ws.out,
+                      &ws.sched, &ws.scan_tmp, &ws.scan_tmp2, &ws.partial, &ws.redo})
+      sig.push_back(b->p);
+  }
+  sig.push_back(pk);
+  return sig;
+}
+
+// One proof on the current lane.  With ZKP_GRAPH=1 the ~250 launches of a proof (4 streams, fork/join by events) are
+// captured once per (key, lane) into a hipGraph and replayed; the inputs are copied in front of the graph launch.
+template <class FrP>
+static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
+                          const uint64_t* s) {
+  static const bool graph_on = getenv("ZKP_GRAPH") && atoi(getenv("ZKP_GRAPH")) != 0;
+  static const bool single_stream = getenv("ZKP_SINGLE_STREAM") && atoi(getenv("ZKP_SINGLE_STREAM")) != 0;
+  if (!graph_on || ctx->profiling || single_stream) {
+    prove_enqueue_part<FrP>(ctx, pk, z, z_on_device, r, s, 3);
+    return;
+  }
+  zkp_groth16_pk::PerLane& PL = pk->lane[ctx->cur_idx];
+  hipStream_t st = ctx->cur->stream;
+  if (PL.graph_state == 2 && PL.sig == lane_signature(ctx, pk)) {
+    prove_enqueue_part<FrP>(ctx, pk, z, z_on_device, r, s, 1);
+    ZKP_HIP(hipGraphLaunch(PL.graph_exec, st));
+    ctx->cur->busy = true;
+    return;
+  }
+  if (PL.graph_state == 2) {                              // stale
+    (void)hipGraphExecDestroy(PL.graph_exec);
+    (void)hipGraphDestroy(PL.graph);
+    PL.graph_exec = nullptr;
+    PL.graph = nullptr;
+    PL.graph_state = 0;
+  }
+  if (PL.graph_state == 1 && PL.sig == lane_signature(ctx, pk)) {
+    prove_enqueue_part<FrP>(ctx, pk, z, z_on_device, r, s, 1);
+    ZKP_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    try {
+      prove_enqueue_part<FrP>(ctx, pk, z, z_on_device, r, s, 2);
+    } catch (...) {
+      hipGraph_t g = nullptr;
+      (void)hipStreamEndCapture(st, &g);
+      if (g) (void)hipGraphDestroy(g);
+      throw;
+    }
+    ZKP_HIP(hipStreamEndCapture(st, &PL.graph));
+    ZKP_HIP(hipGraphInstantiate(&PL.graph_exec, PL.graph, nullptr, nullptr, 0));
+    PL.graph_state = 2;
+    ZKP_HIP(hipGraphLaunch(PL.graph_exec, st));
+    ctx->cur->busy = true;
+    return;
+  }
+  prove_enqueue_part<FrP>(ctx, pk, z, z_on_device, r, s, 3);    // eager run: allocates every scratch buffer
+  PL.sig = lane_signature(ctx, pk);
+  PL.graph_state = 1;
 }
 
 static void prove_finish(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t* proof_out, uint8_t* inf_out) {
