@@ -177,3 +177,40 @@ def test_full_size_proof_trapdoor_and_pipeline(ctx, curve, k):
         ctx.dev_free(zd)
     finally:
         pk.free()
+
+
+def test_graph_replay_equals_eager():
+    """ZKP_GRAPH=1: the third and later proofs on a lane replay a captured hipGraph; they must equal the eager proofs
+    (own process: the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, random
+from ckb_zkp_amd import codec, groth16
+from ckb_zkp_amd.api import Context
+from ckb_zkp_amd.circuits import mimc_chain_instance, samples_for_domain
+TOXIC = dict(alpha=11, beta=13, gamma=17, delta=19, tau=23)
+ctx = Context(0)
+inst = mimc_chain_instance("bn254", samples_for_domain(12))
+params = groth16.generate_parameters(ctx, "bn254", inst, **TOXIC)
+pk = groth16.ProvingKey(ctx, params, inst)
+c = params.curve
+z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+zd = ctx.to_device(z)
+rnd = random.Random(4)
+n = 7
+rs = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(n)], c)
+ss = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(n)], c)
+outs, infs = pk.prove_batch_raw([zd] * n, rs, ss)
+print("PROOFS", outs.tobytes().hex(), infs.tobytes().hex())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for g in ("0", "1"):
+        env = dict(os.environ, ZKP_GRAPH=g, ZKP_LANES="2", PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[g] = [l for l in out.stdout.splitlines() if l.startswith("PROOFS")][0]
+    assert res["0"] == res["1"]
+
