@@ -264,7 +264,20 @@ class DeviceIndex:
         self.w_idx = self.be.upload_raw(np.where(i % ratio == 0, -1, i - i // ratio - 1).astype(np.int32))
         self.x_idx = self.be.upload_raw(np.where(i % ratio == 0, -1, i).astype(np.int32))
         self.be.ctx.sync()
-        self.be._live = []          # index data stays resident for the lifetime of the context
+        # index data stays resident for the lifetime of the context; everything else the construction allocated goes back
+        keep = {self.h_el.ptr, self.w_idx, self.x_idx}
+        for m in "abc":
+            keep.update(self.csr[m])
+            keep.update(self.csr_t[m])
+            keep.update(v.ptr for v in self.on_k[m].values())
+            keep.update(v.ptr for v in self.on_b[m].values())
+        keep.update(v.ptr for v in self.polys.values())
+        for v in self.be._live:
+            if v.owner and v.ptr and v.ptr not in keep:
+                self.be.ctx.dev_free(v.ptr)
+                v.ptr = 0
+        self.be._live = []
+        self._owned = keep
 
     @classmethod
     def from_host_index(cls, ctx: Context, idx):
@@ -361,6 +374,13 @@ class DeviceIndex:
         self.num_non_zeros = nnz
         self._finish(xs, hs, ks, bs, n)
         return self
+
+    def free(self):
+        """release the resident index"""
+        for p in getattr(self, "_owned", ()):
+            if p:
+                self.be.ctx.dev_free(p)
+        self._owned = set()
 
     def commit_index(self, ctx: Context, ck: kzg10.CommitterKey):
         """index commitments (the verifier key's half of AHP::index, lib.rs:69-86) -> {label: (affine, None)}"""

@@ -230,3 +230,4 @@ def test_marlin_config4_full_size_verifies(ctx):
         ck.powers_of_g.free()
         ck.powers_of_gamma_g.free()
         marlin_dev.DeviceBackend.trim_pool(ctx)
+        didx.free()
