@@ -166,3 +166,32 @@ def test_msm_skewed_scalars_known_dlog(ctx, curve):
         assert jac_limbs_to_affine_oracle(curve, 1, bases.msm(k)) == G.mul(G.gen, e)
     finally:
         bases.free()
+
+
+@pytest.mark.parametrize("curve,group", [("bn254", 1), ("bn254", 2), ("bls12_381", 1), ("bls12_381", 2)])
+def test_msm_random_lengths_and_offsets(ctx, curve, group):
+    """Ragged inputs: random lengths (0 .. a few thousand, not powers of two), random offsets into the resident bases,
+    lengths that overrun the bases (ark's min(len) truncation) — against the known-discrete-log expectation."""
+    c = get_curve(curve)
+    G = Group(OC[curve], group)
+    nb = 3001
+    rng = np.random.default_rng(1000 + group)
+    d = rng.integers(0, 1 << 63, size=(nb, 4), dtype=np.uint64)
+    d[:, 3] >>= np.uint64(4)
+    g_xy, _ = to_abi_points(curve, group, [G.gen])
+    xy, inf = ctx.fixed_base_mul(c, group, g_xy, d)
+    bases = ctx.upload_bases(c, group, xy, inf)
+    dl = codec.limbs_to_ints(d)
+    try:
+        for n, off in ((0, 0), (1, 0), (1, 3000), (2, 17), (63, 1), (64, 100), (65, 2936), (257, 5), (1000, 2001),
+                       (3001, 0), (3500, 0), (500, 2900), (7, 3001)):
+            k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+            if n:
+                k[:, 3] >>= np.uint64(4)
+                k[rng.random(n) < 0.1] = 0
+            m = max(0, min(n, nb - off))                      # terms that exist on both sides
+            e = sum(a * b for a, b in zip(dl[off:off + m], codec.limbs_to_ints(k[:m]))) % c.r if m else 0
+            got = jac_limbs_to_affine_oracle(curve, group, bases.msm(k, offset=off))
+            assert got == (G.mul(G.gen, e) if e else None), (n, off)
+    finally:
+        bases.free()
