@@ -137,10 +137,10 @@ def test_batch_prove_equals_sequential(ctx):
         pk.free()
 
 
-@pytest.mark.parametrize("curve,k", [("bn254", 20), ("bls12_381", 20)])
+@pytest.mark.parametrize("curve,k", [("bn254", 20), ("bls12_381", 20), ("bls12_381", 22)])
 def test_full_size_proof_trapdoor_and_pipeline(ctx, curve, k):
-    """BASELINE.json configs[1] at FULL size (1 048 570 constraints, domain 2^20, BN254) and the same instance over
-    BLS12-381: the device proof equals the proof computed in the exponent from the toxic waste (size-independent check,
+    """BASELINE.json configs[1] at FULL size (1 048 570 constraints, domain 2^20, BN254), the same instance over
+    BLS12-381, and configs[2] at full size (4 194 300 constraints, domain 2^22, BLS12-381): the device proof equals the proof computed in the exponent from the toxic waste (size-independent check,
     SURVEY §8(c).3), and the pipelined batch path (several proofs in flight on the context's lanes) returns the same
     proof as the blocking call."""
     from ckb_zkp_amd.circuits import samples_for_domain
