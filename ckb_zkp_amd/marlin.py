@@ -158,11 +158,10 @@ class MarlinCS(ConstraintSystem):
                 self.enforce(lambda lc: lc, lambda lc: lc, lambda lc: lc)
 
 
-def index(ctx: Context, curve, circuit):
-    """AHP::index (indexer.rs:70-117) + compose_matrix_polynomials (arithmetic.rs:98-172)."""
+def index_matrices(curve, circuit):
+    """Host half of AHP::index (indexer.rs:70-96): synthesis, make_matrices_square, balance_matrices, per-row column
+    sort.  -> (constraint system, [a, b, c]) with rows as lists of (coeff, column)."""
     c = get_curve(curve)
-    r = c.r
-    dev = Dev(ctx, c)
     cs = MarlinCS(c, assign=False)
     circuit.generate_constraints(cs)
     cs.make_matrices_square()
@@ -181,6 +180,16 @@ def index(ctx: Context, curve, circuit):
     for m in mats:
         for row in m:
             row.sort(key=lambda t: t[1])
+    return cs, mats
+
+
+def index(ctx: Context, curve, circuit):
+    """AHP::index (indexer.rs:70-117) + compose_matrix_polynomials (arithmetic.rs:98-172)."""
+    c = get_curve(curve)
+    r = c.r
+    dev = Dev(ctx, c)
+    cs, mats = index_matrices(c, circuit)
+    a, b, cc = mats
     nnz = max(sum(map(len, m)) for m in mats)
     nvars = cs.num_inputs + cs.num_aux
     xs, _ = _domain(c, cs.num_inputs)

@@ -246,6 +246,48 @@ def _csr_upload(be: DeviceBackend, ptr, col, cf_mont):
             be.upload_raw(np.ascontiguousarray(cf, dtype=np.uint64)))
 
 
+def prepare_matrices(inst):
+    """make_matrices_square + balance_matrices + per-row column sort on CSR index arrays (pure host code).
+    -> (n rows = columns, padding variables added, [(row_ptr, col, coeff_mont, row_of_entry)] for A, B, C)"""
+    nv, nc = inst.num_inputs + inst.num_aux, inst.num_constraints()
+    pad_aux = max(nc - nv, 0)                   # make_matrices_square: dummy variables (value one) ...
+    n = max(nv, nc)                             # ... or empty constraints
+    mats = []
+    for ptr, col, cf in (inst.csr("a"), inst.csr("b"), inst.csr("c")):
+        ptr = np.asarray(ptr, dtype=np.int64)
+        ptr = np.concatenate([ptr, np.full(n - nc, ptr[-1], dtype=np.int64)])
+        mats.append((ptr, np.asarray(col, dtype=np.int64), np.asarray(cf, dtype=np.uint64).reshape(-1, 4)))
+    # balance_matrices (constraint_systems.rs): greedy row swaps while A is the denser matrix
+    la, lb = np.diff(mats[0][0]).tolist(), np.diff(mats[1][0]).tolist()
+    da, db_ = sum(la), sum(lb)
+    swap = np.zeros(n, dtype=bool)
+    denser = da > db_
+    for i in range(n):
+        if not denser:
+            break
+        swap[i] = True
+        da += lb[i] - la[i]
+        db_ += la[i] - lb[i]
+        denser = da > db_
+
+    def select(mask, P, Q):
+        lp, lq = np.diff(P[0]), np.diff(Q[0])
+        ln = np.where(mask, lp, lq)
+        ptr = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+        start = np.where(mask, P[0][:-1], Q[0][:-1] + len(P[1]))
+        src = np.repeat(start, ln) + (np.arange(ptr[-1]) - np.repeat(ptr[:-1], ln))
+        return ptr, np.concatenate([P[1], Q[1]])[src], np.concatenate([P[2], Q[2]])[src]
+
+    if swap.any():
+        mats[0], mats[1] = select(swap, mats[1], mats[0]), select(swap, mats[0], mats[1])
+    sorted_mats = []
+    for ptr, col, cf in mats:
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ptr))
+        order = np.lexsort((col, rows))         # stable: by row, then by column (`row.sort_by_key(col)`)
+        sorted_mats.append((ptr, col[order], cf[order], rows))
+    return n, pad_aux, sorted_mats
+
+
 class DeviceIndex:
     """Prover-side index resident in HBM.  Built either from a host index (`marlin.index`, small circuits / tests) or
     directly from array-form matrices (`from_instance`), in which case the arithmetization itself — row/col/val over K,
@@ -304,45 +346,12 @@ class DeviceIndex:
     @classmethod
     def from_instance(cls, ctx: Context, inst):
         """AHP::index (indexer.rs:70-117) on array-form matrices: make_matrices_square, balance_matrices, per-row
-        column sort, then compose_matrix_polynomials on the device.  inst: r1cs.R1csInstance (CSR, Montgomery coeffs)."""
+        column sort (prepare_matrices, host index arrays), then compose_matrix_polynomials on the device.
+        inst: r1cs.R1csInstance (CSR, Montgomery coeffs)."""
         self = cls(ctx, inst.curve)
         be, c = self.be, self.curve
-        ni, nv, nc = inst.num_inputs, inst.num_inputs + inst.num_aux, inst.num_constraints()
-        self.pad_aux = max(nc - nv, 0)              # make_matrices_square: dummy variables (value one) ...
-        n = max(nv, nc)                             # ... or empty constraints
-        mats = []
-        for ptr, col, cf in (inst.csr("a"), inst.csr("b"), inst.csr("c")):
-            ptr = np.asarray(ptr, dtype=np.int64)
-            ptr = np.concatenate([ptr, np.full(n - nc, ptr[-1], dtype=np.int64)])
-            mats.append((ptr, np.asarray(col, dtype=np.int64), np.asarray(cf, dtype=np.uint64).reshape(-1, 4)))
-        # balance_matrices (constraint_systems.rs): greedy row swaps while A is the denser matrix
-        la, lb = np.diff(mats[0][0]).tolist(), np.diff(mats[1][0]).tolist()
-        da, db_ = sum(la), sum(lb)
-        swap = np.zeros(n, dtype=bool)
-        denser = da > db_
-        for i in range(n):
-            if not denser:
-                break
-            swap[i] = True
-            da += lb[i] - la[i]
-            db_ += la[i] - lb[i]
-            denser = da > db_
-
-        def select(mask, P, Q):
-            lp, lq = np.diff(P[0]), np.diff(Q[0])
-            ln = np.where(mask, lp, lq)
-            ptr = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
-            start = np.where(mask, P[0][:-1], Q[0][:-1] + len(P[1]))
-            src = np.repeat(start, ln) + (np.arange(ptr[-1]) - np.repeat(ptr[:-1], ln))
-            return ptr, np.concatenate([P[1], Q[1]])[src], np.concatenate([P[2], Q[2]])[src]
-
-        if swap.any():
-            mats[0], mats[1] = select(swap, mats[1], mats[0]), select(swap, mats[0], mats[1])
-        sorted_mats = []
-        for ptr, col, cf in mats:
-            rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ptr))
-            order = np.lexsort((col, rows))         # stable: by row, then by column (`row.sort_by_key(col)`)
-            sorted_mats.append((ptr, col[order], cf[order], rows))
+        ni = inst.num_inputs
+        n, self.pad_aux, sorted_mats = prepare_matrices(inst)
         nnz = max(int(m[0][-1]) for m in sorted_mats)
         xs, hs, ks = _next_pow2(ni), _next_pow2(n), _next_pow2(nnz)
         bs = _next_pow2(3 * ks - 3)

@@ -137,7 +137,14 @@ def test_batch_prove_equals_sequential(ctx):
         pk.free()
 
 
-@pytest.mark.parametrize("curve,k", [("bn254", 20), ("bls12_381", 20), ("bls12_381", 22)])
+import os as _os
+
+_FULL = [("bn254", 20), ("bls12_381", 20), ("bls12_381", 22)]
+if _os.environ.get("ZKP_TEST_2P24"):          # configs[4]'s instance on ONE GPU: ~6 minutes, ~100 GB of HBM
+    _FULL.append(("bn254", 24))
+
+
+@pytest.mark.parametrize("curve,k", _FULL)
 def test_full_size_proof_trapdoor_and_pipeline(ctx, curve, k):
     """BASELINE.json configs[1] at FULL size (1 048 570 constraints, domain 2^20, BN254), the same instance over
     BLS12-381, and configs[2] at full size (4 194 300 constraints, domain 2^22, BLS12-381): the device proof equals the proof computed in the exponent from the toxic waste (size-independent check,

@@ -81,3 +81,43 @@ def test_qap_exponents_match_oracle_instance_map(curve):
     og.MimcChain(OC[curve], inst.constants, inst.preimages).generate_constraints(ocs)
     oa, ob, oc, ozt, _, oN = og.instance_map_with_evaluation(ocs, 0x3333333333333333335)
     assert (a, b, c_, zt, N) == (oa, ob, oc, ozt, oN)
+
+
+def test_marlin_array_indexer_matches_constraint_by_constraint_synthesis():
+    """marlin_dev.prepare_matrices (make_matrices_square + balance_matrices + column sort on CSR index arrays) yields the
+    matrices marlin.index_matrices builds row by row (ahp/constraint_systems.rs:9-31,100-114), incl. the case where A is
+    denser and rows are swapped, and the case with more constraints than variables (padding variables)."""
+    from ckb_zkp_amd import codec, marlin, marlin_dev
+    from ckb_zkp_amd.circuits import MimcChain, mimc_chain_instance
+    from ckb_zkp_amd.params import get_curve
+    from ckb_zkp_amd.r1cs import R1csInstance
+
+    class SwapAB:
+        def __init__(self, inner):
+            self.inner = inner
+
+        def generate_constraints(self, cs):
+            class Proxy:
+                def __getattr__(self, name):
+                    return getattr(cs, name)
+
+                def enforce(self, a, b, c):
+                    return cs.enforce(b, a, c)
+            self.inner.generate_constraints(Proxy())
+
+    for curve, samples, swap in (("bn254", 5, False), ("bls12_381", 3, False), ("bn254", 9, True)):
+        c = get_curve(curve)
+        inst = mimc_chain_instance(curve, samples, seed=5)
+        circ = MimcChain(curve, inst.constants, [(None, None)] * samples)
+        if swap:
+            inst = R1csInstance(curve, inst.num_inputs, inst.num_aux, inst.num_constraints(), inst.csr("b"), inst.csr("a"),
+                                inst.csr("c"), inst.z)
+            circ = SwapAB(circ)
+        cs, mats = marlin.index_matrices(curve, circ)
+        n, pad_aux, arr = marlin_dev.prepare_matrices(inst)
+        assert n == len(mats[0]) == cs.num_inputs + cs.num_aux and pad_aux == 0
+        for want, (ptr, col, cf, rows) in zip(mats, arr):
+            vals = codec.fr_from_mont(cf, c)
+            got = [[(vals[k], int(col[k])) for k in range(ptr[i], ptr[i + 1])] for i in range(n)]
+            assert got == want
+            assert rows.tolist() == [i for i in range(n) for _ in range(ptr[i + 1] - ptr[i])]
