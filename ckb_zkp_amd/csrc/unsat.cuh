@@ -22,10 +22,12 @@ struct UnsatCfg;
 template <>
 struct UnsatCfg<Bn254Fq> {
   static constexpr int L = 9, B = 29;
+  static constexpr int MULCAP = 128;                        // floor(R' / p) = 169: products of (KA p) x (KB p) with KA KB <= 128 stay < 2p
 };
 template <>
 struct UnsatCfg<Bls381Fq> {
   static constexpr int L = 14, B = 28;
+  static constexpr int MULCAP = 2500;                       // floor(R' / p) = 2519
 };
 
 template <class P>
@@ -43,7 +45,7 @@ struct Fu {
   static constexpr int PBITS = pbits();
   uint32_t v[L];
 
-  static constexpr int KMAX = 10;                           // multiples of p kept as limb tables
+  static constexpr int KMAX = 48;                           // multiples of p kept as limb tables
   struct Tab {
     uint32_t mp[KMAX + 1][L];                               // limbs of M * p (top limb unmasked)
     uint32_t one[L];                                        // R' mod p = canonical "1" of this representation
@@ -105,6 +107,12 @@ struct Fu {
   static constexpr Tab TAB = make_tab();
   static constexpr uint32_t mp_limb(int M, int i) { return TAB.mp[M][i]; }
   static constexpr uint32_t ninv() { return TAB.ninv; }
+  ZKP_DEV static Fu zero() {
+    Fu r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.v[i] = 0;
+    return r;
+  }
   ZKP_DEV static Fu one() {
     Fu r;
 #pragma unroll
@@ -201,6 +209,22 @@ struct Fu {
     }
     return r;
   }
+  // a + b, normalised
+  ZKP_DEV static Fu add(const Fu& a, const Fu& b) {
+    Fu r;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      uint32_t t = a.v[i] + b.v[i] + carry;
+      if (i < L - 1) {
+        r.v[i] = t & MASK;
+        carry = t >> B;
+      } else {
+        r.v[i] = t;
+      }
+    }
+    return r;
+  }
   // 2a, normalised
   ZKP_DEV Fu dbl() const {
     Fu r;
@@ -243,7 +267,8 @@ struct UB {
 template <class P>
 struct UBLimits {
   // p / R' <= 2^-(L*B - bits(p)):  BN254 2^-7, BLS12-381 2^-11
-  static constexpr int MULCAP = 1 << (Fu<P>::L * Fu<P>::B - Fu<P>::PBITS);
+  static constexpr int MULCAP = UnsatCfg<P>::MULCAP;
+  static_assert(MULCAP < (1 << (Fu<P>::L * Fu<P>::B - Fu<P>::PBITS + 1)), "MULCAP must be below R' / p");
   static constexpr int CAPK = MULCAP;                      // K*p < 2^(L*B) with the same margin
 };
 template <class P, int KA, int KB>
@@ -256,6 +281,11 @@ ZKP_DEV UB<P, KA + KB> ub_sub(const UB<P, KA>& a, const UB<P, KB>& b) {
   static_assert(KB <= Fu<P>::KMAX, "no table entry for this multiple of p");
   static_assert(KA + KB <= UBLimits<P>::CAPK, "value would outgrow the limbs");
   return {Fu<P>::template sub<KB>(a.f, b.f)};
+}
+template <class P, int KA, int KB>
+ZKP_DEV UB<P, KA + KB> ub_add(const UB<P, KA>& a, const UB<P, KB>& b) {
+  static_assert(KA + KB <= UBLimits<P>::CAPK, "value would outgrow the limbs");
+  return {Fu<P>::add(a.f, b.f)};
 }
 template <class P, int KA>
 ZKP_DEV UB<P, 2 * KA> ub_dbl(const UB<P, KA>& a) {
@@ -307,5 +337,10 @@ ZKP_DEV bool xyzz_madd_u(XYZZu<P>& acc, const Fu<P>& ux_, const Fu<P>& uy_) {
   acc.y = y3;
   return true;
 }
+
+// (An Fq2 layer on these types — Karatsuba products <4p, 6p>, complex squarings <2p, 4p>, accumulator bounds x <14p, 22p>,
+//  y <8p, 12p> closed without reductions, window table stored as x * R' — was built for BLS12-381 G2, where p / R' = 2^-11
+//  leaves room for the Karatsuba sums.  Bit-exact, but 391 VGPRs and only 5 % faster than the saturated G2 kernel (24.3 vs
+//  25.5 ms for the 2^22 B2 MSM) and slower end to end (15.9 vs 16.4 proofs/s): removed, see DESIGN.md.)
 
 }  // namespace zkp
