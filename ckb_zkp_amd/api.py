@@ -234,11 +234,10 @@ def poly_div_linear(self, curve, p_dev: int, n: int, z_mont: np.ndarray, q_dev: 
 
 
 def _bases_msm_mont_dev(self, scalars_dev: int, n: int, offset: int = 0) -> np.ndarray:
-    """MSM of device-resident Montgomery Fr coefficients against powers[offset..] (KZG10 commit/open)."""
-    assert self.group == 1
+    """MSM of device-resident Montgomery Fr scalars against bases[offset..] (KZG10 commit/open; sharded queries)."""
     out = self._out()
-    _lib.check(self.ctx.lib.zkp_msm_g1_mont_dev(self.ctx.h, self.handle, offset, C.c_void_p(scalars_dev), n, _ptr(out)),
-               "zkp_msm_g1_mont_dev")
+    fn = self.ctx.lib.zkp_msm_g1_mont_dev if self.group == 1 else self.ctx.lib.zkp_msm_g2_mont_dev
+    _lib.check(fn(self.ctx.h, self.handle, offset, C.c_void_p(scalars_dev), n, _ptr(out)), "zkp_msm_mont_dev")
     return out
 
 

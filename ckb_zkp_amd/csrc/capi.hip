@@ -270,6 +270,9 @@ int32_t zkp_msm_g1_mont_dev(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t
   return msm_common(ctx, 1, h, off, s, n, out, true, true);
 }
 
+int32_t zkp_msm_g2_mont_dev(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t* s, size_t n, uint64_t* out) {
+  return msm_common(ctx, 2, h, off, s, n, out, true, true);
+}
 int32_t zkp_msm_g1_mont_batch_dev(zkp_ctx* ctx, uint64_t h, size_t count, const size_t* offsets,
                                   const uint64_t* const* scalars_dev, const size_t* ns, uint64_t* out_xyz) {
   if (count && (!offsets || !scalars_dev || !ns || !out_xyz)) return ZKP_ERR_BAD_ARG;

@@ -40,6 +40,10 @@ class GpuEngine:
         # Montgomery scalars: into_repr() is fused into the device digit scan
         return handle.vartime_multiscalar_mul(scalars_mont)
 
+    def msm_dev(self, handle, scalars_dev: int, n: int):
+        """scalars already resident in HBM (Montgomery): no PCIe traffic in the step"""
+        return handle.msm_mont_dev(scalars_dev, n)
+
     def fold(self, curve, group, stacked):
         return self.ctx.fold(curve, group, stacked)
 
@@ -73,6 +77,12 @@ class ShardedBases:
         n = min(self.n, scalars_mont.shape[0])           # ark min(len) truncation
         lo, hi = min(self.lo, n), min(self.hi, n)
         return self.engine.msm(self.handle, np.ascontiguousarray(scalars_mont[lo:hi]))
+
+    def partial_dev(self, scalars_dev: int, n_scalars: int) -> np.ndarray:
+        """the same on a device-resident scalar vector (pointer to element 0, Montgomery, n_scalars elements)"""
+        n = min(self.n, n_scalars)
+        lo, hi = min(self.lo, n), min(self.hi, n)
+        return self.engine.msm_dev(self.handle, scalars_dev + 32 * lo, hi - lo)
 
     def msm(self, scalars_mont: np.ndarray) -> np.ndarray:
         """Full MSM, identical on every rank: partial -> all-gather -> fold."""
@@ -125,6 +135,23 @@ class ShardedGroth16Prover:
         for o, w, g in offs:
             out.append(self.engine.fold(self.curve, g, np.ascontiguousarray(gathered[:, o:o + w]).reshape(-1)))
         return np.concatenate(out)
+
+    def prove_sums_dev(self, ctx, pk_m, z_dev: int, r: int, s: int) -> np.ndarray:
+        """Device-resident step: z stays in HBM, the witness map runs on the device (replicated), every partial MSM reads its
+        slice of S = z ++ [1, r, s, -rs] / h in place; only 5 partial points leave the device before the all-gather."""
+        c = self.curve
+        nz = self.inst.num_inputs + self.inst.num_aux
+        if getattr(self, "_S", None) is None:
+            self._S = ctx.dev_alloc((nz + 4) * 32)
+            self._h = ctx.dev_alloc(pk_m.domain_size * 32)
+        ctx.d2d(self._S, z_dev, nz * 32)
+        ctx.h2d(self._S + nz * 32, codec.fr_to_mont([1, r, s, (-(r * s)) % c.r], c).reshape(4, 4))
+        pk_m.witness_map_dev(z_dev, self._h)
+        ni = self.inst.num_inputs
+        part = np.concatenate([self.A.partial_dev(self._S, nz + 4), self.B1.partial_dev(self._S, nz + 4),
+                               self.B2.partial_dev(self._S, nz + 4), self.H.partial_dev(self._h, pk_m.domain_size),
+                               self.L.partial_dev(self._S + 32 * ni, nz + 4 - ni)])
+        return self.fold_sums(all_gather_points(part, self.world, self.device))
 
     def prove_sums(self, z_mont, r: int, s: int) -> np.ndarray:
         h = self.witness_mapper(z_mont)

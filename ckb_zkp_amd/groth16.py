@@ -215,6 +215,11 @@ class ProvingKey:
         _lib.check(self.ctx.lib.zkp_groth16_witness_map(self.ctx.h, self.h, _ptr(z), _ptr(h)), "zkp_groth16_witness_map")
         return h
 
+    def witness_map_dev(self, z_dev: int, h_dev: int):
+        """device pointers in and out (domain_size Fr written at h_dev)"""
+        _lib.check(self.ctx.lib.zkp_groth16_witness_map_dev(self.ctx.h, self.h, C.c_void_p(z_dev), C.c_void_p(h_dev)),
+                   "zkp_groth16_witness_map_dev")
+
     def prove_raw(self, z, r_mont: np.ndarray, s_mont: np.ndarray, z_on_device: bool = False):
         """-> (proof limbs uint64, identity flags[3])."""
         c = self.curve

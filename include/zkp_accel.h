@@ -133,6 +133,8 @@ int32_t zkp_vartime_multiscalar_mul_g2(zkp_ctx* ctx, uint64_t handle, const uint
  * on the DEVICE against powers[offset ..] (offset = number of skipped leading zeros) */
 int32_t zkp_msm_g1_mont_dev(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* fr_scalars_dev, size_t n,
                             uint64_t* out_xyz_host);
+int32_t zkp_msm_g2_mont_dev(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* fr_scalars_dev, size_t n,
+                            uint64_t* out_xyz_host);
 /* PC::commit over a LIST of polynomials (marlin/src/pc/mod.rs:34-71; one KZG10::commit = one MSM each, kzg10.rs:100-123):
  * `count` MSMs of device-resident Montgomery coefficient vectors against powers[offsets[k] ..], min(ns[k], len - offset)
  * terms each, three in flight at a time on the context's MSM streams.  out_xyz: count Jacobian results. */

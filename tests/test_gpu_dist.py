@@ -34,6 +34,23 @@ def test_sharded_prover_equals_single_gpu_prover(ctx, curve, k, world):
         sums = provers[0].fold_sums(parts)
         out2, inf2 = groth16.assemble(ctx, c, sums, r_, s_)
         assert np.array_equal(out1, out2) and np.array_equal(inf1, inf2)
+        # device-resident step (world 1: the whole path on one rank, no host scalars): same proof
+        solo = ShardedGroth16Prover(eng, params, inst, 0, 1, witness_mapper=pk_m.witness_map)
+        zd = ctx.to_device(z)
+        out3, inf3 = groth16.assemble(ctx, c, solo.prove_sums_dev(ctx, pk_m, zd, r_, s_), r_, s_)
+        assert np.array_equal(out1, out3) and np.array_equal(inf1, inf3)
+        # ... and the partial sums of the sharded ranks computed from device-resident scalars
+        S = ctx.to_device(np.concatenate([z, codec.fr_to_mont([1, r_, s_, (-(r_ * s_)) % c.r], c).reshape(4, 4)]))
+        nz = z.shape[0]
+        for pr, want in zip(provers, parts):
+            got = pr.A.partial_dev(S, nz + 4)
+            wa = want[:got.shape[0]]
+            assert ctx.into_affine(c, 1, got)[0].tolist() == ctx.into_affine(c, 1, wa)[0].tolist()
+            f = c.fq_limbs
+            got2 = pr.B2.partial_dev(S, nz + 4)
+            assert ctx.into_affine(c, 2, got2)[0].tolist() == ctx.into_affine(c, 2, want[6 * f:12 * f])[0].tolist()
+        ctx.dev_free(zd)
+        ctx.dev_free(S)
         # matrices-only key refuses to prove
         from ckb_zkp_amd._lib import ZkpError
         with pytest.raises(ZkpError):
