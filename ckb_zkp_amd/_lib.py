@@ -74,6 +74,7 @@ SIGNATURES = {
     "zkp_msm_g1_mont_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
     "zkp_msm_g2_mont_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
     "zkp_msm_g1_mont_batch_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, vp, vp, vp]),
+    "zkp_msm_mont_multi_dev": (C.c_int32, [vp, C.c_size_t, vp, vp, vp, vp, vp, C.c_size_t]),
     "zkp_fr_vec_op_dev": (C.c_int32, [vp, C.c_int, C.c_int32, vp, vp, vp, vp, C.c_size_t]),
     "zkp_fr_spmv_dev": (C.c_int32, [vp, C.c_int, vp, vp, vp, C.c_size_t, vp, vp]),
     "zkp_fr_gather_dev": (C.c_int32, [vp, vp, vp, C.c_size_t, vp]),

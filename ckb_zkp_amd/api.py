@@ -295,3 +295,20 @@ def d2d(self, dst_dev: int, src_dev: int, nbytes: int):
 @_ctx_method
 def dev_zero(self, dst_dev: int, nbytes: int):
     _lib.check(self.lib.zkp_dev_zero(self.h, C.c_void_p(dst_dev), nbytes), "zkp_dev_zero")
+
+
+@_ctx_method
+def msm_mont_multi_dev(self, jobs) -> list:
+    """jobs = [(Bases, scalars_dev, n, offset)] with possibly different (G1 / G2) base vectors -> list of Jacobian limb
+    arrays; the MSMs run four at a time on the context's MSM streams (zkp_msm_mont_multi_dev)."""
+    k = len(jobs)
+    if k == 0:
+        return []
+    slot = max(3 * b.curve.fq_limbs * (1 if b.group == 1 else 2) for b, *_ in jobs)
+    out = np.zeros((k, slot), dtype=np.uint64)
+    handles = (C.c_uint64 * k)(*[b.handle for b, *_ in jobs])
+    ptrs = (C.c_void_p * k)(*[j[1] for j in jobs])
+    ns = (C.c_size_t * k)(*[j[2] for j in jobs])
+    offs = (C.c_size_t * k)(*[j[3] for j in jobs])
+    _lib.check(self.lib.zkp_msm_mont_multi_dev(self.h, k, handles, offs, ptrs, ns, _ptr(out), slot), "zkp_msm_mont_multi_dev")
+    return [out[i, :3 * b.curve.fq_limbs * (1 if b.group == 1 else 2)].copy() for i, (b, *_) in enumerate(jobs)]

@@ -282,6 +282,13 @@ int32_t zkp_msm_g1_mont_batch_dev(zkp_ctx* ctx, uint64_t h, size_t count, const 
   });
 }
 
+int32_t zkp_msm_mont_multi_dev(zkp_ctx* ctx, size_t count, const uint64_t* handles, const size_t* offsets,
+                               const uint64_t* const* scalars_dev, const size_t* ns, uint64_t* out_xyz,
+                               size_t slot_u64) {
+  if (count && (!handles || !offsets || !scalars_dev || !ns || !out_xyz)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { msm_run_multi(ctx, count, handles, offsets, scalars_dev, ns, true, out_xyz, 2 * slot_u64); });
+}
+
 // ------------------------------------------------------------------------------------------- Fr vectors / polynomials
 int32_t zkp_fr_vec_op_dev(zkp_ctx* ctx, zkp_curve_t curve, int32_t op, const uint64_t* a, const uint64_t* b,
                           const uint64_t* k, uint64_t* out, size_t n) {

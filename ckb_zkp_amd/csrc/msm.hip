@@ -597,11 +597,13 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
 // `count` MSMs against ONE resident base vector (different offsets / lengths / scalar vectors), three in flight at a
 // time: one per MSM workspace (stream + scratch) of the current lane, so that the latency-bound bucket-reduction tail
 // of one overlaps the throughput-bound kernels of the next.  Results (Jacobian) land in out_xyz_host[k * 3 * fN u64].
-void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* offsets, const uint64_t* const* scalars_dev,
-                   const size_t* ns, bool montgomery, uint64_t* out_xyz_host) {
+// handles[k]: the resident base vector of job k (G1 and G2 may be mixed); every result occupies a slot of `slot_words` 32-bit
+// words in out_xyz_host (>= the Jacobian size of the job's group), its Jacobian limbs at the start of the slot
+void msm_run_multi(zkp_ctx* ctx, size_t count, const uint64_t* handles, const size_t* offsets,
+                   const uint64_t* const* scalars_dev, const size_t* ns, bool montgomery, uint64_t* out_xyz_host,
+                   size_t slot_words) {
   if (count == 0) return;
-  auto be = get_bases(ctx, handle);
-  const size_t jw = 3 * (size_t)be->vt->fN;                       // 32-bit words per Jacobian result
+  const size_t jw = slot_words;
   zkp_lane* L = ctx->cur;
   if (ctx->pinned_cap < count * jw * 4) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -629,12 +631,15 @@ void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* of
       if (stream_of(li, w) != L->stream) ZKP_HIP(hipStreamWaitEvent(stream_of(li, w), L->ev_fork, 0));
   for (size_t k = 0; k < count; k++) {
     const int li = (int)((k / NW) % NL), w = (int)(k % NW);
+    auto be = get_bases(ctx, handles[k]);
+    const size_t words = 3 * (size_t)be->vt->fN;                  // 32-bit words of this job's Jacobian result
+    ZKP_REQUIRE(words <= jw, ZKP_ERR_BAD_ARG);
     ZKP_REQUIRE(offsets[k] <= be->n, ZKP_ERR_BAD_ARG);
     const size_t n = std::min(ns[k], be->n - offsets[k]);        // ark min(len) truncation
     ctx->cur = &ctx->lanes[li];
     ctx->cur_idx = li;
-    msm_run(ctx, handle, offsets[k], scalars_dev[k], n, montgomery, nullptr, nullptr, nullptr, nullptr, w);
-    ZKP_HIP(hipMemcpyAsync(ctx->pinned + k * jw, ctx->lanes[li].ws[w].out.p, jw * 4, hipMemcpyDeviceToHost, stream_of(li, w)));
+    msm_run(ctx, handles[k], offsets[k], scalars_dev[k], n, montgomery, nullptr, nullptr, nullptr, nullptr, w);
+    ZKP_HIP(hipMemcpyAsync(ctx->pinned + k * jw, ctx->lanes[li].ws[w].out.p, words * 4, hipMemcpyDeviceToHost, stream_of(li, w)));
   }
   ctx->cur = restore.cur;
   ctx->cur_idx = restore.idx;
@@ -646,6 +651,14 @@ void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* of
     }
   ZKP_HIP(hipStreamSynchronize(L->stream));
   memcpy(out_xyz_host, ctx->pinned, count * jw * 4);
+}
+
+void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* offsets, const uint64_t* const* scalars_dev,
+                   const size_t* ns, bool montgomery, uint64_t* out_xyz_host) {
+  if (count == 0) return;
+  std::vector<uint64_t> handles(count, handle);
+  msm_run_multi(ctx, count, handles.data(), offsets, scalars_dev, ns, montgomery, out_xyz_host,
+                3 * (size_t)get_bases(ctx, handle)->vt->fN);
 }
 
 void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz, size_t k, uint64_t* out) {

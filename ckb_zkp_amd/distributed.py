@@ -148,9 +148,14 @@ class ShardedGroth16Prover:
         ctx.h2d(self._S + nz * 32, codec.fr_to_mont([1, r, s, (-(r * s)) % c.r], c).reshape(4, 4))
         pk_m.witness_map_dev(z_dev, self._h)
         ni = self.inst.num_inputs
-        part = np.concatenate([self.A.partial_dev(self._S, nz + 4), self.B1.partial_dev(self._S, nz + 4),
-                               self.B2.partial_dev(self._S, nz + 4), self.H.partial_dev(self._h, pk_m.domain_size),
-                               self.L.partial_dev(self._S + 32 * ni, nz + 4 - ni)])
+        # the five partial MSMs of this rank in ONE call (four in flight on the context's MSM streams)
+        jobs = []
+        for sb, ptr, cnt in ((self.A, self._S, nz + 4), (self.B1, self._S, nz + 4), (self.B2, self._S, nz + 4),
+                             (self.H, self._h, pk_m.domain_size), (self.L, self._S + 32 * ni, nz + 4 - ni)):
+            n = min(sb.n, cnt)
+            lo, hi = min(sb.lo, n), min(sb.hi, n)
+            jobs.append((sb.handle, ptr + 32 * lo, hi - lo, 0))
+        part = np.concatenate(ctx.msm_mont_multi_dev(jobs))
         return self.fold_sums(all_gather_points(part, self.world, self.device))
 
     def prove_sums(self, z_mont, r: int, s: int) -> np.ndarray:

@@ -140,6 +140,11 @@ int32_t zkp_msm_g2_mont_dev(zkp_ctx* ctx, uint64_t handle, size_t offset, const 
  * terms each, three in flight at a time on the context's MSM streams.  out_xyz: count Jacobian results. */
 int32_t zkp_msm_g1_mont_batch_dev(zkp_ctx* ctx, uint64_t bases_handle, size_t count, const size_t* offsets,
                                   const uint64_t* const* scalars_dev, const size_t* ns, uint64_t* out_xyz);
+/* The same for MSMs against DIFFERENT resident base vectors (G1 and G2 mixed): the five partial MSMs of a base-sharded
+ * Groth16 proof (prover.rs:164-190) in one call, four in flight.  Result k is written at out_xyz + k * slot_u64 (its
+ * Jacobian limbs first); slot_u64 >= 3 * limbs of the largest group involved (18 for BN254 G2, 36 for BLS12-381 G2). */
+int32_t zkp_msm_mont_multi_dev(zkp_ctx* ctx, size_t count, const uint64_t* bases_handles, const size_t* offsets,
+                               const uint64_t* const* scalars_dev, const size_t* ns, uint64_t* out_xyz, size_t slot_u64);
 /* fold k Jacobian points (host) into one: the local step after the multi-GPU all-gather of partial MSM
  * results (EC addition is not an RCCL reduction op) */
 int32_t zkp_g1_fold(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz);
