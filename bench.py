@@ -42,14 +42,13 @@ def log(*a):
 
 def bench_sharded(args, ctx, c, inst, params, z, rank, world, local):
     """BASELINE configs[4]: one proof per step; every query is split by index over the ranks (each rank keeps 1/N of the
-    key resident), partial MSM results are all-gathered and folded, the NTTs are replicated.  Host-driven first version:
-    The witness, S = z ++ [1, r, s, -rs] and h stay in HBM; 5 partial points per rank leave the device."""
+    key resident), the partial MSM results are all-gathered (device tensors, RCCL) and folded + assembled on the device;
+    the NTTs are replicated.  Nothing but the 3 proof points leaves HBM inside a step."""
     import torch
-    from ckb_zkp_amd import groth16
-    from ckb_zkp_amd.distributed import GpuEngine, ShardedGroth16Prover
-    device = None if (args.single_device_test or world == 1) else torch.device("cuda", local)
-    pk_m = groth16.ProvingKey(ctx, params, inst, matrices_only=True)
-    prover = ShardedGroth16Prover(GpuEngine(ctx), params, inst, rank, world, device=device, witness_mapper=pk_m.witness_map)
+    from ckb_zkp_amd.distributed import DeviceShardedGroth16Prover
+    device = torch.device("cuda", local)
+    prover = DeviceShardedGroth16Prover(ctx, params, inst, rank, world, device=device,
+                                        transport="gloo" if args.single_device_test else "nccl")
     r_, s_ = 0x1234567, 0x7654321
 
     def barrier():
@@ -62,8 +61,9 @@ def bench_sharded(args, ctx, c, inst, params, z, rank, world, local):
     z_dev = ctx.to_device(z)                                    # witness resident in HBM before the timed region
 
     def step():
-        sums = prover.prove_sums_dev(ctx, pk_m, z_dev, r_, s_)
-        return groth16.assemble(ctx, c, sums, r_, s_)
+        # partial MSMs (this rank's 1/world of every query) -> all_gather_into_tensor on device buffers (RCCL) ->
+        # fold + assembly on the device; only the 3 affine proof points come back to the host
+        return prover.prove(z_dev, r_, s_)
 
     for _ in range(args.warmup):
         step()
@@ -88,7 +88,8 @@ def bench_sharded(args, ctx, c, inst, params, z, rank, world, local):
             "config": {"workload": f"Groth16 prove, MiMC-chain R1CS, {inst.num_constraints()} constraints, {c.name}, "
                                    f"queries sharded {world}-way by index, all-gather of 5 partial points + fold",
                        "curve": c.name, "log_domain": args.log_n, "parallelism": f"base-sharded x{world}",
-                       "note": "witness and h resident in HBM; MSMs of one rank run back to back on one stream"},
+                       "note": "witness, h, partial sums and the gathered buffer resident in HBM; NTT pipeline replicated per rank; "
+                               "per step: zkp_groth16_prove_partials_dev -> all_gather_into_tensor -> zkp_groth16_fold_assemble_dev"},
             "roofline": None, "cpu_baseline": None}), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -366,6 +366,26 @@ int32_t zkp_groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, zkp
   if (!desc || !out) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { *out = groth16_pk_upload(ctx, desc); });
 }
+int32_t zkp_groth16_pk_upload_shard(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, int32_t rank, int32_t world,
+                                    zkp_groth16_pk** out) {
+  if (!desc || !out || world < 1 || rank < 0 || rank >= world) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { *out = groth16_pk_upload(ctx, desc, rank, world); });
+}
+int32_t zkp_groth16_partials_bytes(zkp_curve_t curve, size_t* bytes) {
+  if (!bytes || (curve != ZKP_BN254 && curve != ZKP_BLS12_381)) return ZKP_ERR_BAD_ARG;
+  *bytes = groth16_partials_bytes(curve);
+  return ZKP_OK;
+}
+int32_t zkp_groth16_prove_partials_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_dev, const uint64_t* r,
+                                       const uint64_t* s, void* partials_dev) {
+  if (!pk || !z_dev || !r || !s || !partials_dev) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_prove_partials(ctx, pk, z_dev, r, s, partials_dev); });
+}
+int32_t zkp_groth16_fold_assemble_dev(zkp_ctx* ctx, zkp_curve_t curve, const void* gathered_dev, int32_t world,
+                                      const uint64_t* r, const uint64_t* s, uint64_t* proof, uint8_t* inf) {
+  if (!gathered_dev || world < 1 || !r || !s || !proof || !inf) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_fold_assemble(ctx, curve, gathered_dev, world, r, s, proof, inf); });
+}
 int32_t zkp_groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk) {
   if (!pk) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { groth16_pk_free(ctx, pk); });

@@ -49,6 +49,10 @@ struct zkp_groth16_pk {
   DevCsr m[3];
   uint64_t hA = 0, hB1 = 0, hB2 = 0, hH = 0, hL = 0;
   bool share_b_sort = false;     // b_g1_query / b_g2_query: same length, window configuration and identity pattern
+  // Base-sharded key (BASELINE configs[4]): this rank holds elements [q_lo, q_lo + q_n) of every
+  // (extended) query; world == 0 means the whole key.  Index order: A, B1, B2, H, L.
+  int shard_rank = 0, shard_world = 0;
+  size_t q_lo[5] = {0, 0, 0, 0, 0}, q_n[5] = {0, 0, 0, 0, 0};
   struct PerLane {   // per in-flight proof (zkp_ctx lanes)
     DevBuf abc;      // 3 * N Fr
     DevBuf S;        // nz + 4 Fr
@@ -144,23 +148,43 @@ static DevCsr upload_csr(zkp_ctx* ctx, const zkp_csr& m, uint32_t rows) {
 }
 
 // query ++ tail points (tail entry nullptr = identity)
-static uint64_t upload_ext(zkp_ctx* ctx, int curve, int group, const uint64_t* q, const uint8_t* inf, size_t n,
-                           size_t limbs_per_point, const uint64_t* const tail[4]) {
-  std::vector<uint64_t> xy((n + 4) * limbs_per_point, 0);
-  std::vector<uint8_t> fl(n + 4, 0);
-  if (n) memcpy(xy.data(), q, n * limbs_per_point * 8);
-  if (inf && n) memcpy(fl.data(), inf, n);
-  for (int k = 0; k < 4; k++) {
-    if (tail[k]) memcpy(xy.data() + (n + k) * limbs_per_point, tail[k], limbs_per_point * 8);
-    else fl[n + k] = 1;
+// contiguous, balanced index ranges: the first (n % world) ranks get one extra element
+static void shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* cnt) {
+  if (world <= 0) {
+    *lo = 0;
+    *cnt = n;
+    return;
   }
-  return bases_upload(ctx, curve, group, xy.data(), fl.data(), n + 4);
+  const size_t base = n / (size_t)world, rem = n % (size_t)world, r = (size_t)rank;
+  *lo = r * base + std::min(r, rem);
+  *cnt = base + (r < rem ? 1 : 0);
+}
+// only elements [lo, lo + cnt) of the extended query are uploaded (the whole of it for an unsharded key)
+static uint64_t upload_ext(zkp_ctx* ctx, int curve, int group, const uint64_t* q, const uint8_t* inf, size_t n,
+                           size_t limbs_per_point, const uint64_t* const tail[4], size_t lo, size_t cnt) {
+  std::vector<uint64_t> xy(std::max<size_t>(cnt, 1) * limbs_per_point, 0);
+  std::vector<uint8_t> fl(std::max<size_t>(cnt, 1), 0);
+  for (size_t j = 0; j < cnt; j++) {
+    const size_t i = lo + j;
+    if (i < n) {
+      memcpy(xy.data() + j * limbs_per_point, q + i * limbs_per_point, limbs_per_point * 8);
+      fl[j] = inf ? inf[i] : 0;
+    } else if (tail[i - n]) {
+      memcpy(xy.data() + j * limbs_per_point, tail[i - n], limbs_per_point * 8);
+    } else {
+      fl[j] = 1;
+    }
+  }
+  return bases_upload(ctx, curve, group, xy.data(), fl.data(), cnt);
 }
 
-zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d) {
+zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, int rank, int world) {
   ZKP_REQUIRE(d->curve == ZKP_BN254 || d->curve == ZKP_BLS12_381, ZKP_ERR_UNSUPPORTED_CURVE);
   ZKP_REQUIRE(d->num_inputs >= 1, ZKP_ERR_BAD_ARG);
+  ZKP_REQUIRE(world >= 0 && (world == 0 ? rank == 0 : (rank >= 0 && rank < world)), ZKP_ERR_BAD_ARG);
   std::unique_ptr<zkp_groth16_pk> pk(new zkp_groth16_pk());
+  pk->shard_rank = rank;
+  pk->shard_world = world;
   pk->curve = d->curve;
   pk->num_inputs = d->num_inputs;
   pk->num_aux = d->num_aux;
@@ -185,11 +209,20 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d) {
   pk->m[0] = upload_csr(ctx, d->at, d->num_constraints);
   pk->m[1] = upload_csr(ctx, d->bt, d->num_constraints);
   pk->m[2] = upload_csr(ctx, d->ct, d->num_constraints);
+  ZKP_REQUIRE(!(matrices_only && world > 0), ZKP_ERR_BAD_ARG);
   if (!matrices_only) {
     for (auto p : {d->alpha_g1, d->beta_g1, d->delta_g1, d->beta_g2, d->delta_g2}) ZKP_REQUIRE(p, ZKP_ERR_BAD_ARG);
-    pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA);
-    pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1);
-    pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2);
+    // slice of every query this rank keeps resident (everything for an unsharded key).  The H slice is cut from the
+    // min(h_len, N) terms the MSM actually uses (prover.rs:186-187)
+    const size_t h_used = std::min<size_t>(d->h_len, pk->N);
+    shard_bounds(pk->nz + 4, rank, world, &pk->q_lo[0], &pk->q_n[0]);
+    pk->q_lo[1] = pk->q_lo[2] = pk->q_lo[0];
+    pk->q_n[1] = pk->q_n[2] = pk->q_n[0];
+    shard_bounds(h_used, rank, world, &pk->q_lo[3], &pk->q_n[3]);
+    shard_bounds((size_t)d->num_aux + 4, rank, world, &pk->q_lo[4], &pk->q_n[4]);
+    pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA, pk->q_lo[0], pk->q_n[0]);
+    pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1, pk->q_lo[1], pk->q_n[1]);
+    pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2, pk->q_lo[2], pk->q_n[2]);
     {
       // B1 reuses B2's bucket sort + task schedule (same scalars, window configuration and identity pattern): -0.55 ms of
       // memory-bound sort kernels per proof.  With 4 hardware queues this LOST 2 % (84.7 -> 83.0 proofs/s: the wait on
@@ -199,8 +232,9 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d) {
                             (d->b_g1_inf && d->b_g2_inf && memcmp(d->b_g1_inf, d->b_g2_inf, d->b_g1_len) == 0);
       pk->share_b_sort = on && same_inf && bases_same_shape(ctx, pk->hB1, pk->hB2);
     }
-    pk->hH = bases_upload(ctx, d->curve, 1, d->h_query, d->h_inf, d->h_len);
-    pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL);
+    pk->hH = bases_upload(ctx, d->curve, 1, d->h_query ? d->h_query + pk->q_lo[3] * 2 * fq : nullptr,
+                          d->h_inf ? d->h_inf + pk->q_lo[3] : nullptr, world > 0 ? pk->q_n[3] : (size_t)d->h_len);
+    pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL, pk->q_lo[4], pk->q_n[4]);
   }
   uint32_t* consts = pk->consts.as<uint32_t>(64);
   if (d->curve == ZKP_BN254) hipLaunchKernelGGL(qap_consts_kernel<Bn254Fr>, dim3(1), dim3(64), 0, ctx->cur->stream, consts, lg);
@@ -283,19 +317,25 @@ void groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, ui
 // part: 1 = copy the inputs (z, r, s) into the lane's buffers, 2 = everything else (the part a hipGraph captures), 3 = both
 template <class FrP>
 static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
-                               const uint64_t* s, int part) {
+                               const uint64_t* s, int part, char* partial_out = nullptr) {
+  // partial_out != nullptr (base-sharded key): no assembly; the 5 XYZZ sums of this rank's slices (A | B1 | B2 | H | L,
+  // G2-sized slots) are left at partial_out (device) for the all-gather
+  ZKP_REQUIRE((pk->shard_world > 0) == (partial_out != nullptr), ZKP_ERR_BAD_ARG);
   ZKP_REQUIRE(pk->hA != 0, ZKP_ERR_BAD_ARG);             // matrices-only key: use the sharded path
   zkp_groth16_pk::PerLane& PL = pk->lane[ctx->cur_idx];
   hipStream_t st = ctx->cur->stream;
   const bool prof = ctx->profiling;
   zkp_groth16_timing tm{};
-  hipEvent_t e0 = nullptr, e1 = nullptr, eT0 = nullptr, eT1 = nullptr;
-  if (prof) {
-    ZKP_HIP(hipEventCreate(&eT0));
-    ZKP_HIP(hipEventCreate(&eT1));
-    ZKP_HIP(hipEventCreate(&e0));
-    ZKP_HIP(hipEventCreate(&e1));
-  }
+  struct ProfEvents {                                   // destroyed on every exit path (msm_run may throw)
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    ~ProfEvents() {
+      for (hipEvent_t x : e)
+        if (x) (void)hipEventDestroy(x);
+    }
+  } pev;
+  if (prof)
+    for (hipEvent_t& x : pev.e) ZKP_HIP(hipEventCreate(&x));
+  hipEvent_t &e0 = pev.e[0], &e1 = pev.e[1], &eT0 = pev.e[2], &eT1 = pev.e[3];
   auto tic = [&] { if (prof) ZKP_HIP(hipEventRecord(e0, st)); };
   auto toc = [&](float* dst) {
     if (!prof) return;
@@ -344,29 +384,31 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[w].stream, ctx->cur->ev_fork, 0));
     // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H | ws3: L, then part 1 after A, B1
     // (4 lanes x 4 streams = 16 streams = one hardware queue each under GPU_MAX_HW_QUEUES=16)
-    run(2, pk->hB2, Sd, pk->nz + 4, 2);                                            // prover.rs:182-184
-    run(0, pk->hA, Sd, pk->nz + 4, 1);                                             // prover.rs:164-167
-    run(1, pk->hB1, Sd, pk->nz + 4, 1, pk->share_b_sort ? 2 : -1);                 // prover.rs:170-177 (B2's bucket sort reused)
+    run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2);                          // prover.rs:182-184
+    run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1);                           // prover.rs:164-167
+    run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 1, pk->share_b_sort ? 2 : -1);   // prover.rs:170-177 (B2's bucket sort reused)
     static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
-    if (l_own) run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 3);
+    if (l_own) run(4, pk->hL, Sd + ((size_t)pk->num_inputs + pk->q_lo[4]) * 4, pk->q_n[4], 3);
     ZKP_HIP(hipEventRecord(ctx->cur->ev_b1, ctx->cur->ws[1].stream));
     // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~4 ms single-wave chain: start them as soon as
     // A and B1 exist so they hide under the remaining MSMs
-    ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_b1, 0));
-    v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, proof_dev, flags_dev);
+    if (!partial_out) {
+      ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_b1, 0));
+      v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, proof_dev, flags_dev);
+    }
   }
   tic();
   uint32_t* h = witness_map_dev<FrP>(ctx, pk, S);
   toc(&tm.ms_witness_map);
   if (!fan) {
-    run(0, pk->hA, Sd, pk->nz + 4, 0);
-    run(1, pk->hB1, Sd, pk->nz + 4, 0);
-    run(2, pk->hB2, Sd, pk->nz + 4, 0);
+    run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 0);
+    run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 0);
+    run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 0);
   }
-  run(3, pk->hH, reinterpret_cast<const uint64_t*>(h), std::min(pk->N, bases_len(ctx, pk->hH)), 0);  // :186-187
+  run(3, pk->hH, reinterpret_cast<const uint64_t*>(h) + 4 * pk->q_lo[3], pk->q_n[3], 0);  // :186-187 (min(len) truncation in q_n)
   {
     static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
-    if (!(fan && l_own)) run(4, pk->hL, Sd + (size_t)pk->num_inputs * 4, (size_t)pk->num_aux + 4, 0);               // :189-190
+    if (!(fan && l_own)) run(4, pk->hL, Sd + ((size_t)pk->num_inputs + pk->q_lo[4]) * 4, pk->q_n[4], 0);             // :189-190
   }
   if (fan) {
     for (int w = 1; w < zkp_ctx::N_WS; w++) {
@@ -376,6 +418,17 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   }
   tm.ms_msm_accumulate = acc_ms;
   tm.msm_points = ent;
+  if (partial_out) {
+    ZKP_HIP(hipMemcpyAsync(partial_out, res, 5 * slot, hipMemcpyDeviceToDevice, st));
+    ZKP_HIP(hipGetLastError());
+    if (prof) {
+      ZKP_HIP(hipEventRecord(eT1, st));
+      ZKP_HIP(hipStreamSynchronize(st));
+      ZKP_HIP(hipEventElapsedTime(&tm.ms_total, eT0, eT1));
+      ctx->last_timing = tm;
+    }
+    return;
+  }
 
   tic();
   // proof layout (32-bit words): A = 2*fN1 | B = 2*fN2 | C = 2*fN1
@@ -393,10 +446,6 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     ZKP_HIP(hipStreamSynchronize(st));
     ZKP_HIP(hipEventElapsedTime(&tm.ms_total, eT0, eT1));
     ctx->last_timing = tm;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(eT0);
-    (void)hipEventDestroy(eT1);
   }
 }
 
@@ -507,8 +556,53 @@ void groth16_assemble(zkp_ctx* ctx, int curve, const uint64_t* sums, const uint6
   for (int i = 0; i < 3; i++) inf_out[i] = (uint8_t)flags_host[i];
 }
 
+size_t groth16_partials_bytes(int curve) { return 5 * msm_vtbl(curve, 2)->xyzz_bytes; }
+
+// Base-sharded step, part 1 (this rank): witness map (replicated) + the five partial MSMs over this rank's slices.
+// Everything stays in HBM: out_dev receives groth16_partials_bytes() bytes, complete when the call returns.
+void groth16_prove_partials(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_dev, const uint64_t* r, const uint64_t* s,
+                            void* out_dev) {
+  ZKP_REQUIRE(pk->shard_world > 0, ZKP_ERR_BAD_ARG);
+  ctx->cur = &ctx->lanes[0];
+  ctx->cur_idx = 0;
+  if (pk->curve == ZKP_BN254) prove_enqueue_part<Bn254Fr>(ctx, pk, z_dev, true, r, s, 3, (char*)out_dev);
+  else prove_enqueue_part<Bls381Fr>(ctx, pk, z_dev, true, r, s, 3, (char*)out_dev);
+  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
+}
+
+// Base-sharded step, part 2 (every rank, after the all-gather): fold the `world` rank buffers slot by slot and assemble
+// the proof (prover.rs:192-210).  gathered_dev: world x groth16_partials_bytes() bytes of device memory.
+void groth16_fold_assemble(zkp_ctx* ctx, int curve, const void* gathered_dev, int world, const uint64_t* r,
+                           const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out) {
+  ZKP_REQUIRE(world >= 1, ZKP_ERR_BAD_ARG);
+  const MsmVtbl* v1 = msm_vtbl(curve, 1);
+  const MsmVtbl* v2 = msm_vtbl(curve, 2);
+  hipStream_t st = ctx->cur->stream;
+  const size_t slot = v2->xyzz_bytes;
+  uint32_t* buf = ctx->msm_misc.as<uint32_t>(16 + 6 * slot / 4 + 256 + 16);
+  uint32_t* rs = buf;
+  char* res = reinterpret_cast<char*>(rs + 16);
+  uint32_t* proof_dev = reinterpret_cast<uint32_t*>(res + 6 * slot);
+  uint32_t* flags_dev = proof_dev + 240;
+  ZKP_HIP(hipMemcpyAsync(rs, r, 32, hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipMemcpyAsync(rs + 8, s, 32, hipMemcpyHostToDevice, st));
+  v1->fold_slots(st, (const char*)gathered_dev, 5 * slot, world, slot, 0x1b, res);     // A, B1, H, L
+  v2->fold_slots(st, (const char*)gathered_dev, 5 * slot, world, slot, 0x04, res);     // B2
+  v1->assemble_g1_part1(st, res, slot, rs, proof_dev, flags_dev);
+  v1->assemble_g1_part2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN + 2 * v2->fN);
+  v2->assemble_g2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN);
+  ZKP_HIP(hipGetLastError());
+  const size_t proof_words = 4 * (size_t)v1->fN + 2 * (size_t)v2->fN;
+  uint32_t flags_host[4] = {0, 0, 0, 0};
+  ZKP_HIP(hipMemcpyAsync(proof_out, proof_dev, proof_words * 4, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(flags_host, flags_dev, 12, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < 3; i++) inf_out[i] = (uint8_t)flags_host[i];
+}
+
 void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
                    const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out) {
+  ZKP_REQUIRE(pk->shard_world == 0, ZKP_ERR_BAD_ARG);     // a sharded key yields partial sums only
   ctx->cur = &ctx->lanes[0];
   ctx->cur_idx = 0;
   if (pk->curve == ZKP_BN254) prove_enqueue<Bn254Fr>(ctx, pk, z, z_on_device, r, s);
@@ -524,6 +618,7 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
   const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
   const size_t pw64 = (4 * (size_t)v1->fN + 2 * (size_t)v2->fN) / 2;
   const bool prof = ctx->profiling;
+  ZKP_REQUIRE(pk->shard_world == 0, ZKP_ERR_BAD_ARG);
   size_t pending[zkp_ctx::N_LANES] = {};
   // proofs in flight: 8 lanes x 4 streams = 2 streams per hardware queue (measured optimum at 2^20: 4 lanes 102, 6 lanes 103,
   // 8 lanes 108-110, 12 lanes 104 proofs/s); 4 above 2^22 where a lane's scratch is tens of GB.  ZKP_LANES overrides.

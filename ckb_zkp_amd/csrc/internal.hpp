@@ -47,7 +47,12 @@ void fixed_base_mul(zkp_ctx* ctx, int curve, int group, const uint64_t* base_xy,
                     uint64_t* out_xy, uint8_t* out_inf);
 
 // groth16.hip
-zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d);
+zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, int rank = 0, int world = 0);
+size_t groth16_partials_bytes(int curve);
+void groth16_prove_partials(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_dev, const uint64_t* r, const uint64_t* s,
+                            void* out_dev);
+void groth16_fold_assemble(zkp_ctx* ctx, int curve, const void* gathered_dev, int world, const uint64_t* r,
+                           const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 void groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk);
 uint64_t groth16_domain_size(zkp_groth16_pk* pk);
 void groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, uint64_t* h, bool on_device);

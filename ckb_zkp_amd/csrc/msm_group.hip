@@ -209,6 +209,19 @@ __global__ void fold_kernel(const uint32_t* pts, int k, uint32_t* out_jac) {
   acc.store_jacobian(out_jac);
 }
 
+// Multi-GPU exchange step: `gathered` holds, per rank, the 5 partial MSM results of a base-sharded
+// Groth16 proof as XYZZ slots (A | B1 | B2 | H | L, `slot` bytes each, rank stride `rank_stride`) exactly as the
+// all-gather delivered them; lane t sums slot t over the ranks into res.  mask selects the slots of this group.
+template <class F>
+__global__ void fold_slots_kernel(const char* __restrict__ gathered, size_t rank_stride, int world, size_t slot,
+                                  uint32_t mask, char* __restrict__ res) {
+  const int t = threadIdx.x;
+  if (blockIdx.x || t >= 5 || !((mask >> t) & 1)) return;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int k = 0; k < world; k++) acc.add(XYZZ<F>::load(gathered + (size_t)k * rank_stride + (size_t)t * slot));
+  acc.store(res + (size_t)t * slot);
+}
+
 template <class F>
 __global__ void into_affine_kernel(const uint32_t* jac, uint32_t* xy, uint32_t* inf) {
   if (threadIdx.x || blockIdx.x) return;
@@ -338,6 +351,10 @@ void l_identity(hipStream_t s, char* out_xyzz, uint32_t* out_jac) {
 void l_fold(hipStream_t s, const uint32_t* pts, int k, uint32_t* out_jac) {
   hipLaunchKernelGGL(fold_kernel<F>, dim3(1), dim3(64), 0, s, pts, k, out_jac);
 }
+void l_fold_slots(hipStream_t s, const char* gathered, size_t rank_stride, int world, size_t slot, uint32_t mask,
+                  char* res) {
+  hipLaunchKernelGGL(fold_slots_kernel<F>, dim3(1), dim3(64), 0, s, gathered, rank_stride, world, slot, mask, res);
+}
 void l_into_affine(hipStream_t s, const uint32_t* jac, uint32_t* xy, uint32_t* inf) {
   hipLaunchKernelGGL(into_affine_kernel<F>, dim3(1), dim3(64), 0, s, jac, xy, inf);
 }
@@ -367,7 +384,7 @@ const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
   static const MsmVtbl v = {
       F::N, Affine<F>::BYTES, XYZZ<F>::BYTES, CFG_BITS,
       l_ingest, l_precompute, ZKP_CFG_SYM(msm_accumulate_launch), l_combine, l_pair, l_segsum, l_final, l_identity, l_fold,
-      l_into_affine, l_from_jacobian, l_fixed_base,
+      l_into_affine, l_from_jacobian, l_fixed_base, l_fold_slots,
 #if ZKP_CFG_GROUP == 1
       l_assemble_g1_p1, l_assemble_g1_p2, nullptr,
 #else

@@ -43,6 +43,9 @@ struct MsmVtbl {
   void (*from_jacobian)(hipStream_t, const uint32_t* jac, char* out_xyzz);
   void (*fixed_base)(hipStream_t, const uint32_t* base, const uint32_t* scalars, size_t n, char* out_xy,
                      uint8_t* out_inf);
+  // sum slot t (t < 5, mask bit t set) of `world` gathered rank buffers into res + t * slot (XYZZ slots)
+  void (*fold_slots)(hipStream_t, const char* gathered, size_t rank_stride, int world, size_t slot, uint32_t mask,
+                     char* res);
   // Groth16 assembly (groth16.hip): G1 tables implement assemble_g1, G2 tables assemble_g2
   // part 1 needs only g_a (slot 0) and g1_b (slot 1): proof.a = affine(g_a); T = s*g_a + r*g1_b -> slot 5.
   // part 2: C = T + h_acc (slot 3) + l' (slot 4) -> affine.  Split so part 1 overlaps the remaining MSMs.

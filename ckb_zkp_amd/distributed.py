@@ -89,6 +89,11 @@ class ShardedBases:
         parts = all_gather_points(self.partial(scalars_mont), self.world, self.device)
         return self.engine.fold(self.curve, self.group, parts.reshape(-1))
 
+    def free(self):
+        if self.handle is not None and hasattr(self.handle, "free"):
+            self.handle.free()
+        self.handle = None
+
 
 class ShardedGroth16Prover:
     """create_proof (groth16/src/prover.rs:124-211) with every query sharded by index across ranks."""
@@ -144,6 +149,7 @@ class ShardedGroth16Prover:
         if getattr(self, "_S", None) is None:
             self._S = ctx.dev_alloc((nz + 4) * 32)
             self._h = ctx.dev_alloc(pk_m.domain_size * 32)
+            self._ctx_for_free = ctx
         ctx.d2d(self._S, z_dev, nz * 32)
         ctx.h2d(self._S + nz * 32, codec.fr_to_mont([1, r, s, (-(r * s)) % c.r], c).reshape(4, 4))
         pk_m.witness_map_dev(z_dev, self._h)
@@ -158,7 +164,69 @@ class ShardedGroth16Prover:
         part = np.concatenate(ctx.msm_mont_multi_dev(jobs))
         return self.fold_sums(all_gather_points(part, self.world, self.device))
 
+    def free(self):
+        """release the resident slices and the cached device buffers"""
+        for sb in (self.A, self.B1, self.B2, self.L, self.H):
+            sb.free()
+        if getattr(self, "_S", None) is not None:
+            self._ctx_for_free.dev_free(self._S)
+            self._ctx_for_free.dev_free(self._h)
+            self._S = self._h = None
+
     def prove_sums(self, z_mont, r: int, s: int) -> np.ndarray:
         h = self.witness_mapper(z_mont)
         part = self.partial_sums(z_mont, h, r, s)
         return self.fold_sums(all_gather_points(part, self.world, self.device))
+
+
+class DeviceShardedGroth16Prover:
+    """One rank of the device-resident base-sharded prover (BASELINE configs[4]): the product path of `--mode shard`.
+
+        partials = zkp_groth16_prove_partials_dev      (witness map + 5 partial MSMs over this rank's 1/world of the key)
+        gathered = all_gather_into_tensor(partials)    (RCCL over xGMI; world x 1.25 KiB for BN254)
+        proof    = zkp_groth16_fold_assemble_dev       (slot-wise EC sum over the ranks + prover.rs:192-210)
+
+    The partial sums never leave HBM: the send/receive buffers are device tensors handed to the library by pointer.
+    transport="gloo" (tests on a one-GPU box / CPU collectives only) stages the 1.25 KiB through the host."""
+
+    def __init__(self, ctx, params, inst, rank: int, world: int, device=None, transport: str = "nccl"):
+        from . import groth16
+        self.ctx, self.curve, self.rank, self.world, self.transport = ctx, params.curve, rank, world, transport
+        self.pk = groth16.ProvingKey(ctx, params, inst, shard=(rank, world))
+        self.pb = groth16.partials_bytes(ctx, self.curve)
+        self._torch_bufs = None
+        self._raw = None
+        if world > 1:
+            import torch
+            dev = device if device is not None else torch.device("cuda", ctx.device)
+            self._torch_bufs = (torch.zeros(self.pb, dtype=torch.uint8, device=dev),
+                                torch.zeros(self.pb * world, dtype=torch.uint8, device=dev))
+        else:
+            self._raw = ctx.dev_alloc(self.pb)
+
+    def prove(self, z_dev: int, r: int, s: int):
+        from . import groth16
+        if self.world == 1:
+            self.pk.partials_dev(z_dev, r, s, self._raw)
+            return groth16.fold_assemble_dev(self.ctx, self.curve, self._raw, 1, r, s)
+        import torch
+        import torch.distributed as dist
+        mine, gathered = self._torch_bufs
+        self.pk.partials_dev(z_dev, r, s, mine.data_ptr())          # complete on return (library stream synchronised)
+        if self.transport == "gloo":
+            parts = [torch.empty(self.pb, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, mine.cpu())
+            gathered.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(gathered, mine)
+        torch.cuda.current_stream(gathered.device).synchronize()       # the fold runs on the library's stream
+        return groth16.fold_assemble_dev(self.ctx, self.curve, gathered.data_ptr(), self.world, r, s)
+
+    def free(self):
+        if self.pk is not None:
+            self.pk.free()
+            self.pk = None
+        if self._raw is not None:
+            self.ctx.dev_free(self._raw)
+            self._raw = None
+        self._torch_bufs = None

@@ -163,12 +163,33 @@ def assemble(ctx: Context, curve, sums_xyz: np.ndarray, r: int, s: int):
     return out, inf
 
 
+def partials_bytes(ctx: Context, curve) -> int:
+    n = C.c_size_t()
+    _lib.check(ctx.lib.zkp_groth16_partials_bytes(get_curve(curve).cid, C.byref(n)), "zkp_groth16_partials_bytes")
+    return n.value
+
+
+def fold_assemble_dev(ctx: Context, curve, gathered_dev: int, world: int, r: int, s: int):
+    """zkp_groth16_fold_assemble_dev: the all-gathered partial sums (device pointer, world x partials_bytes) ->
+    (proof limbs, identity flags)."""
+    c = get_curve(curve)
+    out = np.zeros(8 * c.fq_limbs, dtype=np.uint64)
+    inf = np.zeros(3, dtype=np.uint8)
+    rm, sm = fr_to_mont([r], c)[0], fr_to_mont([s], c)[0]
+    _lib.check(ctx.lib.zkp_groth16_fold_assemble_dev(ctx.h, c.cid, C.c_void_p(gathered_dev), world, _ptr(rm), _ptr(sm),
+                                                     _ptr(out), _ptr(inf)), "zkp_groth16_fold_assemble_dev")
+    return out, inf
+
+
 class ProvingKey:
     """Device-resident proving key + circuit matrices (zkp_groth16_pk_upload).
-    matrices_only=True uploads just at/bt/ct (witness_map only) for the base-sharded multi-GPU prover."""
+    matrices_only=True uploads just at/bt/ct (witness_map only) for the host-driven sharded prover;
+    shard=(rank, world) keeps 1/world of every query resident (zkp_groth16_pk_upload_shard): such a key yields the
+    partial sums of its slices (partials_dev) and refuses to prove on its own."""
 
-    def __init__(self, ctx: Context, params: Parameters, circuit, matrices_only: bool = False):
+    def __init__(self, ctx: Context, params: Parameters, circuit, matrices_only: bool = False, shard=None):
         self.ctx, self.params, self.curve = ctx, params, params.curve
+        self.shard = shard
         inst = _as_instance(self.curve, circuit, assign=False)
         assert (inst.num_inputs, inst.num_aux, inst.num_constraints()) == \
             (params.num_inputs, params.num_aux, params.num_constraints)
@@ -195,7 +216,11 @@ class ProvingKey:
             setattr(d, f"{name}_inf", P(inf.astype(np.uint8)) if len(inf) else None)
             setattr(d, f"{name}_len", len(inf))
         h = C.c_void_p()
-        _lib.check(ctx.lib.zkp_groth16_pk_upload(ctx.h, C.byref(d), C.byref(h)), "zkp_groth16_pk_upload")
+        if shard is None:
+            _lib.check(ctx.lib.zkp_groth16_pk_upload(ctx.h, C.byref(d), C.byref(h)), "zkp_groth16_pk_upload")
+        else:
+            _lib.check(ctx.lib.zkp_groth16_pk_upload_shard(ctx.h, C.byref(d), shard[0], shard[1], C.byref(h)),
+                       "zkp_groth16_pk_upload_shard")
         self.h = h
         n = C.c_uint64()
         _lib.check(ctx.lib.zkp_groth16_domain_size(self.h, C.byref(n)), "zkp_groth16_domain_size")
@@ -219,6 +244,13 @@ class ProvingKey:
         """device pointers in and out (domain_size Fr written at h_dev)"""
         _lib.check(self.ctx.lib.zkp_groth16_witness_map_dev(self.ctx.h, self.h, C.c_void_p(z_dev), C.c_void_p(h_dev)),
                    "zkp_groth16_witness_map_dev")
+
+    def partials_dev(self, z_dev: int, r: int, s: int, out_dev: int):
+        """sharded key: witness map + the five partial MSMs of this rank -> partials_bytes() bytes at out_dev (device)"""
+        c = self.curve
+        rm, sm = fr_to_mont([r], c)[0], fr_to_mont([s], c)[0]
+        _lib.check(self.ctx.lib.zkp_groth16_prove_partials_dev(self.ctx.h, self.h, C.c_void_p(z_dev), _ptr(rm), _ptr(sm),
+                                                              C.c_void_p(out_dev)), "zkp_groth16_prove_partials_dev")
 
     def prove_raw(self, z, r_mont: np.ndarray, s_mont: np.ndarray, z_on_device: bool = False):
         """-> (proof limbs uint64, identity flags[3])."""

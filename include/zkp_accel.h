@@ -224,6 +224,25 @@ int32_t zkp_groth16_prove_batch_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, 
 int32_t zkp_groth16_assemble(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* sums_xyz, const uint64_t* r,
                              const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 
+/* Device-resident base-sharded step (BASELINE configs[4]) — nothing but the collective between the calls:
+ *   zkp_groth16_pk_upload_shard     rank `rank` of `world` keeps elements [lo, hi) of every query of prover.rs:164-190
+ *                                   resident (contiguous, balanced ranges over the extended queries; 1/world of the key)
+ *                                   plus the circuit matrices;
+ *   zkp_groth16_prove_partials_dev  witness map (replicated) + the five partial MSMs of this rank; r, s (host, Montgomery)
+ *                                   must be the same on every rank.  partials_dev (DEVICE, zkp_groth16_partials_bytes()
+ *                                   bytes: 5 XYZZ slots A|B1|B2|H|L) is complete when the call returns;
+ *   -- ncclAllGather(partials_dev -> gathered_dev, world x partials bytes) over RCCL, by the caller --
+ *   zkp_groth16_fold_assemble_dev   slot-wise sum over the ranks (EC addition is not an RCCL reduction op) + assembly of
+ *                                   prover.rs:192-210 -> proof_out (host).
+ * A sharded key is refused by zkp_groth16_prove*. */
+int32_t zkp_groth16_pk_upload_shard(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, int32_t rank, int32_t world,
+                                    zkp_groth16_pk** out);
+int32_t zkp_groth16_partials_bytes(zkp_curve_t curve, size_t* bytes);
+int32_t zkp_groth16_prove_partials_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_dev, const uint64_t* r,
+                                       const uint64_t* s, void* partials_dev);
+int32_t zkp_groth16_fold_assemble_dev(zkp_ctx* ctx, zkp_curve_t curve, const void* gathered_dev, int32_t world,
+                                      const uint64_t* r, const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
+
 /* ---- introspection for bench.py / rocprof bookkeeping ------------------------------------------ */
 typedef struct {
   float ms_total;          /* last zkp_groth16_prove*: stream time, HIP events */

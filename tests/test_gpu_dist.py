@@ -58,3 +58,88 @@ def test_sharded_prover_equals_single_gpu_prover(ctx, curve, k, world):
     finally:
         pk.free()
         pk_m.free()
+
+
+def _device_sharded_proof(ctx, params, inst, z_dev, world, r_, s_):
+    """all ranks of the device-resident sharded step simulated in one process: rank k's partial sums land in slot k of
+    the buffer the all-gather would fill; fold + assembly read it in place (no host copy of any point)."""
+    pb = groth16.partials_bytes(ctx, params.curve)
+    gathered = ctx.dev_alloc(world * pb)
+    try:
+        for rank in range(world):
+            pk_s = groth16.ProvingKey(ctx, params, inst, shard=(rank, world))
+            try:
+                pk_s.partials_dev(z_dev, r_, s_, gathered + rank * pb)
+                from ckb_zkp_amd._lib import ZkpError
+                if rank == 0:
+                    c = params.curve
+                    with pytest.raises(ZkpError):        # a sharded key yields partial sums only
+                        pk_s.prove_raw(z_dev, codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0], z_on_device=True)
+            finally:
+                pk_s.free()
+        return groth16.fold_assemble_dev(ctx, params.curve, gathered, world, r_, s_)
+    finally:
+        ctx.dev_free(gathered)
+
+
+@pytest.mark.parametrize("curve,k,world", [("bn254", 12, 2), ("bn254", 11, 8), ("bn254", 4, 8), ("bls12_381", 9, 3)])
+def test_device_sharded_step_equals_single_gpu_proof(ctx, curve, k, world):
+    """zkp_groth16_pk_upload_shard / zkp_groth16_prove_partials_dev / zkp_groth16_fold_assemble_dev: the proof of the
+    base-sharded step (world ranks, slices that do not divide evenly, k = 4: ranks with EMPTY slices) is bit-identical
+    to the single-GPU proof, for (r, s) random and (0, 0)."""
+    c = get_curve(curve)
+    inst = mimc_chain_instance(curve, samples_for_domain(k))
+    params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    pk = groth16.ProvingKey(ctx, params, inst)
+    z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+    zd = ctx.to_device(z)
+    try:
+        for r_, s_ in ((0xABCDEF0123456789ABCDEF, 0x13579BDF02468ACE), (0, 0)):
+            out1, inf1 = pk.prove_raw(zd, codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0], z_on_device=True)
+            out2, inf2 = _device_sharded_proof(ctx, params, inst, zd, world, r_, s_)
+            assert np.array_equal(out1, out2) and np.array_equal(inf1, inf2), (r_, s_)
+    finally:
+        ctx.dev_free(zd)
+        pk.free()
+
+
+def test_config5_2p24_single_gpu_and_8way_sharded(ctx):
+    """BASELINE.json configs[4] at FULL size: 16 777 210-constraint MiMC chain, domain 2^24, BN254.
+    (1) the single-GPU proof equals the proof computed in the exponent from the toxic waste (size-independent check,
+    SURVEY §8(c).3) and h has degree <= N-2; (2) the 8-way base-sharded device-resident step (every rank's slice of the
+    20 132 656-point queries, partial sums all-gathered in HBM, folded and assembled on the device) returns the same
+    proof bit for bit.  ~100 GB of HBM, a few minutes."""
+    from oracle.pyref.curves import Group
+    from tests.util import OC
+    curve, k, world = "bn254", 24, 8
+    c = get_curve(curve)
+    inst = mimc_chain_instance(curve, samples_for_domain(k))
+    params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+    zd = ctx.to_device(z)
+    r_, s_ = 0x1F2E3D4C5B6A7988, 0x8899AABBCCDDEEFF
+    try:
+        pk = groth16.ProvingKey(ctx, params, inst)
+        try:
+            assert pk.domain_size == 1 << k
+            h = codec.fr_from_mont(pk.witness_map(z), c)
+            assert h[-1] == 0
+            out1, inf1 = pk.prove_raw(zd, codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0], z_on_device=True)
+            proof = pk.decode_proof(out1, inf1)
+        finally:
+            pk.free()
+        t, r, ni = params.toxic, c.r, inst.num_inputs
+        A = (t["alpha"] + sum(zi * ai for zi, ai in zip(inst.z, t["a"])) + r_ * t["delta"]) % r
+        B = (t["beta"] + sum(zi * bi for zi, bi in zip(inst.z, t["b"])) + s_ * t["delta"]) % r
+        L = sum(zi * li for zi, li in zip(inst.z[ni:], t["l"][ni:])) % r
+        H = sum(hi * qi for hi, qi in zip(h, t["h"])) % r
+        Cc = (s_ * A + r_ * B - r_ * s_ % r * t["delta"] + L + H) % r
+        G1, G2 = Group(OC[curve], 1), Group(OC[curve], 2)
+        assert proof.a == G1.mul(G1.gen, A)
+        assert proof.b == G2.mul(G2.gen, B)
+        assert proof.c == G1.mul(G1.gen, Cc)
+        del h, t
+        out2, inf2 = _device_sharded_proof(ctx, params, inst, zd, world, r_, s_)
+        assert np.array_equal(out1, out2) and np.array_equal(inf1, inf2)
+    finally:
+        ctx.dev_free(zd)

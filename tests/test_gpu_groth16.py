@@ -137,11 +137,8 @@ def test_batch_prove_equals_sequential(ctx):
         pk.free()
 
 
-import os as _os
-
+# configs[4]'s instance (2^24, BN254) is covered — single GPU and 8-way sharded — by tests/test_gpu_dist.py
 _FULL = [("bn254", 20), ("bls12_381", 20), ("bls12_381", 22)]
-if _os.environ.get("ZKP_TEST_2P24"):          # configs[4]'s instance (16 777 210 constraints) on ONE GPU: 2.5 minutes, ~100 GB of HBM; passed on MI355X in round 1
-    _FULL.append(("bn254", 24))
 
 
 @pytest.mark.parametrize("curve,k", _FULL)
