@@ -58,10 +58,10 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
             device_id);
     return ZKP_ERR_DEVICE;
   }
-  // The proof pipeline keeps ~20 streams busy (5 lanes x 4).  ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES
+  // The proof pipeline keeps ~32 streams busy (8 lanes x 4).  ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES
   // hardware queues (default 4) and streams that share a queue serialise; 16 queues measured best on MI355X
-  // (84 -> 95 proofs/s at 2^20).  Only effective if the HIP runtime has not been initialised by the host yet.
-  setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  // (84 -> 95 proofs/s at 2^20).  The library does NOT touch the process environment: the host exports
+  // GPU_MAX_HW_QUEUES=16 before its first HIP call (the Python package and bench.py do so).
   zkp_ctx* ctx = new (std::nothrow) zkp_ctx();
   if (!ctx) return ZKP_ERR_OOM;
   ctx->device = device_id;
@@ -88,7 +88,7 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
     }
   });
   if (st != ZKP_OK) {
-    delete ctx;
+    (void)zkp_ctx_destroy(ctx);                 // releases whatever streams / events / pinned buffers already exist
     return st;
   }
   *out = ctx;

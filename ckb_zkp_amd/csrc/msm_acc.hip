@@ -111,9 +111,15 @@ __global__ __launch_bounds__(64) void accumulate_redo_kernel(const char* __restr
 }
 }  // namespace ZKP_CFG_SYM(cfg)
 
-static uint32_t dbg_mask() {   // ZKP_DEBUG_GATHER_MASK=0xffff: wrong results, cache-resident gathers (profiling experiments only)
+// Profiling builds only (-DZKP_DEBUG_GATHER, never the shipped library): ZKP_DEBUG_GATHER_MASK=0xffff makes every gather
+// hit cache — WRONG RESULTS, used once to show the kernel is VALU-bound.  The shipped build has no such switch.
+static uint32_t dbg_mask() {
+#ifdef ZKP_DEBUG_GATHER
   static uint32_t m = [] { const char* e = getenv("ZKP_DEBUG_GATHER_MASK"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0x7fffffffu; }();
   return m;
+#else
+  return 0x7fffffffu;
+#endif
 }
 void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint32_t* order,
                                         const uint32_t* task_start, const uint32_t* task_len, const uint32_t* task_dst,

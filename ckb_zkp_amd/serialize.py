@@ -9,7 +9,11 @@ Layout (arkworks `CanonicalSerialize`, compressed form — the default `serializ
   * Fq2: c0 then c1;
   * short-Weierstrass affine point: x only, with two flag bits in the top of the LAST byte: bit 7 = "y is the larger of
     {y, -y}" (Fq: as integers; Fq2: compare c1 first, then c0), bit 6 = point at infinity (x = 0);
-  * uncompressed form: x, then y, the infinity flag on y's last byte;
+  * uncompressed form: x, then y, the infinity flag on y's last byte; the identity is written with ark's in-memory
+    coordinates of `GroupAffine::zero()` = (x = 0, y = 1) plus the flag (compressed: x = 0 plus the flag);
+  * `deserialize` (compressed and uncompressed) rejects points outside the prime-order subgroup
+    (`is_in_correct_subgroup_assuming_on_curve`): relevant for BN254 G2 and both BLS12-381 groups (BN254 G1 has
+    cofactor 1).  `checked=False` is ark's `deserialize_unchecked` (bulk loads of trusted keys);
   * `Vec<T>`: u64 little-endian length, then the elements; structs: their fields in declaration order.
 
 PARITY UNPINNED: the reference holds no serialized fixture and ark-serialize is not vendored (Cargo dependency "0.2"),
@@ -89,6 +93,62 @@ def _g1_b(c: CurveParams) -> int:
     return 3 if c.name == "bn254" else 4
 
 
+# ---- prime-order subgroup membership: [r]P == O, affine double-and-add on host big integers (a = 0 curves)
+def _fq2_inv(a, q):
+    d = pow((a[0] * a[0] + a[1] * a[1]) % q, -1, q)
+    return (a[0] * d % q, (-a[1] * d) % q)
+
+
+class _F1:
+    def __init__(self, q): self.q = q
+    def add(self, a, b): return (a + b) % self.q
+    def sub(self, a, b): return (a - b) % self.q
+    def mul(self, a, b): return a * b % self.q
+    def inv(self, a): return pow(a, -1, self.q)
+    def small(self, k, a): return k * a % self.q
+    zero = 0
+
+
+class _F2:
+    def __init__(self, q): self.q = q
+    def add(self, a, b): return ((a[0] + b[0]) % self.q, (a[1] + b[1]) % self.q)
+    def sub(self, a, b): return ((a[0] - b[0]) % self.q, (a[1] - b[1]) % self.q)
+    def mul(self, a, b): return _fq2_mul(a, b, self.q)
+    def inv(self, a): return _fq2_inv(a, self.q)
+    def small(self, k, a): return (k * a[0] % self.q, k * a[1] % self.q)
+    zero = (0, 0)
+
+
+def _affine_add(F, p, q_):
+    if p is None:
+        return q_
+    if q_ is None:
+        return p
+    (x1, y1), (x2, y2) = p, q_
+    if x1 == x2:
+        if F.add(y1, y2) == F.zero:
+            return None
+        lam = F.mul(F.small(3, F.mul(x1, x1)), F.inv(F.small(2, y1)))
+    else:
+        lam = F.mul(F.sub(y2, y1), F.inv(F.sub(x2, x1)))
+    x3 = F.sub(F.sub(F.mul(lam, lam), x1), x2)
+    return (x3, F.sub(F.mul(lam, F.sub(x1, x3)), y1))
+
+
+def in_prime_order_subgroup(p, curve, group: int) -> bool:
+    """ark-ec `is_in_correct_subgroup_assuming_on_curve`: [r]P is the identity."""
+    c = get_curve(curve)
+    if p is None or (group == 1 and c.name == "bn254"):          # cofactor 1
+        return True
+    F = _F1(c.q) if group == 1 else _F2(c.q)
+    acc = None
+    for bit in bin(c.r)[2:]:
+        acc = _affine_add(F, acc, acc)
+        if bit == "1":
+            acc = _affine_add(F, acc, p)
+    return acc is None
+
+
 # ------------------------------------------------------------------ elements
 def fr_to_bytes(x: int, curve) -> bytes:
     c = get_curve(curve)
@@ -119,6 +179,8 @@ def g1_to_bytes(p, curve, compressed: bool = True) -> bytes:
     n = _fq_bytes(c)
     if p is None:
         out = bytearray(n if compressed else 2 * n)
+        if not compressed:
+            out[n] = 1                                # GroupAffine::zero() = (0, 1, infinity)
         out[-1] |= FLAG_INFINITY
         return bytes(out)
     x, y = p
@@ -130,7 +192,7 @@ def g1_to_bytes(p, curve, compressed: bool = True) -> bytes:
     return x.to_bytes(n, "little") + y.to_bytes(n, "little")
 
 
-def g1_from_bytes(b: bytes, curve, compressed: bool = True):
+def g1_from_bytes(b: bytes, curve, compressed: bool = True, checked: bool = True):
     c = get_curve(curve)
     n, q = _fq_bytes(c), c.q
     if len(b) != (n if compressed else 2 * n):
@@ -151,9 +213,11 @@ def g1_from_bytes(b: bytes, curve, compressed: bool = True):
             raise SerializationError("InvalidData")
         if _y_is_positive_g1(y, q) != bool(flags & FLAG_POSITIVE_Y):
             y = (q - y) % q
-        return (x, y)
-    x, y = int.from_bytes(body[:n], "little"), int.from_bytes(body[n:], "little")
-    if x >= q or y >= q or (y * y - x * x * x - _g1_b(c)) % q:
+    else:
+        x, y = int.from_bytes(body[:n], "little"), int.from_bytes(body[n:], "little")
+        if x >= q or y >= q or (y * y - x * x * x - _g1_b(c)) % q:
+            raise SerializationError("InvalidData")
+    if checked and not in_prime_order_subgroup((x, y), c, 1):
         raise SerializationError("InvalidData")
     return (x, y)
 
@@ -163,6 +227,8 @@ def g2_to_bytes(p, curve, compressed: bool = True) -> bytes:
     n = _fq_bytes(c)
     if p is None:
         out = bytearray(2 * n if compressed else 4 * n)
+        if not compressed:
+            out[2 * n] = 1                            # y = Fq2::one() = (1, 0)
         out[-1] |= FLAG_INFINITY
         return bytes(out)
     (x0, x1), (y0, y1) = p
@@ -174,7 +240,7 @@ def g2_to_bytes(p, curve, compressed: bool = True) -> bytes:
     return b"".join(v.to_bytes(n, "little") for v in (x0, x1, y0, y1))
 
 
-def g2_from_bytes(b: bytes, curve, compressed: bool = True):
+def g2_from_bytes(b: bytes, curve, compressed: bool = True, checked: bool = True):
     c = get_curve(curve)
     n, q = _fq_bytes(c), c.q
     if len(b) != (2 * n if compressed else 4 * n):
@@ -199,9 +265,11 @@ def g2_from_bytes(b: bytes, curve, compressed: bool = True):
             raise SerializationError("InvalidData")
         if _y_is_positive_g2(y, q) != bool(flags & FLAG_POSITIVE_Y):
             y = ((q - y[0]) % q, (q - y[1]) % q)
-        return (x, y)
-    y = (vals[2], vals[3])
-    if _fq2_mul(y, y, q) != rhs:
+    else:
+        y = (vals[2], vals[3])
+        if _fq2_mul(y, y, q) != rhs:
+            raise SerializationError("InvalidData")
+    if checked and not in_prime_order_subgroup((x, y), c, 2):
         raise SerializationError("InvalidData")
     return (x, y)
 
@@ -232,6 +300,7 @@ def proof_to_bytes(proof, curve) -> bytes:
 
 
 def proof_from_bytes(b: bytes, curve):
+    """`Proof::deserialize` (checked: an untrusted proof with a small-subgroup component is rejected)"""
     from .groth16 import Proof
     c = get_curve(curve)
     n = _fq_bytes(c)
@@ -246,17 +315,18 @@ def verify_key_to_bytes(alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, cur
             g2_to_bytes(delta_g2, curve) + _vec(gamma_abc_g1, lambda p: g1_to_bytes(p, curve)))
 
 
-def _read_verify_key(r: _Reader, c: CurveParams) -> dict:
+def _read_verify_key(r: _Reader, c: CurveParams, checked: bool = True) -> dict:
     n = _fq_bytes(c)
-    vk = dict(alpha_g1=g1_from_bytes(r.take(n), c), beta_g2=g2_from_bytes(r.take(2 * n), c),
-              gamma_g2=g2_from_bytes(r.take(2 * n), c), delta_g2=g2_from_bytes(r.take(2 * n), c))
-    vk["gamma_abc_g1"] = [g1_from_bytes(r.take(n), c) for _ in range(r.u64())]
+    k = dict(checked=checked)
+    vk = dict(alpha_g1=g1_from_bytes(r.take(n), c, **k), beta_g2=g2_from_bytes(r.take(2 * n), c, **k),
+              gamma_g2=g2_from_bytes(r.take(2 * n), c, **k), delta_g2=g2_from_bytes(r.take(2 * n), c, **k))
+    vk["gamma_abc_g1"] = [g1_from_bytes(r.take(n), c, **k) for _ in range(r.u64())]
     return vk
 
 
-def verify_key_from_bytes(b: bytes, curve) -> dict:
+def verify_key_from_bytes(b: bytes, curve, checked: bool = True) -> dict:
     r = _Reader(b)
-    vk = _read_verify_key(r, get_curve(curve))
+    vk = _read_verify_key(r, get_curve(curve), checked)
     if r.o != len(b):
         raise SerializationError("InvalidData")
     return vk
@@ -273,17 +343,19 @@ def parameters_to_bytes(p: dict, curve) -> bytes:
             _vec(p["b_g2_query"], g2) + _vec(p["h_query"], g1) + _vec(p["l_query"], g1))
 
 
-def parameters_from_bytes(b: bytes, curve) -> dict:
+def parameters_from_bytes(b: bytes, curve, checked: bool = True) -> dict:
+    """`Parameters::deserialize`; checked=False = `deserialize_unchecked` (a trusted multi-million-point key: the
+    subgroup test costs one 255-bit scalar multiplication per point)"""
     c = get_curve(curve)
     n = _fq_bytes(c)
     r = _Reader(b)
-    out = dict(vk=_read_verify_key(r, c))
-    out["beta_g1"] = g1_from_bytes(r.take(n), c)
-    out["delta_g1"] = g1_from_bytes(r.take(n), c)
+    out = dict(vk=_read_verify_key(r, c, checked))
+    out["beta_g1"] = g1_from_bytes(r.take(n), c, checked=checked)
+    out["delta_g1"] = g1_from_bytes(r.take(n), c, checked=checked)
     for name, size, dec in (("a_query", n, g1_from_bytes), ("b_g1_query", n, g1_from_bytes),
                             ("b_g2_query", 2 * n, g2_from_bytes), ("h_query", n, g1_from_bytes),
                             ("l_query", n, g1_from_bytes)):
-        out[name] = [dec(r.take(size), c) for _ in range(r.u64())]
+        out[name] = [dec(r.take(size), c, checked=checked) for _ in range(r.u64())]
     if r.o != len(b):
         raise SerializationError("InvalidData")
     return out

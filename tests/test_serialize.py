@@ -90,3 +90,54 @@ def test_rejects_bad_encodings():
     with pytest.raises(ser.SerializationError):
         ser.fr_from_bytes(c.r.to_bytes(32, "little"), "bn254")
     assert ser.fr_from_bytes(ser.fr_to_bytes(c.r - 1, "bn254"), "bn254") == c.r - 1
+
+
+def test_identity_encodings():
+    """compressed: x = 0 + infinity flag; uncompressed: ark's GroupAffine::zero() = (0, 1) + flag on y's last byte."""
+    for curve, n in (("bn254", 32), ("bls12_381", 48)):
+        b = ser.g1_to_bytes(None, curve, compressed=False)
+        assert b[:n] == bytes(n) and b[n] == 1 and not any(b[n + 1:-1]) and b[-1] == ser.FLAG_INFINITY
+        b2 = ser.g2_to_bytes(None, curve, compressed=False)
+        assert b2[:2 * n] == bytes(2 * n) and b2[2 * n] == 1 and not any(b2[2 * n + 1:-1]) and b2[-1] == ser.FLAG_INFINITY
+        assert ser.g1_from_bytes(b, curve, False) is None and ser.g2_from_bytes(b2, curve, False) is None
+
+
+def _off_subgroup_point(curve, group):
+    """a curve point outside the prime-order subgroup (exists where the cofactor is > 1)"""
+    c = get_curve(curve)
+    q = c.q
+    for v in range(1, 200):
+        if group == 1:
+            y = ser._sqrt_fq(v ** 3 + ser._g1_b(c), q)
+            p = None if y is None else (v, y)
+        else:
+            x = (v, 1)
+            x3 = ser._fq2_mul(ser._fq2_mul(x, x, q), x, q)
+            bb = ser._g2_b(c)
+            y = ser._sqrt_fq2(((x3[0] + bb[0]) % q, (x3[1] + bb[1]) % q), q)
+            p = None if y is None else (x, y)
+        if p is not None and not ser.in_prime_order_subgroup(p, curve, group):
+            return p
+    raise AssertionError("no off-subgroup point found")
+
+
+@pytest.mark.parametrize("curve,group", [("bn254", 2), ("bls12_381", 1), ("bls12_381", 2)])
+def test_rejects_points_outside_the_prime_order_subgroup(curve, group):
+    """ark-ec 0.2 `deserialize` runs is_in_correct_subgroup_assuming_on_curve: a curve point with a small-subgroup
+    component (possible on BN254 G2 and both BLS12-381 groups) must not decode; deserialize_unchecked accepts it."""
+    c = get_curve(curve)
+    gen = c.g1 if group == 1 else c.g2
+    enc, dec = (ser.g1_to_bytes, ser.g1_from_bytes) if group == 1 else (ser.g2_to_bytes, ser.g2_from_bytes)
+    assert ser.in_prime_order_subgroup(gen, curve, group)
+    bad = _off_subgroup_point(curve, group)
+    for comp in (True, False):
+        raw = enc(bad, curve, comp)
+        with pytest.raises(ser.SerializationError):
+            dec(raw, curve, comp)
+        assert dec(raw, curve, comp, checked=False) == bad
+        assert dec(enc(gen, curve, comp), curve, comp) == gen
+    if group == 2:                                          # a proof whose B is off-subgroup is refused as a whole
+        g1 = _pts(curve, 1, 2, 9)
+        raw = ser.g1_to_bytes(g1[0], curve) + ser.g2_to_bytes(bad, curve) + ser.g1_to_bytes(g1[1], curve)
+        with pytest.raises(ser.SerializationError):
+            ser.proof_from_bytes(raw, curve)
