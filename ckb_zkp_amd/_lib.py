@@ -40,7 +40,8 @@ class Groth16PkDesc(C.Structure):
 class Groth16Timing(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_witness_map", C.c_float), ("ms_msm", C.c_float * 5),
                 ("ms_assemble", C.c_float), ("ms_msm_accumulate", C.c_float),
-                ("msm_accumulate_launches", C.c_uint64), ("msm_points", C.c_uint64)]
+                ("msm_accumulate_launches", C.c_uint64), ("msm_points", C.c_uint64),
+                ("ms_msm_scan", C.c_float), ("msm_scan_launches", C.c_uint64), ("msm_scan_bytes", C.c_uint64)]
 
 
 # name -> (restype, argtypes).  Must list every symbol declared in include/zkp_accel.h
@@ -102,9 +103,11 @@ SIGNATURES = {
     "zkp_groth16_prove": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp]),
     "zkp_groth16_prove_dev": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp]),
     "zkp_groth16_prove_batch_dev": (C.c_int32, [vp, vp, C.c_size_t, vp, vp, vp, vp, vp]),
+    "zkp_groth16_prove_batch": (C.c_int32, [vp, vp, C.c_size_t, vp, vp, vp, vp, vp]),
     "zkp_groth16_assemble": (C.c_int32, [vp, C.c_int, vp, vp, vp, vp, vp]),
     "zkp_groth16_last_timing": (C.c_int32, [vp, C.POINTER(Groth16Timing)]),
     "zkp_set_profiling": (C.c_int32, [vp, C.c_int32]),
+    "zkp_bench_mulmod": (C.c_int32, [vp, C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
 }
 
 _lib = None

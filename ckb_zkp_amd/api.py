@@ -90,6 +90,13 @@ class Context:
         _lib.check(self.lib.zkp_timer_stop_ms(self.h, C.byref(ms)), "zkp_timer_stop_ms")
         return ms.value
 
+    def bench_mulmod(self, curve, field: int, unsaturated: bool) -> float:
+        """zkp_bench_mulmod: sustained 1e9 Montgomery products / s of the library's multiplier (field 0 = Fr, 1 = Fq)"""
+        g = C.c_double()
+        _lib.check(self.lib.zkp_bench_mulmod(self.h, get_curve(curve).cid, field, 1 if unsaturated else 0, C.byref(g)),
+                   "zkp_bench_mulmod")
+        return g.value
+
     # ---- NTT (ark-poly EvaluationDomain ops)
     def ntt(self, curve, data: np.ndarray, op: int) -> np.ndarray:
         """data: (2^k, 4) uint64 Montgomery Fr; returns the transformed copy."""

@@ -418,10 +418,19 @@ int32_t zkp_groth16_prove_batch_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, 
   if (!pk || (n && (!z_dev || !r || !s || !proofs || !inf))) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { groth16_prove_batch(ctx, pk, n, z_dev, r, s, proofs, inf); });
 }
+int32_t zkp_groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint64_t* const* z_host,
+                                const uint64_t* r, const uint64_t* s, uint64_t* proofs, uint8_t* inf) {
+  if (!pk || (n && (!z_host || !r || !s || !proofs || !inf))) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_prove_batch(ctx, pk, n, z_host, r, s, proofs, inf, false); });
+}
 int32_t zkp_groth16_assemble(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* sums, const uint64_t* r,
                              const uint64_t* s, uint64_t* proof, uint8_t* inf) {
   if (!sums || !r || !s || !proof || !inf) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { groth16_assemble(ctx, curve, sums, r, s, proof, inf); });
+}
+int32_t zkp_bench_mulmod(zkp_ctx* ctx, zkp_curve_t curve, int32_t field, int32_t unsaturated, double* out) {
+  if (!out || (curve != ZKP_BN254 && curve != ZKP_BLS12_381) || field < 0 || field > 1) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { *out = bench_mulmod(ctx, curve, field, unsaturated != 0); });
 }
 int32_t zkp_groth16_last_timing(zkp_ctx* ctx, zkp_groth16_timing* out) {
   if (!ctx || !out) return ZKP_ERR_BAD_ARG;

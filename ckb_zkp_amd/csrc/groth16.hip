@@ -361,22 +361,27 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   const size_t slot = v2->xyzz_bytes;                  // uniform slot size
   char* res = reinterpret_cast<char*>(PL.results.get(6 * slot));
   const uint64_t* Sd = reinterpret_cast<const uint64_t*>(S);
-  float acc_ms = 0.f;
-  uint64_t ent = 0;
+  float acc_ms = 0.f, scan_ms = 0.f;
+  uint64_t ent = 0, scan_bytes = 0, scan_runs = 0;
   // Schedule.  profiling: everything on the main stream, one MSM at a time, with per-phase events.
   // otherwise: three streams —  main: witness_map -> H ;  ws1: A -> L ;  ws2: B1 -> B2  — joined before assembly.
   // ZKP_SINGLE_STREAM=1: one stream per proof (no fan-out inside a proof); concurrency then comes from the lanes only
   static const bool single_stream = getenv("ZKP_SINGLE_STREAM") && atoi(getenv("ZKP_SINGLE_STREAM")) != 0;
   const bool fan = !prof && !single_stream;
   auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n, int w, int sort_src = -1) {
-    float ms = 0.f;
+    float ms = 0.f, ms_sc = 0.f;
     uint64_t e = 0;
     tic();
     msm_run(ctx, handle, 0, sc, n, true, nullptr, res + idx * slot, prof ? &ms : nullptr, &e, fan ? w : 0,
-            fan ? sort_src : -1);
+            fan ? sort_src : -1, prof ? &ms_sc : nullptr);
     toc(&tm.ms_msm[idx]);
     acc_ms += ms;
     ent += e;
+    if (ms_sc > 0.f) {                       // algorithmic bytes of the scalar scan: scalars read by both passes + one 8-B word per entry
+      scan_ms += ms_sc;
+      scan_bytes += 2 * 32 * (uint64_t)n + 8 * e;
+      scan_runs += 1;
+    }
     tm.msm_accumulate_launches += 1;
   };
   if (fan) {
@@ -418,6 +423,9 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   }
   tm.ms_msm_accumulate = acc_ms;
   tm.msm_points = ent;
+  tm.ms_msm_scan = scan_ms;
+  tm.msm_scan_bytes = scan_bytes;
+  tm.msm_scan_launches = scan_runs;
   if (partial_out) {
     ZKP_HIP(hipMemcpyAsync(partial_out, res, 5 * slot, hipMemcpyDeviceToDevice, st));
     ZKP_HIP(hipGetLastError());
@@ -613,7 +621,7 @@ void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_o
 // n proofs, software-pipelined over the two lanes: proof i+1 is enqueued before proof i is awaited, so the
 // latency-bound tails (bucket reduction, assembly) of one proof overlap the throughput-bound kernels of the next.
 void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint64_t* const* z_dev, const uint64_t* r,
-                         const uint64_t* s, uint64_t* proofs_out, uint8_t* inf_out) {
+                         const uint64_t* s, uint64_t* proofs_out, uint8_t* inf_out, bool z_on_device) {
   const MsmVtbl* v1 = msm_vtbl(pk->curve, 1);
   const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
   const size_t pw64 = (4 * (size_t)v1->fN + 2 * (size_t)v2->fN) / 2;
@@ -634,8 +642,8 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
       const int l = prof ? 0 : (int)(i % nl);
       select(l);
       if (ctx->cur->busy) prove_finish(ctx, pk, proofs_out + pending[l] * pw64, inf_out + pending[l] * 3);
-      if (pk->curve == ZKP_BN254) prove_enqueue<Bn254Fr>(ctx, pk, z_dev[i], true, r + 4 * i, s + 4 * i);
-      else prove_enqueue<Bls381Fr>(ctx, pk, z_dev[i], true, r + 4 * i, s + 4 * i);
+      if (pk->curve == ZKP_BN254) prove_enqueue<Bn254Fr>(ctx, pk, z_dev[i], z_on_device, r + 4 * i, s + 4 * i);
+      else prove_enqueue<Bls381Fr>(ctx, pk, z_dev[i], z_on_device, r + 4 * i, s + 4 * i);
       pending[l] = i;
     }
     for (int l = 0; l < zkp_ctx::N_LANES; l++) {

@@ -31,7 +31,9 @@ int bases_group(zkp_ctx* ctx, uint64_t handle);
 // runs on workspace `ws` (its stream + scratch); does not synchronise unless out_xyz_host != nullptr
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
              uint64_t* out_xyz_host, void* out_dev_xyzz = nullptr, float* ms_accumulate = nullptr,
-             uint64_t* n_entries = nullptr, int ws = 0, int sort_src = -1);
+             uint64_t* n_entries = nullptr, int ws = 0, int sort_src = -1, float* ms_scan = nullptr);
+// bench_kern.hip: sustained rate (1e9 products/s) of the library's Montgomery multipliers; field 0 = Fr, 1 = Fq
+double bench_mulmod(zkp_ctx* ctx, int curve, int field, bool unsaturated);
 // sort_src >= 0: reuse the bucket sort + task schedule that workspace `sort_src` of the same lane computed for the SAME
 // scalars, length, window configuration and identity flags (Groth16: b_g1_query / b_g2_query) instead of redoing it
 bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2);
@@ -60,7 +62,7 @@ void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_o
                    const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 
 void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint64_t* const* z_dev, const uint64_t* r,
-                         const uint64_t* s, uint64_t* proofs_out, uint8_t* inf_out);
+                         const uint64_t* s, uint64_t* proofs_out, uint8_t* inf_out, bool z_on_device = true);
 void groth16_assemble(zkp_ctx* ctx, int curve, const uint64_t* sums_xyz, const uint64_t* r, const uint64_t* s,
                       uint64_t* proof_out, uint8_t* inf_out);
 

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void task_order_kernel(const uint32_t* __restr
 
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
              uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries, int ws_idx,
-             int sort_src) {
+             int sort_src, float* ms_scan) {
   auto be = get_bases(ctx, handle);
   const MsmVtbl* vt = be->vt;
   MsmWorkspace& ws = ctx->cur->ws[ws_idx];
@@ -462,6 +462,7 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
   const size_t jac_words = 3 * (size_t)vt->fN;
   uint32_t* out_jac = ws.out.as<uint32_t>(64 * 4);
   if (ms_accumulate) *ms_accumulate = 0.f;
+  if (ms_scan) *ms_scan = 0.f;
   if (n_entries) *n_entries = 0;
   if (n == 0) {
     vt->write_identity(st, (char*)out_dev_xyzz, out_jac);
@@ -495,6 +496,8 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     uint32_t* end = start + nb;
     if (reuse) ZKP_HIP(hipStreamWaitEvent(st, sw.sorted, 0));
     else ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
+    const bool timed_scan = ms_scan && ctx->profiling && !reuse;      // K5 "scalar scan": histogram pass + count scan + scatter pass
+    if (timed_scan) ZKP_HIP(hipEventRecord(ctx->ev2, st));
     if (reuse) {
     } else if (be->curve == ZKP_BN254) {
       hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
@@ -508,6 +511,11 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
       hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
                          be->n, c, W, nb, LB, nbins1, offs, nblocks, tile, kv);
+    }
+    if (timed_scan) {
+      ZKP_HIP(hipEventRecord(ctx->ev3, st));
+      ZKP_HIP(hipEventSynchronize(ctx->ev3));
+      ZKP_HIP(hipEventElapsedTime(ms_scan, ctx->ev2, ctx->ev3));
     }
     if (!reuse)
       hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(SORT_BIN_THREADS), ((size_t)4 << LB) + 4 * (size_t)SORT_BIN_STAGE, st,

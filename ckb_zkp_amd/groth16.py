@@ -274,8 +274,9 @@ class ProvingKey:
     def witness_map_host(self, z_mont: np.ndarray) -> np.ndarray:
         return self.witness_map(z_mont)
 
-    def prove_batch_raw(self, z_devs, r_mont: np.ndarray, s_mont: np.ndarray):
-        """zkp_groth16_prove_batch_dev: n proofs pipelined over two lanes -> (n x proof limbs, n x 3 flags)."""
+    def prove_batch_raw(self, z_devs, r_mont: np.ndarray, s_mont: np.ndarray, z_on_device: bool = True):
+        """zkp_groth16_prove_batch_dev (z_devs: device pointers) / zkp_groth16_prove_batch (z_devs: HOST addresses of
+        nz x 4 u64 buffers, ideally pinned): n proofs pipelined over the lanes -> (n x proof limbs, n x 3 flags)."""
         n = len(z_devs)
         words = 8 * self.curve.fq_limbs
         out = np.zeros((n, words), dtype=np.uint64)
@@ -283,9 +284,9 @@ class ProvingKey:
         zp = (C.c_void_p * n)(*[C.c_void_p(z) for z in z_devs])
         r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64).reshape(n, 4)
         s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64).reshape(n, 4)
-        _lib.check(self.ctx.lib.zkp_groth16_prove_batch_dev(self.ctx.h, self.h, n, C.cast(zp, C.c_void_p), _ptr(r_mont),
-                                                            _ptr(s_mont), _ptr(out), _ptr(inf)),
-                   "zkp_groth16_prove_batch_dev")
+        fn = self.ctx.lib.zkp_groth16_prove_batch_dev if z_on_device else self.ctx.lib.zkp_groth16_prove_batch
+        _lib.check(fn(self.ctx.h, self.h, n, C.cast(zp, C.c_void_p), _ptr(r_mont), _ptr(s_mont), _ptr(out), _ptr(inf)),
+                   "zkp_groth16_prove_batch(_dev)")
         return out, inf
 
     def decode_proof(self, out: np.ndarray, inf) -> Proof:
@@ -301,7 +302,8 @@ class ProvingKey:
         _lib.check(self.ctx.lib.zkp_groth16_last_timing(self.ctx.h, C.byref(t)), "zkp_groth16_last_timing")
         return dict(ms_total=t.ms_total, ms_witness_map=t.ms_witness_map, ms_msm=list(t.ms_msm),
                     ms_assemble=t.ms_assemble, ms_msm_accumulate=t.ms_msm_accumulate,
-                    msm_accumulate_launches=t.msm_accumulate_launches, msm_points=t.msm_points)
+                    msm_accumulate_launches=t.msm_accumulate_launches, msm_points=t.msm_points,
+                    ms_msm_scan=t.ms_msm_scan, msm_scan_launches=t.msm_scan_launches, msm_scan_bytes=t.msm_scan_bytes)
 
 
 def create_proof(pk: ProvingKey, circuit, r: int, s: int) -> Proof:

@@ -216,6 +216,12 @@ int32_t zkp_groth16_prove_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* 
 int32_t zkp_groth16_prove_batch_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint64_t* const* z_dev,
                                     const uint64_t* r, const uint64_t* s, uint64_t* proofs_out, uint8_t* inf_out);
 
+/* The same with the witnesses in HOST memory: each proof's assignment (num_inputs + num_aux Fr) is copied to the device on
+ * its lane's stream in front of the proof, so the PCIe transfer of proof i+1 overlaps the kernels of proof i when the
+ * host buffers are pinned (hipHostMalloc / hipHostRegister); pageable buffers work but the copy then blocks the caller. */
+int32_t zkp_groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint64_t* const* z_host,
+                                const uint64_t* r, const uint64_t* s, uint64_t* proofs_out, uint8_t* inf_out);
+
 /* Multi-GPU (one process per GPU, bases sharded by index): every rank computes partial sums with zkp_msm_*,
  * the host all-gathers them (RCCL / any transport: 5 points, < 2 KiB), folds them with zkp_g*_fold and finishes
  * here.  sums_xyz: Jacobian Montgomery  g_a (G1) | g1_b (G1) | g2_b (G2) | h_acc (G1) | l_acc (G1)  where the
@@ -251,10 +257,17 @@ typedef struct {
   float ms_assemble;
   float ms_msm_accumulate; /* sum over the five MSMs of the bucket-accumulate kernel (dominant kernel) */
   uint64_t msm_accumulate_launches;
-  uint64_t msm_points;     /* non-identity (scalar, base) pairs fed to the five MSMs */
+  uint64_t msm_points;     /* (scalar, window) entries of the five MSMs = mixed additions of the accumulate kernels */
+  float ms_msm_scan;       /* MSM "scalar scan" (digit extraction fused into the level-1 histogram + scatter passes), summed */
+  uint64_t msm_scan_launches; /* MSMs that ran their own scan (B1 reuses B2's) */
+  uint64_t msm_scan_bytes; /* algorithmic bytes of those scans: 2 x 32 B per scalar read + 8 B per entry written */
 } zkp_groth16_timing;
 int32_t zkp_groth16_last_timing(zkp_ctx* ctx, zkp_groth16_timing* out);
 int32_t zkp_set_profiling(zkp_ctx* ctx, int32_t enable); /* per-phase HIP events (adds sync points) */
+/* Sustained rate (1e9 products / s) of the library's own Montgomery multipliers with every CU saturated: the integer-VALU
+ * roof the MSM / NTT kernels are bound by, measured in the calling process (bench.py `valu_roof`).
+ * field: 0 = Fr, 1 = Fq; unsaturated: 0 = 32-bit saturated limbs (field.cuh), 1 = 29/28-bit limbs (unsat.cuh, Fq only). */
+int32_t zkp_bench_mulmod(zkp_ctx* ctx, zkp_curve_t curve, int32_t field, int32_t unsaturated, double* gmulmod_per_s);
 
 #ifdef __cplusplus
 }
