@@ -41,7 +41,8 @@ class Groth16Timing(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_witness_map", C.c_float), ("ms_msm", C.c_float * 5),
                 ("ms_assemble", C.c_float), ("ms_msm_accumulate", C.c_float),
                 ("msm_accumulate_launches", C.c_uint64), ("msm_points", C.c_uint64),
-                ("ms_msm_scan", C.c_float), ("msm_scan_launches", C.c_uint64), ("msm_scan_bytes", C.c_uint64)]
+                ("ms_msm_scan", C.c_float), ("msm_scan_launches", C.c_uint64), ("msm_scan_bytes", C.c_uint64),
+                ("ms_msm_acc", C.c_float * 5), ("msm_entries", C.c_uint64 * 5)]
 
 
 # name -> (restype, argtypes).  Must list every symbol declared in include/zkp_accel.h

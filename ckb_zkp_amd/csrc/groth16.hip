@@ -377,6 +377,8 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     toc(&tm.ms_msm[idx]);
     acc_ms += ms;
     ent += e;
+    tm.ms_msm_acc[idx] = ms;
+    tm.msm_entries[idx] = e;
     if (ms_sc > 0.f) {                       // algorithmic bytes of the scalar scan: scalars read by both passes + one 8-B word per entry
       scan_ms += ms_sc;
       scan_bytes += 2 * 32 * (uint64_t)n + 8 * e;

@@ -303,7 +303,8 @@ class ProvingKey:
         return dict(ms_total=t.ms_total, ms_witness_map=t.ms_witness_map, ms_msm=list(t.ms_msm),
                     ms_assemble=t.ms_assemble, ms_msm_accumulate=t.ms_msm_accumulate,
                     msm_accumulate_launches=t.msm_accumulate_launches, msm_points=t.msm_points,
-                    ms_msm_scan=t.ms_msm_scan, msm_scan_launches=t.msm_scan_launches, msm_scan_bytes=t.msm_scan_bytes)
+                    ms_msm_scan=t.ms_msm_scan, msm_scan_launches=t.msm_scan_launches, msm_scan_bytes=t.msm_scan_bytes,
+                    ms_msm_acc=list(t.ms_msm_acc), msm_entries=list(t.msm_entries))
 
 
 def create_proof(pk: ProvingKey, circuit, r: int, s: int) -> Proof:

@@ -261,6 +261,8 @@ typedef struct {
   float ms_msm_scan;       /* MSM "scalar scan" (digit extraction fused into the level-1 histogram + scatter passes), summed */
   uint64_t msm_scan_launches; /* MSMs that ran their own scan (B1 reuses B2's) */
   uint64_t msm_scan_bytes; /* algorithmic bytes of those scans: 2 x 32 B per scalar read + 8 B per entry written */
+  float ms_msm_acc[5];     /* accumulate kernel per MSM (A, B1, B2, H, L) */
+  uint64_t msm_entries[5]; /* entries (= mixed additions) per MSM */
 } zkp_groth16_timing;
 int32_t zkp_groth16_last_timing(zkp_ctx* ctx, zkp_groth16_timing* out);
 int32_t zkp_set_profiling(zkp_ctx* ctx, int32_t enable); /* per-phase HIP events (adds sync points) */

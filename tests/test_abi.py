@@ -38,7 +38,20 @@ def test_desc_struct_layout_matches_header():
     """ctypes mirror of zkp_groth16_pk_desc must have the C layout (x86-64 SysV): 4 ints, 3 CSR triples, 5+15 words."""
     assert ctypes.sizeof(_lib.Csr) == 24
     assert ctypes.sizeof(_lib.Groth16PkDesc) == 16 + 3 * 24 + 5 * 8 + 5 * 24
-    assert ctypes.sizeof(_lib.Groth16Timing) == 4 * 9 + 4 + 16   # 9 floats, pad, 2 u64
+    # zkp_groth16_timing: ask the C compiler (sizeof + offset of every member) and compare with the ctypes mirror
+    import subprocess
+    import tempfile
+    fields = [f[0] for f in _lib.Groth16Timing._fields_]
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"zkp_accel.h\"\nint main(void){printf(\"%zu\", sizeof(zkp_groth16_timing));" + \
+        "".join(f'printf(" %zu", offsetof(zkp_groth16_timing, {f}));' for f in fields) + \
+        "printf(\" %zu %zu\", sizeof(zkp_groth16_pk_desc), sizeof(zkp_csr));return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "t.c").write_text(prog)
+        subprocess.run(["gcc", "-std=c99", f"-I{ROOT / 'include'}", str(Path(d) / "t.c"), "-o", str(Path(d) / "t")], check=True)
+        nums = [int(x) for x in subprocess.run([str(Path(d) / "t")], capture_output=True, text=True, check=True).stdout.split()]
+    assert nums[0] == ctypes.sizeof(_lib.Groth16Timing)
+    assert nums[1:1 + len(fields)] == [getattr(_lib.Groth16Timing, f).offset for f in fields]
+    assert nums[-2:] == [ctypes.sizeof(_lib.Groth16PkDesc), ctypes.sizeof(_lib.Csr)]
 
 
 def test_product_does_not_import_oracle():
@@ -48,3 +61,16 @@ def test_product_does_not_import_oracle():
             txt = f.read_text()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
             assert "libzkp_oracle" not in txt and "cpu_oracle" not in txt and "pyref" not in txt, f
+
+
+def test_plain_c_program_links_against_the_header_and_library():
+    """A C99 translation unit (gcc -std=c99 -pedantic -Werror) that includes include/zkp_accel.h links against
+    libzkp_accel.so and runs: no ctypes, no C++ in between.  Without a GPU the context creation must fail LOUDLY with
+    ZKP_ERR_DEVICE (there is no CPU fallback); with one it succeeds."""
+    import subprocess
+    from tests import c_driver
+    exe = c_driver.build()
+    r = subprocess.run([str(exe), "probe"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "version=zkp_accel" in r.stdout
+    assert ("ctx=0 " in r.stdout) or ("ctx=-5 " in r.stdout and "no CPU fallback" in r.stdout), r.stdout

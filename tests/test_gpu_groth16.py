@@ -218,3 +218,36 @@ print("PROOFS", outs.tobytes().hex(), infs.tobytes().hex())
         res[g] = [l for l in out.stdout.splitlines() if l.startswith("PROOFS")][0]
     assert res["0"] == res["1"]
 
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_create_random_proof_and_no_zk_pass_the_reference_verifier(ctx, curve):
+    """The reference's own round trip (groth16/tests/mini.rs:80-96): create_random_proof -> verify_proof == true, and
+    the same for create_proof_no_zk (prover.rs:113-122); a wrong public input and a tampered proof are rejected.
+    The verifier is the oracle's from-scratch pairing check of groth16/src/verifier.rs:18-44."""
+    from oracle.pyref.pairing import verify_proof
+    from oracle.pyref.curves import Group
+    params = groth16.generate_parameters(ctx, curve, Mini(num=10), **TOXIC, g1_k=7, g2_k=9)
+    vk = _oracle_params(curve, og.MiniCircuit(num=10), 7, 9)           # same trapdoor -> same verifying key
+    c = params.curve
+    assert codec.g1_from_mont(*params.gamma_abc_g1, c) == vk.gamma_abc_g1
+    pk = groth16.ProvingKey(ctx, params, Mini(num=10))
+    try:
+        rng = random.Random(2024)
+        p1 = groth16.create_random_proof(pk, Mini(2, 3, 10, 10), rng)
+        p2 = groth16.create_random_proof(pk, Mini(2, 3, 10, 10), rng)
+        p0 = groth16.create_proof_no_zk(pk, Mini(2, 3, 10, 10))
+        assert (p1.a, p1.b, p1.c) != (p2.a, p2.b, p2.c)                # fresh (r, s) every time
+        for p in (p1, p2, p0):
+            assert verify_proof(OC[curve], vk, og.Proof(p.a, p.b, p.c), [10])
+        assert not verify_proof(OC[curve], vk, og.Proof(p1.a, p1.b, p1.c), [11])
+        G1 = Group(OC[curve], 1)
+        assert not verify_proof(OC[curve], vk, og.Proof(G1.add(p1.a, G1.gen), p1.b, p1.c), [10])
+        # no_zk == create_proof with (r, s) = (0, 0)
+        q = groth16.create_proof(pk, Mini(2, 3, 10, 10), 0, 0)
+        assert (p0.a, p0.b, p0.c) == (q.a, q.b, q.c)
+        # OS randomness path (rng=None)
+        p3 = groth16.create_random_proof(pk, Mini(2, 3, 10, 10))
+        assert verify_proof(OC[curve], vk, og.Proof(p3.a, p3.b, p3.c), [10])
+    finally:
+        pk.free()

@@ -195,3 +195,63 @@ def test_msm_random_lengths_and_offsets(ctx, curve, group):
             assert got == (G.mul(G.gen, e) if e else None), (n, off)
     finally:
         bases.free()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_vartime_multiscalar_mul_g2_and_mont_dev_vs_oracle(ctx, curve):
+    """zkp_vartime_multiscalar_mul_g2 and zkp_msm_g2_mont_dev / zkp_msm_g1_mont_dev (device-resident Montgomery scalars,
+    non-zero offset) against the oracle's naive MSM on oracle-generated bases, incl. an identity base and n > len."""
+    c = get_curve(curve)
+    rnd = random.Random(31)
+    for group, n in ((2, 45), (1, 70)):
+        G = Group(OC[curve], group)
+        pts = random_points(curve, group, n, seed=40 + group)
+        pts[2] = None
+        ks = [rnd.randrange(c.r) for _ in range(n + 5)]
+        ks[0], ks[1] = 0, c.r - 1
+        xy, inf = to_abi_points(curve, group, pts)
+        bases = ctx.upload_bases(c, group, xy, inf)
+        try:
+            km = codec.fr_to_mont(ks, c).reshape(-1, 4)
+            out = bases.vartime_multiscalar_mul(km)                   # n + 5 scalars: truncated to the n bases
+            assert jac_limbs_to_affine_oracle(curve, group, out) == G.msm_naive(pts, ks[:n])
+            kd = ctx.to_device(km)
+            for off, m in ((0, n), (7, n - 7), (n - 1, 1), (3, 20)):
+                got = bases.msm_mont_dev(kd, m, offset=off)
+                assert jac_limbs_to_affine_oracle(curve, group, got) == G.msm_naive(pts[off:off + m], ks[:m]), (group, off, m)
+            ctx.dev_free(kd)
+        finally:
+            bases.free()
+
+
+@pytest.mark.parametrize("curve,group,log_n", [("bn254", 1, 16), ("bn254", 2, 13)])
+def test_msm_host_generated_bases_vs_cpu_oracle(ctx, curve, group, log_n):
+    """Bases that never touched the device: built on the host by the C++ oracle's own fixed-base multiplication (and
+    spot-checked against the Python big-int oracle), uniformly random canonical scalars; the device MSM must equal the
+    oracle's window-parallel Pippenger (ark's algorithm) after normalisation."""
+    from oracle import cpu_oracle
+    c = get_curve(curve)
+    G = Group(OC[curve], group)
+    n = (1 << log_n) + 11
+    rng = np.random.default_rng(2 * log_n + group)
+    d = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    d[:, 3] >>= np.uint64(4)
+    d[5] = 0                                                           # -> an identity base
+    g_xy, _ = to_abi_points(curve, group, [G.gen])
+    xy, inf = cpu_oracle.fixed_base_mul(c.cid, group, g_xy, d)
+    assert inf[5] == 1 and inf.sum() == 1
+    dl = codec.limbs_to_ints(d)
+    for i in (0, 1, n - 1):
+        want = to_abi_points(curve, group, [G.mul(G.gen, dl[i])])[0][0]
+        assert np.array_equal(xy[i], want)
+    k = np.frombuffer(rng.bytes(32 * n), dtype=np.uint64).reshape(-1, 4).copy()
+    k[:, 3] &= np.uint64((1 << (c.r.bit_length() - 193)) - 1)          # < r
+    bases = ctx.upload_bases(c, group, xy, inf)
+    try:
+        got = jac_limbs_to_affine_oracle(curve, group, bases.msm(k))
+        want = jac_limbs_to_affine_oracle(curve, group, cpu_oracle.msm(c.cid, group, xy, inf, k, threads=8))
+        assert got == want
+        e = sum(a * b for a, b in zip(dl, codec.limbs_to_ints(k))) % c.r
+        assert got == G.mul(G.gen, e)
+    finally:
+        bases.free()
