@@ -73,6 +73,8 @@ SIGNATURES = {
     "zkp_msm_g2_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
     "zkp_vartime_multiscalar_mul_g1": (C.c_int32, [vp, C.c_uint64, vp, C.c_size_t, vp]),
     "zkp_vartime_multiscalar_mul_g2": (C.c_int32, [vp, C.c_uint64, vp, C.c_size_t, vp]),
+    "zkp_msm_g1_var": (C.c_int32, [vp, C.c_int, vp, vp, vp, C.c_size_t, C.c_int32, vp]),
+    "zkp_msm_g2_var": (C.c_int32, [vp, C.c_int, vp, vp, vp, C.c_size_t, C.c_int32, vp]),
     "zkp_msm_g1_mont_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
     "zkp_msm_g2_mont_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, vp]),
     "zkp_msm_g1_mont_batch_dev": (C.c_int32, [vp, C.c_uint64, C.c_size_t, vp, vp, vp, vp]),

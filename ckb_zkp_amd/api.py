@@ -122,6 +122,18 @@ class Context:
         _lib.check(fn(self.h, c.cid, _ptr(xy), _ptr(inf), n, C.byref(hnd)), "zkp_bases_upload")
         return Bases(self, c, group, hnd.value, n)
 
+    def msm_var(self, curve, group: int, xy: np.ndarray, inf, scalars: np.ndarray, montgomery: bool = False) -> np.ndarray:
+        """zkp_msm_g*_var: true variable-base MSM (fresh host bases, nothing resident) -> Jacobian limbs."""
+        c = get_curve(curve)
+        xy, s = _c64(xy), _c64(scalars)
+        n = min(xy.shape[0] if xy.ndim == 2 else 0, s.shape[0] if s.ndim == 2 else 0)
+        if inf is not None:
+            inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        out = np.zeros(3 * c.fq_limbs * (1 if group == 1 else 2), dtype=np.uint64)
+        fn = self.lib.zkp_msm_g1_var if group == 1 else self.lib.zkp_msm_g2_var
+        _lib.check(fn(self.h, c.cid, _ptr(xy), _ptr(inf), _ptr(s), n, 1 if montgomery else 0, _ptr(out)), "zkp_msm_var")
+        return out
+
     def fold(self, curve, group: int, xyz: np.ndarray) -> np.ndarray:
         c = get_curve(curve)
         xyz = _c64(xyz)

@@ -273,6 +273,16 @@ int32_t zkp_msm_g1_mont_dev(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t
 int32_t zkp_msm_g2_mont_dev(zkp_ctx* ctx, uint64_t h, size_t off, const uint64_t* s, size_t n, uint64_t* out) {
   return msm_common(ctx, 2, h, off, s, n, out, true, true);
 }
+int32_t zkp_msm_g1_var(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, const uint64_t* scalars,
+                       size_t n, int32_t montgomery, uint64_t* out_xyz) {
+  if (!out_xyz || (n && (!xy || !scalars))) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { msm_var_run(ctx, curve, 1, xy, inf, scalars, n, montgomery != 0, out_xyz); });
+}
+int32_t zkp_msm_g2_var(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, const uint64_t* scalars,
+                       size_t n, int32_t montgomery, uint64_t* out_xyz) {
+  if (!out_xyz || (n && (!xy || !scalars))) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { msm_var_run(ctx, curve, 2, xy, inf, scalars, n, montgomery != 0, out_xyz); });
+}
 int32_t zkp_msm_g1_mont_batch_dev(zkp_ctx* ctx, uint64_t h, size_t count, const size_t* offsets,
                                   const uint64_t* const* scalars_dev, const size_t* ns, uint64_t* out_xyz) {
   if (count && (!offsets || !scalars_dev || !ns || !out_xyz)) return ZKP_ERR_BAD_ARG;

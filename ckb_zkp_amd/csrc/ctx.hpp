@@ -129,7 +129,7 @@ struct zkp_ctx {
   std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)
   zkp::DevBuf ntt_io, poly_tmp, poly_consts, spmv_list;
   // MSM scratch
-  zkp::DevBuf msm_scalars, msm_misc;
+  zkp::DevBuf msm_scalars, msm_misc, var_bases;
   uint32_t* pinned = nullptr;      // pinned host landing zone for batched MSM results
   size_t pinned_cap = 0;
   std::unordered_map<uint64_t, std::shared_ptr<zkp::BasesEntry>> bases;

@@ -42,6 +42,8 @@ void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* of
 void msm_run_multi(zkp_ctx* ctx, size_t count, const uint64_t* handles, const size_t* offsets,
                    const uint64_t* const* scalars_dev, const size_t* ns, bool montgomery, uint64_t* out_xyz_host,
                    size_t slot_words);
+void msm_var_run(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, const uint8_t* inf_host,
+                 const uint64_t* scalars_host, size_t n, bool montgomery, uint64_t* out_xyz_host);
 void msm_free_all(zkp_ctx* ctx);
 void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz_host);
 void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, uint64_t* xy_out, uint8_t* inf_out);

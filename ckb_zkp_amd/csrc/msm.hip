@@ -27,6 +27,10 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
 
 #include "field.cuh"
 #include "internal.hpp"
@@ -54,9 +58,13 @@ struct BasesEntry {
   int c = 0, W = 0;
   char* table = nullptr;       // W * n affine points: T[w][i] = 2^(c*w) * P_i
   uint8_t* inf = nullptr;      // n identity flags (device) or nullptr
+  // Variable-base mode (zkp_msm_g*_var): no window tables — `table` holds the n points as uploaded, the digit scan emits
+  // entry (bucket w * 2^(c-1) + |d| - 1, point i) into W SEPARATE bucket sets, and the reduction weights window w by 2^(c*w).
+  bool var = false;
+  bool owns = true;            // false: table / inf live in context scratch
   ~BasesEntry() {
-    if (table) (void)hipFree(table);
-    if (inf) (void)hipFree(inf);
+    if (owns && table) (void)hipFree(table);
+    if (owns && inf) (void)hipFree(inf);
   }
 };
 
@@ -264,7 +272,8 @@ template <class FrP>
 __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restrict__ scalars, size_t n, size_t offset,
                                                         const uint8_t* __restrict__ inf, int montgomery, int c, int W,
                                                         uint32_t nb, int L, uint32_t nbins1,
-                                                        uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t tile) {
+                                                        uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t tile,
+                                                        int var) {
   __shared__ uint32_t cnt[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i <= nbins1; i += 256) cnt[i] = 0;
   __syncthreads();
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restri
       for (int w = 0; w < W; w++) {
         uint32_t key, neg;
         it.next(w, c, nb, key, neg);
-        if (key < nb) atomicAdd(&cnt[key >> L], 1u);
+        if (key < nb) atomicAdd(&cnt[(var ? ((uint32_t)w << (c - 1)) | key : key) >> L], 1u);
       }
     }
   }
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
                                                            int montgomery, size_t ntab, int c, int W, uint32_t nb,
                                                            int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
                                                            uint32_t nblocks, uint32_t tile,
-                                                           uint64_t* __restrict__ kv) {   // (low key << 32) | val
+                                                           uint64_t* __restrict__ kv, int var) {   // (low key << 32) | val
   __shared__ uint32_t cur[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i < nbins1; i += 256) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
   __syncthreads();
@@ -301,9 +310,10 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
         uint32_t key, neg;
         it.next(w, c, nb, key, neg);
         if (key < nb) {                                // zero digits are dropped here
-          uint32_t pos = atomicAdd(&cur[key >> L], 1u);
-          uint32_t val = (uint32_t)((size_t)w * ntab + offset + i) | (neg << 31);
-          kv[pos] = ((uint64_t)(key & lmask) << 32) | val;   // one 8-B store per entry
+          const uint32_t fk = var ? ((uint32_t)w << (c - 1)) | key : key;     // variable-base: one bucket set per window
+          uint32_t pos = atomicAdd(&cur[fk >> L], 1u);
+          uint32_t val = (uint32_t)((var ? (size_t)0 : (size_t)w * ntab) + offset + i) | (neg << 31);
+          kv[pos] = ((uint64_t)(fk & lmask) << 32) | val;   // one 8-B store per entry
         }
       }
     }
@@ -449,10 +459,62 @@ __global__ __launch_bounds__(256) void task_order_kernel(const uint32_t* __restr
   if (live) order[base[l] + rank] = t;
 }
 
+static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, const uint64_t* scalars_dev, size_t n,
+                          bool montgomery, uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate,
+                          uint64_t* n_entries, int ws_idx, int sort_src, float* ms_scan);
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
              uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries, int ws_idx,
              int sort_src, float* ms_scan) {
   auto be = get_bases(ctx, handle);
+  msm_run_entry(ctx, be.get(), offset, scalars_dev, n, montgomery, out_xyz_host, out_dev_xyzz, ms_accumulate, n_entries,
+                ws_idx, sort_src, ms_scan);
+}
+
+// Reduction plan of the variable-base mode (per (c, W), cached in the context): block descriptors for the two
+// segmented-sum stages.  Level l of the pairwise pyramid holds W windows x (nb_w >> l) entries; O_{l,w} = sum of the odd
+// entries of window w at level l; R_t = O_{l,w} for t = c*w + l; result = sum_t 2^t R_t + sum_w 2^(c*w) root_w.
+struct VarPlan {
+  DevBuf d1, d2;
+  uint32_t n1 = 0, n2 = 0;
+};
+static VarPlan& var_plan(zkp_ctx* ctx, int c, int W, hipStream_t st) {
+  // per DEVICE (not per context): the descriptors are immutable and live until process exit
+  static std::map<std::pair<int, std::pair<int, int>>, std::unique_ptr<VarPlan>> plans;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(ctx->device, std::make_pair(c, W));
+  auto it = plans.find(key);
+  if (it != plans.end()) return *it->second;
+  const uint32_t nb_w = 1u << (c - 1);
+  std::vector<SegDesc> s1, s2(256);
+  uint32_t lvl_off = 0, cnt = (uint32_t)W * nb_w;
+  for (auto& d : s2) d = SegDesc{0, 1, 0, 0};
+  for (int l = 0; l < c - 1; l++) {
+    const uint32_t pw = nb_w >> (l + 1);                         // odd entries per window at this level
+    const uint32_t ch = std::min<uint32_t>((uint32_t)SEG_CHUNK, pw);
+    for (int w = 0; w < W; w++) {
+      const uint32_t first = (uint32_t)s1.size();
+      for (uint32_t j = 0; j < pw / ch; j++)
+        s1.push_back(SegDesc{lvl_off + (uint32_t)w * (nb_w >> l) + 1 + 2 * j * ch, 2, ch, (uint32_t)s1.size()});
+      const int t = c * w + l;
+      if (t < 256) s2[t] = SegDesc{first, 1, (uint32_t)s1.size() - first, (uint32_t)t};
+    }
+    lvl_off += cnt;
+    cnt >>= 1;
+  }
+  for (int t = 0; t < 256; t++) s2[t].out = (uint32_t)t;
+  auto vp = std::make_unique<VarPlan>();
+  vp->n1 = (uint32_t)s1.size();
+  vp->n2 = 256;
+  ZKP_HIP(hipMemcpyAsync(vp->d1.as<SegDesc>(s1.size()), s1.data(), s1.size() * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipMemcpyAsync(vp->d2.as<SegDesc>(256), s2.data(), 256 * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipStreamSynchronize(st));                             // the host vectors die with this call
+  return *(plans[key] = std::move(vp));
+}
+
+static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, const uint64_t* scalars_dev, size_t n,
+                          bool montgomery, uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate,
+                          uint64_t* n_entries, int ws_idx, int sort_src, float* ms_scan) {
   const MsmVtbl* vt = be->vt;
   MsmWorkspace& ws = ctx->cur->ws[ws_idx];
   const bool reuse = sort_src >= 0 && sort_src != ws_idx;
@@ -468,7 +530,13 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     vt->write_identity(st, (char*)out_dev_xyzz, out_jac);
   } else {
     const int c = be->c, W = be->W;
-    const uint32_t nb = 1u << (c - 1);
+    const int var = be->var ? 1 : 0;
+    int lgW = 0;
+    while ((1 << lgW) < W) lgW++;
+    ZKP_REQUIRE(!var || (1 << lgW) == W, ZKP_ERR_BAD_ARG);
+    const uint32_t nb_w = 1u << (c - 1);                               // buckets of one window (digit range)
+    const int kbits = (c - 1) + (var ? lgW : 0);                       // bits of a bucket id
+    const uint32_t nb = 1u << kbits;                                   // all buckets
     const size_t E = n * (size_t)W;
     ZKP_REQUIRE(E < 2147483000ull, ZKP_ERR_BAD_ARG);
     uint32_t* vals = sw.vals.as<uint32_t>(E);                        // values grouped by bucket (level-2 output)
@@ -482,9 +550,9 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     int H1 = 10;
     while (H1 < SORT_H1_MAX && (E >> H1) > SORT_BIN_TARGET) H1++;
     if (h1_env > 0) H1 = std::min(SORT_H1_MAX, h1_env);
-    H1 = std::min(H1, c - 1);
-    if ((c - 1) - H1 > SORT_L_MAX) H1 = (c - 1) - SORT_L_MAX;
-    const int LB = (c - 1) - H1;                                       // low bits per level-1 bin
+    H1 = std::min(H1, kbits);
+    if (kbits - H1 > SORT_L_MAX) H1 = kbits - SORT_L_MAX;
+    const int LB = kbits - H1;                                         // low bits per level-1 bin
     const uint32_t nbins1 = 1u << H1;
     uint32_t tile = SORT_SCALARS;
     while ((n + tile - 1) / tile > 1536) tile += 256;
@@ -501,16 +569,16 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     if (reuse) {
     } else if (be->curve == ZKP_BN254) {
       hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
-                         nb, LB, nbins1, hist, nblocks, tile);
+                         nb_w, LB, nbins1, hist, nblocks, tile, var);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
       hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
-                         be->n, c, W, nb, LB, nbins1, offs, nblocks, tile, kv);
+                         be->n, c, W, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
     } else {
       hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
-                         nb, LB, nbins1, hist, nblocks, tile);
+                         nb_w, LB, nbins1, hist, nblocks, tile, var);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
       hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
-                         be->n, c, W, nb, LB, nbins1, offs, nblocks, tile, kv);
+                         be->n, c, W, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
     }
     if (timed_scan) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
@@ -559,6 +627,29 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     }
     vt->combine(st, long_list, tmeta + TM_NLONG, toff, task_partial, buckets);
     if (n_entries) *n_entries = E;
+    if (var) {
+      // K8, variable-base: the pairwise pyramid runs over all W bucket sets at once (pairs never straddle windows), c - 1
+      // levels deep; two descriptor-driven segmented sums give R_t; 256 lanes weigh them by 2^t (<= 255 doublings each)
+      VarPlan& vp = var_plan(ctx, c, W, st);
+      uint32_t lvl_off = 0, cnt = nb;
+      for (int l = 0; l < c - 1; l++) {
+        vt->pair(st, buckets + (size_t)lvl_off * XB, buckets + (size_t)(lvl_off + cnt) * XB, cnt / 2);
+        lvl_off += cnt;
+        cnt /= 2;
+      }
+      const char* roots = buckets + (size_t)lvl_off * XB;            // cnt == W
+      char* partial = reinterpret_cast<char*>(ws.tmp.get(((size_t)vp.n1 + 256 + 8) * XB));
+      char* R = partial + (size_t)vp.n1 * XB;
+      vt->segsum_desc(st, buckets, vp.d1.as<SegDesc>(vp.n1), vp.n1, partial);
+      vt->segsum_desc(st, partial, vp.d2.as<SegDesc>(256), 256, R);
+      vt->final_var(st, R, roots, c, W, (char*)out_dev_xyzz, out_jac);
+      ZKP_HIP(hipGetLastError());
+      if (out_xyz_host) {
+        ZKP_HIP(hipMemcpyAsync(out_xyz_host, out_jac, jac_words * 4, hipMemcpyDeviceToHost, st));
+        ZKP_HIP(hipStreamSynchronize(st));
+      }
+      return;
+    }
     // K8: pyramid
     const int L = c - 1;                           // levels with odd entries: 0..L-1 ; root = level L
     SegPlan plan{};
@@ -667,6 +758,42 @@ void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* of
   std::vector<uint64_t> handles(count, handle);
   msm_run_multi(ctx, count, handles.data(), offsets, scalars_dev, ns, montgomery, out_xyz_host,
                 3 * (size_t)get_bases(ctx, handle)->vt->fN);
+}
+
+// True variable-base MSM (ark `VariableBaseMSM::multi_scalar_mul(bases, scalars)` / `Curve::vartime_multiscalar_mul` with
+// FRESH bases, curve/src/lib.rs:38-45): nothing is precomputed and nothing stays resident.  Points and scalars are staged
+// into context scratch; W windows of c bits with c * W = 256 (c = 16 from 2^12 points on, else 8).
+void msm_var_run(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, const uint8_t* inf_host,
+                 const uint64_t* scalars_host, size_t n, bool montgomery, uint64_t* out_xyz_host) {
+  BasesEntry e;
+  e.curve = curve;
+  e.group = group;
+  e.vt = msm_vtbl(curve, group);
+  e.n = n;
+  e.var = true;
+  e.owns = false;
+  e.c = n >= 4096 ? 16 : 8;
+  if (const char* env = getenv("ZKP_MSM_VAR_C")) {
+    int c = atoi(env);
+    if (c == 4 || c == 8 || c == 16) e.c = c;
+  }
+  e.W = 256 / e.c;
+  ZKP_REQUIRE((double)n * e.W < 2147483000.0, ZKP_ERR_BAD_ARG);
+  hipStream_t st = ctx->cur->stream;
+  const size_t ab = e.vt->aff_bytes;
+  uint64_t* sdev = nullptr;
+  if (n) {
+    char* buf = reinterpret_cast<char*>(ctx->var_bases.get(n * ab + n + 64));
+    e.table = buf;
+    ZKP_HIP(hipMemcpyAsync(e.table, xy_host, n * ab, hipMemcpyHostToDevice, st));
+    if (inf_host) {
+      e.inf = reinterpret_cast<uint8_t*>(buf + n * ab);
+      ZKP_HIP(hipMemcpyAsync(e.inf, inf_host, n, hipMemcpyHostToDevice, st));
+    }
+    sdev = ctx->msm_scalars.as<uint64_t>(n * 4);
+    ZKP_HIP(hipMemcpyAsync(sdev, scalars_host, n * 32, hipMemcpyHostToDevice, st));
+  }
+  msm_run_entry(ctx, &e, 0, sdev, n, montgomery, out_xyz_host, nullptr, nullptr, nullptr, 0, -1, nullptr);
 }
 
 void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz, size_t k, uint64_t* out) {

@@ -183,6 +183,62 @@ __global__ __launch_bounds__(64) void final_kernel(const char* __restrict__ O, i
   }
 }
 
+// descriptor-driven segmented sum (variable-base reduction): one workgroup per descriptor
+template <class F>
+__global__ __launch_bounds__(256) void segsum_desc_kernel(const char* __restrict__ base, const SegDesc* __restrict__ descs,
+                                                          char* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SegDesc d = descs[blockIdx.x];
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t i = threadIdx.x; i < d.count; i += 256)
+    acc.add(XYZZ<F>::load(base + ((size_t)d.off + (size_t)i * d.stride) * XYZZ<F>::BYTES));
+  acc.store(smem + threadIdx.x * XYZZ<F>::BYTES);
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      XYZZ<F> o = XYZZ<F>::load(smem + (threadIdx.x + s) * XYZZ<F>::BYTES);
+      if (!o.is_inf() || !acc.is_inf()) {
+        acc.add(o);
+        acc.store(smem + threadIdx.x * XYZZ<F>::BYTES);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc.store(out + (size_t)d.out * XYZZ<F>::BYTES);
+}
+
+// out = sum_{t < 256} 2^t R[t] + sum_w 2^(c w) roots[w]: lane t adds the window root where t = c*w, doubles t times,
+// then an LDS tree over the 256 lanes.  The <= 255-doubling chain of the top lane is the latency of a variable-base MSM
+// (fixed-base window tables exist precisely to avoid it).
+template <class F>
+__global__ __launch_bounds__(256) void final_var_kernel(const char* __restrict__ R, const char* __restrict__ roots, int c,
+                                                        int W, char* __restrict__ out_xyzz, uint32_t* __restrict__ out_jac) {
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  XYZZ<F> acc = XYZZ<F>::load(R + (size_t)t * XYZZ<F>::BYTES);
+  if (t % c == 0 && t / c < W) acc.add(XYZZ<F>::load(roots + (size_t)(t / c) * XYZZ<F>::BYTES));
+  if (!acc.is_inf())
+    for (int k = 0; k < t; k++) acc = acc.dbl();
+  acc.store(smem + t * XYZZ<F>::BYTES);
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+      XYZZ<F> o = XYZZ<F>::load(smem + (t + s) * XYZZ<F>::BYTES);
+      if (!o.is_inf() || !acc.is_inf()) {
+        acc.add(o);
+        acc.store(smem + t * XYZZ<F>::BYTES);
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (out_xyzz) acc.store(out_xyzz);
+    if (out_jac) acc.store_jacobian(out_jac);
+  }
+}
+
 template <class F>
 __global__ void write_identity_kernel(char* out_xyzz, uint32_t* out_jac) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -351,6 +407,12 @@ void l_identity(hipStream_t s, char* out_xyzz, uint32_t* out_jac) {
 void l_fold(hipStream_t s, const uint32_t* pts, int k, uint32_t* out_jac) {
   hipLaunchKernelGGL(fold_kernel<F>, dim3(1), dim3(64), 0, s, pts, k, out_jac);
 }
+void l_segsum_desc(hipStream_t s, const char* base, const SegDesc* descs, uint32_t n_desc, char* out) {
+  if (n_desc) hipLaunchKernelGGL(segsum_desc_kernel<F>, dim3(n_desc), dim3(256), 256 * XB, s, base, descs, out);
+}
+void l_final_var(hipStream_t s, const char* R, const char* roots, int c, int W, char* out_xyzz, uint32_t* out_jac) {
+  hipLaunchKernelGGL(final_var_kernel<F>, dim3(1), dim3(256), 256 * XB, s, R, roots, c, W, out_xyzz, out_jac);
+}
 void l_fold_slots(hipStream_t s, const char* gathered, size_t rank_stride, int world, size_t slot, uint32_t mask,
                   char* res) {
   hipLaunchKernelGGL(fold_slots_kernel<F>, dim3(1), dim3(64), 0, s, gathered, rank_stride, world, slot, mask, res);
@@ -384,7 +446,7 @@ const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
   static const MsmVtbl v = {
       F::N, Affine<F>::BYTES, XYZZ<F>::BYTES, CFG_BITS,
       l_ingest, l_precompute, ZKP_CFG_SYM(msm_accumulate_launch), l_combine, l_pair, l_segsum, l_final, l_identity, l_fold,
-      l_into_affine, l_from_jacobian, l_fixed_base, l_fold_slots,
+      l_into_affine, l_from_jacobian, l_fixed_base, l_segsum_desc, l_final_var, l_fold_slots,
 #if ZKP_CFG_GROUP == 1
       l_assemble_g1_p1, l_assemble_g1_p2, nullptr,
 #else

@@ -18,6 +18,11 @@ struct SegPlan {
   uint32_t count[25];          // entries in segment l
 };
 
+// one block of a descriptor-driven segmented sum: out[d.out] = sum_{i < count} base[off + i * stride]
+struct SegDesc {
+  uint32_t off, stride, count, out;
+};
+
 struct MsmVtbl {
   int fN;                      // 32-bit words per coordinate (8 / 16 / 12 / 24)
   size_t aff_bytes, xyzz_bytes;
@@ -43,6 +48,10 @@ struct MsmVtbl {
   void (*from_jacobian)(hipStream_t, const uint32_t* jac, char* out_xyzz);
   void (*fixed_base)(hipStream_t, const uint32_t* base, const uint32_t* scalars, size_t n, char* out_xy,
                      uint8_t* out_inf);
+  // variable-base reduction (msm.hip msm_var_run): descriptor-driven segmented sums, then
+  // out = sum_{t < 256} 2^t R[t] + sum_{w < W} 2^(c*w) roots[w]
+  void (*segsum_desc)(hipStream_t, const char* base, const SegDesc* descs, uint32_t n_desc, char* out);
+  void (*final_var)(hipStream_t, const char* R, const char* roots, int c, int W, char* out_xyzz, uint32_t* out_jac);
   // sum slot t (t < 5, mask bit t set) of `world` gathered rank buffers into res + t * slot (XYZZ slots)
   void (*fold_slots)(hipStream_t, const char* gathered, size_t rank_stride, int world, size_t slot, uint32_t mask,
                      char* res);

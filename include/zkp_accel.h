@@ -129,6 +129,16 @@ int32_t zkp_vartime_multiscalar_mul_g1(zkp_ctx* ctx, uint64_t handle, const uint
                                        uint64_t* out_xyz);
 int32_t zkp_vartime_multiscalar_mul_g2(zkp_ctx* ctx, uint64_t handle, const uint64_t* fr_scalars_host, size_t n,
                                        uint64_t* out_xyz);
+/* TRUE variable-base MSM — the literal semantics of `VariableBaseMSM::multi_scalar_mul(bases, scalars)` and of
+ * `Curve::vartime_multiscalar_mul(scalars, points)` (curve/src/lib.rs:38-45) when the bases are FRESH on every call
+ * (bulletproofs / spartan / hyrax generators): points and scalars come from HOST memory, nothing is precomputed and
+ * nothing stays resident (no window tables: W = 256 / c separate bucket sets, c = 16 from 2^12 points on, and a
+ * <= 255-doubling tail).  montgomery != 0: scalars are Fr elements (into_repr() fused), else canonical BigInteger256.
+ * Use the resident-handle entry points above when the same bases serve many MSMs (proving keys, SRS): they are ~3x faster. */
+int32_t zkp_msm_g1_var(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy_host, const uint8_t* inf_host,
+                       const uint64_t* scalars_host, size_t n, int32_t montgomery, uint64_t* out_xyz);
+int32_t zkp_msm_g2_var(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy_host, const uint8_t* inf_host,
+                       const uint64_t* scalars_host, size_t n, int32_t montgomery, uint64_t* out_xyz);
 /* KZG10::commit / open (marlin/src/pc/kzg10.rs:108-109,137-140): MSM of Montgomery Fr coefficients that are already
  * on the DEVICE against powers[offset ..] (offset = number of skipped leading zeros) */
 int32_t zkp_msm_g1_mont_dev(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* fr_scalars_dev, size_t n,

@@ -1,0 +1,337 @@
+//! `zkp-accel`: safe Rust face of `libzkp_accel.so` (include/zkp_accel.h) for sec-bit/ckb-zkp.
+//!
+//! What it replaces in the reference (file:line in the ckb-zkp tree):
+//!   * `ark_ec::msm::VariableBaseMSM::multi_scalar_mul`          groth16/src/prover.rs:187,190,220;
+//!                                                               marlin/src/pc/kzg10.rs:109,118,137,146
+//!   * `zkp_curve::Curve::vartime_multiscalar_mul`               curve/src/lib.rs:38-45
+//!   * `EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place`   groth16/src/r1cs_to_qap.rs:144-169
+//!   * `zkp_groth16::create_proof` after synthesis               groth16/src/prover.rs:148-210
+//!
+//! SOURCE ONLY — never compiled (no Rust toolchain in the authoring image).  arkworks 0.2 facts relied upon
+//! [recalled, to be confirmed by the first `cargo check`]:
+//!   * `Fp256<P>(pub BigInteger256, PhantomData<P>)`, `BigInteger256(pub [u64; 4])`: the public tuple field holds the
+//!     MONTGOMERY representation a*R mod p, little-endian limbs — exactly the ABI's field-element layout;
+//!     `Fp256::new(BigInteger256)` builds an element from that raw representation (what `field_new!` expands to);
+//!     the same for `Fp384` / `BigInteger384` (BLS12-381 Fq);
+//!   * `QuadExtField { pub c0, pub c1 }`;
+//!   * `GroupAffine { pub x, pub y, pub infinity }` (repr(Rust): copied field by field, never transmuted),
+//!     `GroupProjective::new(x, y, z)` is Jacobian (x = X/Z^2, y = Y/Z^3), identity = any Z == 0.
+use std::ffi::CStr;
+use std::os::raw::c_int;
+use std::ptr;
+
+use ark_ec::models::short_weierstrass_jacobian::{GroupAffine, GroupProjective};
+use ark_ec::models::SWModelParameters;
+use ark_ff::{BigInteger256, BigInteger384, Fp256, Fp256Parameters, Fp384, Fp384Parameters, QuadExtField, QuadExtParameters, Zero};
+
+pub mod ffi;
+pub mod groth16;
+
+/// Errors of the device library (zkp_status) — see `Error::into_synthesis_error` for the mapping the reference expects.
+#[derive(Debug, Clone, PartialEq, Eq)]
+pub enum Error {
+    BadArg,
+    UnsupportedCurve,
+    /// == `SynthesisError::PolynomialDegreeTooLarge` (groth16/src/r1cs_to_qap.rs:123-125)
+    DomainTooLarge,
+    OutOfDeviceMemory,
+    /// HIP runtime error or no gfx950 device.  The library has NO CPU fallback; callers that want one keep the arkworks
+    /// call and choose it here (see `msm_or_arkworks` in the patch under rust/patches/).
+    Device(String),
+    BadHandle,
+    Unknown(i32),
+}
+
+impl Error {
+    pub fn from_status(st: i32) -> Self {
+        match st {
+            ffi::ZKP_ERR_BAD_ARG => Error::BadArg,
+            ffi::ZKP_ERR_UNSUPPORTED_CURVE => Error::UnsupportedCurve,
+            ffi::ZKP_ERR_DOMAIN_TOO_LARGE => Error::DomainTooLarge,
+            ffi::ZKP_ERR_OOM => Error::OutOfDeviceMemory,
+            ffi::ZKP_ERR_DEVICE => {
+                let s = unsafe { CStr::from_ptr(ffi::zkp_status_string(st)) };
+                Error::Device(s.to_string_lossy().into_owned())
+            }
+            ffi::ZKP_ERR_BAD_HANDLE => Error::BadHandle,
+            other => Error::Unknown(other),
+        }
+    }
+    /// groth16 / marlin return `SynthesisError`; only the domain-size error has a counterpart there
+    /// (r1cs/src/error.rs): everything else surfaces as `IoError`-like failure of the backend.
+    pub fn into_synthesis_error(self) -> zkp_r1cs::SynthesisError {
+        match self {
+            Error::DomainTooLarge => zkp_r1cs::SynthesisError::PolynomialDegreeTooLarge,
+            other => zkp_r1cs::SynthesisError::IoError(std::io::Error::new(std::io::ErrorKind::Other, format!("zkp-accel: {:?}", other))),
+        }
+    }
+}
+
+fn check(st: i32) -> Result<(), Error> {
+    if st == ffi::ZKP_OK {
+        Ok(())
+    } else {
+        Err(Error::from_status(st))
+    }
+}
+
+/// One device context (`zkp_ctx`): one per prover thread / per GPU.  Not `Sync`: one in-flight call per context.
+pub struct Ctx(pub(crate) *mut ffi::zkp_ctx);
+unsafe impl Send for Ctx {}
+
+impl Ctx {
+    /// Export `GPU_MAX_HW_QUEUES=16` in the process environment BEFORE the first HIP call: the library
+    /// does not touch the environment.
+    pub fn new(device_id: i32) -> Result<Self, Error> {
+        let mut p: *mut ffi::zkp_ctx = ptr::null_mut();
+        check(unsafe { ffi::zkp_ctx_create(&mut p, device_id as c_int) })?;
+        Ok(Ctx(p))
+    }
+}
+impl Drop for Ctx {
+    fn drop(&mut self) {
+        unsafe { ffi::zkp_ctx_destroy(self.0) };
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ marshalling
+/// A base-field element that can be copied to / from the ABI's little-endian Montgomery limbs.
+pub trait AbiField: Sized + Copy {
+    /// u64 limbs per element (4: 256-bit fields, 6: BLS12-381 Fq, 8 / 12: their quadratic extensions)
+    const LIMBS: usize;
+    fn write_limbs(&self, out: &mut [u64]);
+    fn read_limbs(limbs: &[u64]) -> Self;
+}
+impl<P: Fp256Parameters> AbiField for Fp256<P> {
+    const LIMBS: usize = 4;
+    fn write_limbs(&self, out: &mut [u64]) {
+        out[..4].copy_from_slice(&(self.0).0); // Montgomery representation, as stored
+    }
+    fn read_limbs(l: &[u64]) -> Self {
+        Fp256::new(BigInteger256([l[0], l[1], l[2], l[3]]))
+    }
+}
+impl<P: Fp384Parameters> AbiField for Fp384<P> {
+    const LIMBS: usize = 6;
+    fn write_limbs(&self, out: &mut [u64]) {
+        out[..6].copy_from_slice(&(self.0).0);
+    }
+    fn read_limbs(l: &[u64]) -> Self {
+        Fp384::new(BigInteger384([l[0], l[1], l[2], l[3], l[4], l[5]]))
+    }
+}
+impl<P: QuadExtParameters> AbiField for QuadExtField<P>
+where
+    P::BaseField: AbiField,
+{
+    const LIMBS: usize = 2 * <P::BaseField as AbiField>::LIMBS;
+    fn write_limbs(&self, out: &mut [u64]) {
+        let h = <P::BaseField as AbiField>::LIMBS;
+        self.c0.write_limbs(&mut out[..h]); // ABI: (c0, c1)
+        self.c1.write_limbs(&mut out[h..2 * h]);
+    }
+    fn read_limbs(l: &[u64]) -> Self {
+        let h = <P::BaseField as AbiField>::LIMBS;
+        QuadExtField::new(<P::BaseField as AbiField>::read_limbs(&l[..h]), <P::BaseField as AbiField>::read_limbs(&l[h..2 * h]))
+    }
+}
+
+/// `&[GroupAffine]` -> AoS (x, y) limbs + identity flags (the ABI never looks at the coordinates of a flagged point).
+pub fn marshal_points<P: SWModelParameters>(pts: &[GroupAffine<P>]) -> (Vec<u64>, Vec<u8>)
+where
+    P::BaseField: AbiField,
+{
+    let l = <P::BaseField as AbiField>::LIMBS;
+    let mut xy = vec![0u64; pts.len() * 2 * l];
+    let mut inf = vec![0u8; pts.len()];
+    for (i, p) in pts.iter().enumerate() {
+        if p.infinity {
+            inf[i] = 1;
+        } else {
+            p.x.write_limbs(&mut xy[i * 2 * l..i * 2 * l + l]);
+            p.y.write_limbs(&mut xy[i * 2 * l + l..(i + 1) * 2 * l]);
+        }
+    }
+    (xy, inf)
+}
+
+/// Jacobian (X, Y, Z) limbs as returned by `zkp_msm_*` -> `GroupProjective` (identity: Z == 0 -> `zero()`).
+pub fn unmarshal_projective<P: SWModelParameters>(xyz: &[u64]) -> GroupProjective<P>
+where
+    P::BaseField: AbiField,
+{
+    let l = <P::BaseField as AbiField>::LIMBS;
+    let z = <P::BaseField as AbiField>::read_limbs(&xyz[2 * l..3 * l]);
+    if z.is_zero() {
+        return GroupProjective::<P>::zero();
+    }
+    GroupProjective::new(
+        <P::BaseField as AbiField>::read_limbs(&xyz[..l]),
+        <P::BaseField as AbiField>::read_limbs(&xyz[l..2 * l]),
+        z,
+    )
+}
+
+/// affine (x, y) limbs + flag -> `GroupAffine`
+pub fn unmarshal_affine<P: SWModelParameters>(xy: &[u64], infinity: bool) -> GroupAffine<P>
+where
+    P::BaseField: AbiField,
+{
+    let l = <P::BaseField as AbiField>::LIMBS;
+    if infinity {
+        return GroupAffine::<P>::zero();
+    }
+    GroupAffine::new(<P::BaseField as AbiField>::read_limbs(&xy[..l]), <P::BaseField as AbiField>::read_limbs(&xy[l..2 * l]), false)
+}
+
+/// Scalars: `BigInteger256` is `[u64; 4]` (canonical after `into_repr()`), `Fp256` stores its Montgomery limbs in the same
+/// shape; a slice of either is contiguous `4 * n` u64 — passed by pointer, no copy.
+pub fn scalars_ptr<T>(s: &[T]) -> *const u64 {
+    debug_assert_eq!(std::mem::size_of::<T>(), 32);
+    s.as_ptr() as *const u64
+}
+
+// ------------------------------------------------------------------------------------------------ curves
+/// Which ABI curve id / group a short-Weierstrass parameter set maps to.
+pub trait AccelGroup: SWModelParameters
+where
+    Self::BaseField: AbiField,
+{
+    const CURVE: c_int;
+    /// 1 = G1, 2 = G2
+    const GROUP: u8;
+}
+#[cfg(feature = "bn254")]
+impl AccelGroup for ark_bn254::g1::Parameters {
+    const CURVE: c_int = ffi::ZKP_BN254;
+    const GROUP: u8 = 1;
+}
+#[cfg(feature = "bn254")]
+impl AccelGroup for ark_bn254::g2::Parameters {
+    const CURVE: c_int = ffi::ZKP_BN254;
+    const GROUP: u8 = 2;
+}
+#[cfg(feature = "bls12_381")]
+impl AccelGroup for ark_bls12_381::g1::Parameters {
+    const CURVE: c_int = ffi::ZKP_BLS12_381;
+    const GROUP: u8 = 1;
+}
+#[cfg(feature = "bls12_381")]
+impl AccelGroup for ark_bls12_381::g2::Parameters {
+    const CURVE: c_int = ffi::ZKP_BLS12_381;
+    const GROUP: u8 = 2;
+}
+
+// ------------------------------------------------------------------------------------------------ MSM
+/// A query / SRS resident in HBM (`zkp_bases_upload_*`): upload once per `Parameters` / `CommitterKey`, prove many.
+pub struct ResidentBases<'c, P: AccelGroup>
+where
+    P::BaseField: AbiField,
+{
+    ctx: &'c Ctx,
+    handle: u64,
+    len: usize,
+    _p: std::marker::PhantomData<P>,
+}
+
+impl<'c, P: AccelGroup> ResidentBases<'c, P>
+where
+    P::BaseField: AbiField,
+{
+    pub fn upload(ctx: &'c Ctx, pts: &[GroupAffine<P>]) -> Result<Self, Error> {
+        let (xy, inf) = marshal_points(pts);
+        let mut handle = 0u64;
+        let st = unsafe {
+            if P::GROUP == 1 {
+                ffi::zkp_bases_upload_g1(ctx.0, P::CURVE, xy.as_ptr(), inf.as_ptr(), pts.len(), &mut handle)
+            } else {
+                ffi::zkp_bases_upload_g2(ctx.0, P::CURVE, xy.as_ptr(), inf.as_ptr(), pts.len(), &mut handle)
+            }
+        };
+        check(st)?;
+        Ok(ResidentBases { ctx, handle, len: pts.len(), _p: std::marker::PhantomData })
+    }
+    pub fn len(&self) -> usize {
+        self.len
+    }
+
+    /// drop-in for `VariableBaseMSM::multi_scalar_mul(&bases[offset..], scalars)` — canonical `BigInteger256` scalars
+    /// (the output of `into_repr()`); min(len) truncation as in arkworks.
+    pub fn msm(&self, offset: usize, scalars: &[BigInteger256]) -> Result<GroupProjective<P>, Error> {
+        let l = <P::BaseField as AbiField>::LIMBS;
+        let mut out = vec![0u64; 3 * l];
+        let st = unsafe {
+            if P::GROUP == 1 {
+                ffi::zkp_msm_g1(self.ctx.0, self.handle, offset, scalars_ptr(scalars), scalars.len(), out.as_mut_ptr())
+            } else {
+                ffi::zkp_msm_g2(self.ctx.0, self.handle, offset, scalars_ptr(scalars), scalars.len(), out.as_mut_ptr())
+            }
+        };
+        check(st)?;
+        Ok(unmarshal_projective::<P>(&out))
+    }
+
+    /// `Curve::vartime_multiscalar_mul` with resident points: `Fr` elements as they sit in memory (Montgomery);
+    /// `into_repr()` is fused into the device's digit scan.
+    pub fn vartime_multiscalar_mul<F>(&self, scalars: &[F]) -> Result<GroupProjective<P>, Error> {
+        let l = <P::BaseField as AbiField>::LIMBS;
+        let mut out = vec![0u64; 3 * l];
+        let st = unsafe {
+            if P::GROUP == 1 {
+                ffi::zkp_vartime_multiscalar_mul_g1(self.ctx.0, self.handle, scalars_ptr(scalars), scalars.len(), out.as_mut_ptr())
+            } else {
+                ffi::zkp_vartime_multiscalar_mul_g2(self.ctx.0, self.handle, scalars_ptr(scalars), scalars.len(), out.as_mut_ptr())
+            }
+        };
+        check(st)?;
+        Ok(unmarshal_projective::<P>(&out))
+    }
+}
+impl<'c, P: AccelGroup> Drop for ResidentBases<'c, P>
+where
+    P::BaseField: AbiField,
+{
+    fn drop(&mut self) {
+        unsafe { ffi::zkp_bases_free(self.ctx.0, self.handle) };
+    }
+}
+
+/// True variable-base MSM (`zkp_msm_g*_var`): fresh bases every call, nothing stays resident — the semantics of
+/// `Curve::vartime_multiscalar_mul(scalars, points)` for callers such as bulletproofs / spartan whose generators change.
+/// `montgomery = true`: `scalars` are `Fr` elements; `false`: canonical `BigInteger256`.
+pub fn msm_var<P: AccelGroup, S>(ctx: &Ctx, points: &[GroupAffine<P>], scalars: &[S], montgomery: bool) -> Result<GroupProjective<P>, Error>
+where
+    P::BaseField: AbiField,
+{
+    let n = points.len().min(scalars.len());
+    let (xy, inf) = marshal_points(&points[..n]);
+    let l = <P::BaseField as AbiField>::LIMBS;
+    let mut out = vec![0u64; 3 * l];
+    let st = unsafe {
+        if P::GROUP == 1 {
+            ffi::zkp_msm_g1_var(ctx.0, P::CURVE, xy.as_ptr(), inf.as_ptr(), scalars_ptr(scalars), n, montgomery as i32, out.as_mut_ptr())
+        } else {
+            ffi::zkp_msm_g2_var(ctx.0, P::CURVE, xy.as_ptr(), inf.as_ptr(), scalars_ptr(scalars), n, montgomery as i32, out.as_mut_ptr())
+        }
+    };
+    check(st)?;
+    Ok(unmarshal_projective::<P>(&out))
+}
+
+// ------------------------------------------------------------------------------------------------ NTT
+#[derive(Clone, Copy)]
+pub enum NttOp {
+    Fft = ffi::ZKP_NTT_FFT as isize,
+    Ifft = ffi::ZKP_NTT_IFFT as isize,
+    CosetFft = ffi::ZKP_NTT_COSET_FFT as isize,
+    CosetIfft = ffi::ZKP_NTT_COSET_IFFT as isize,
+}
+
+/// drop-in for `domain.{fft,ifft,coset_fft,coset_ifft}_in_place(&mut v)`: `v.len()` must be the domain size (a power of
+/// two; arkworks pads with zeros before calling — do the same), elements are `Fr` in memory layout.
+pub fn ntt_in_place<F>(ctx: &Ctx, curve: c_int, v: &mut [F], op: NttOp) -> Result<(), Error> {
+    debug_assert_eq!(std::mem::size_of::<F>(), 32);
+    assert!(v.len().is_power_of_two());
+    let log_n = v.len().trailing_zeros();
+    check(unsafe { ffi::zkp_ntt(ctx.0, curve, v.as_mut_ptr() as *mut u64, log_n, op as i32) })
+}

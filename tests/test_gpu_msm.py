@@ -255,3 +255,62 @@ def test_msm_host_generated_bases_vs_cpu_oracle(ctx, curve, group, log_n):
         assert got == G.mul(G.gen, e)
     finally:
         bases.free()
+
+
+@pytest.mark.parametrize("curve,group", CFG)
+def test_msm_var_true_variable_base_small(ctx, curve, group):
+    """zkp_msm_g*_var — `VariableBaseMSM::multi_scalar_mul(bases, scalars)` / `Curve::vartime_multiscalar_mul` with FRESH
+    host bases (curve/src/lib.rs:38-45): no window tables, W separate bucket sets, doubling tail.  Edge cases of
+    test_msm_small_edge_cases (c = 8 path), canonical and Montgomery scalars, against the oracle's naive MSM."""
+    c = get_curve(curve)
+    G = Group(OC[curve], group)
+    rnd = random.Random(17)
+    pts = random_points(curve, group, 24, seed=21 + group)
+    pts[3] = None
+    pts[5] = pts[4]
+    pts[7] = G.neg(pts[6])
+    ks = [rnd.randrange(c.r) for _ in range(24)]
+    ks[0], ks[1], ks[2], ks[8], ks[9] = 0, 1, c.r - 1, 2, 1 << 253
+    ks[5] = ks[4]
+    ks[7] = ks[6]
+    xy, inf = to_abi_points(curve, group, pts)
+    for n in (24, 17, 1, 0):
+        exp = G.msm_naive(pts[:n], ks[:n])
+        out = ctx.msm_var(c, group, xy[:n], inf[:n], codec.fr_canonical(ks[:n], c).reshape(-1, 4))
+        assert jac_limbs_to_affine_oracle(curve, group, out) == exp, n
+        out = ctx.msm_var(c, group, xy[:n], inf[:n], codec.fr_to_mont(ks[:n], c).reshape(-1, 4), montgomery=True)
+        assert jac_limbs_to_affine_oracle(curve, group, out) == exp, n
+    # no identity flags at all (NULL), more scalars than points (min(len) truncation)
+    out = ctx.msm_var(c, group, xy[:3], None, codec.fr_canonical(ks[:9], c).reshape(-1, 4))
+    assert jac_limbs_to_affine_oracle(curve, group, out) == G.msm_naive(pts[:3], ks[:3])
+
+
+@pytest.mark.parametrize("curve,group,log_n", [("bn254", 1, 13), ("bn254", 1, 17), ("bn254", 2, 13), ("bls12_381", 1, 14),
+                                               ("bls12_381", 2, 12)])
+def test_msm_var_equals_resident_msm_and_known_dlog(ctx, curve, group, log_n):
+    """The variable-base path (c = 16, 16 bucket sets) against the known-discrete-log expectation and against the
+    resident-table MSM on the same inputs, incl. zero / one scalars, an identity base and skewed (repeated) scalars."""
+    c = get_curve(curve)
+    G = Group(OC[curve], group)
+    n = (1 << log_n) - 7
+    rng = np.random.default_rng(log_n * 7 + group)
+    d = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    d[:, 3] >>= np.uint64(4)
+    d[9] = 0                                   # identity base
+    k = np.frombuffer(rng.bytes(32 * n), dtype=np.uint64).reshape(-1, 4).copy()
+    k[:, 3] &= np.uint64((1 << (c.r.bit_length() - 193)) - 1)
+    k[::7] = 0
+    k[1::11, 1:] = 0
+    k[1::11, 0] = 1
+    k[100:400] = k[99]                          # a 300-entry bucket in every window
+    g_xy, _ = to_abi_points(curve, group, [G.gen])
+    xy, inf = ctx.fixed_base_mul(c, group, g_xy, d)
+    assert inf[9] == 1
+    got = jac_limbs_to_affine_oracle(curve, group, ctx.msm_var(c, group, xy, inf, k))
+    e = sum(a * b for a, b in zip(codec.limbs_to_ints(d), codec.limbs_to_ints(k))) % c.r
+    assert got == G.mul(G.gen, e)
+    bases = ctx.upload_bases(c, group, xy, inf)
+    try:
+        assert jac_limbs_to_affine_oracle(curve, group, bases.msm(k)) == got
+    finally:
+        bases.free()
