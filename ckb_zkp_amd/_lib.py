@@ -110,6 +110,15 @@ SIGNATURES = {
     "zkp_groth16_assemble": (C.c_int32, [vp, C.c_int, vp, vp, vp, vp, vp]),
     "zkp_groth16_last_timing": (C.c_int32, [vp, C.POINTER(Groth16Timing)]),
     "zkp_set_profiling": (C.c_int32, [vp, C.c_int32]),
+    "zkp_fs_rng_new": (C.c_int32, [vp, C.c_size_t, C.POINTER(vp)]),
+    "zkp_fs_rng_free": (C.c_int32, [vp]),
+    "zkp_fs_rng_absorb": (C.c_int32, [vp, vp, C.c_size_t]),
+    "zkp_fs_rng_seed": (C.c_int32, [vp, vp]),
+    "zkp_fs_rng_next_u64": (C.c_int32, [vp, u64p]),
+    "zkp_fs_rng_rand_u128": (C.c_int32, [vp, vp]),
+    "zkp_fs_rng_rand_fr": (C.c_int32, [vp, C.c_int, vp]),
+    "zkp_fs_rng_sample_outside_domain": (C.c_int32, [vp, C.c_int, C.c_uint32, vp]),
+    "zkp_merlin_oneshot": (C.c_int32, [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t]),
     "zkp_bench_mulmod": (C.c_int32, [vp, C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
 }
 

@@ -259,6 +259,29 @@ int32_t zkp_groth16_prove_partials_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const u
 int32_t zkp_groth16_fold_assemble_dev(zkp_ctx* ctx, zkp_curve_t curve, const void* gathered_dev, int32_t world,
                                       const uint64_t* r, const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 
+/* ---- Marlin Fiat–Shamir RNG (host code): replaces marlin/src/fs_rng.rs:11-70 `FiatShamirRng` ----------------------------
+ * merlin 2.0 transcript "MARLINSEED" -> 32-byte seed -> ChaCha20 RNG (rand_chacha 0.2).  The byte strings absorbed are
+ * the caller's `to_bytes![...]` (marlin/src/lib.rs:105-158); samples come back in the ABI's field layout.
+ *   new                  FiatShamirRng::from_seed(&bytes)                       fs_rng.rs:41-53
+ *   absorb               seed = H(bytes || seed), re-key the ChaCha stream      fs_rng.rs:57-69
+ *   rand_fr              `Fr::rand(&mut fs_rng)` (ark-ff 0.2 rejection sampling; Montgomery limbs out)
+ *   sample_outside_domain  AHP::sample_element_outside_domain for a domain of 2^log_domain (ahp/verifier.rs:118-127)
+ *   rand_u128            `u128::rand(&mut fs_rng)` -> out[0] = low, out[1] = high 64 bits (lib.rs:158)
+ *   seed / next_u64      introspection for the parity tests
+ *   zkp_merlin_oneshot   Transcript::new(label); append_message(msg_label, msg); challenge_bytes(chal_label, out) */
+typedef struct zkp_fs_rng zkp_fs_rng;
+int32_t zkp_fs_rng_new(const uint8_t* seed_material, size_t len, zkp_fs_rng** out);
+int32_t zkp_fs_rng_free(zkp_fs_rng* rng);
+int32_t zkp_fs_rng_absorb(zkp_fs_rng* rng, const uint8_t* material, size_t len);
+int32_t zkp_fs_rng_seed(const zkp_fs_rng* rng, uint8_t out32[32]);
+int32_t zkp_fs_rng_next_u64(zkp_fs_rng* rng, uint64_t* out);
+int32_t zkp_fs_rng_rand_u128(zkp_fs_rng* rng, uint64_t out[2]);
+int32_t zkp_fs_rng_rand_fr(zkp_fs_rng* rng, zkp_curve_t curve, uint64_t* out_mont);
+int32_t zkp_fs_rng_sample_outside_domain(zkp_fs_rng* rng, zkp_curve_t curve, uint32_t log_domain, uint64_t* out_mont);
+int32_t zkp_merlin_oneshot(const uint8_t* label, size_t label_len, const uint8_t* msg_label, size_t msg_label_len,
+                           const uint8_t* msg, size_t msg_len, const uint8_t* chal_label, size_t chal_label_len,
+                           uint8_t* out, size_t out_len);
+
 /* ---- introspection for bench.py / rocprof bookkeeping ------------------------------------------ */
 typedef struct {
   float ms_total;          /* last zkp_groth16_prove*: stream time, HIP events */
