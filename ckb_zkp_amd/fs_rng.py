@@ -133,3 +133,62 @@ def index_verifier_key_bytes(ivk: dict, curve) -> bytes:
         out += commitment_bytes(cm, curve)
     out += g1_bytes(ivk["g"], curve) + g1_bytes(ivk["gamma_g"], curve) + g2_bytes(ivk["h"], curve) + g2_bytes(ivk["beta_h"], curve)
     return out + struct.pack("<Q", ivk["supported_degree"])
+
+
+# ---------------------------------------------------------------- verifier messages of create_random_proof
+class FixedChallenger:
+    """TEST HOOK ONLY: verifier messages supplied up front (round-by-round parity with the oracle).  A prover run this
+    way is not sound — `FiatShamirChallenger` is what `create_random_proof` uses."""
+
+    def __init__(self, ch: dict):
+        self.ch = dict(ch)
+
+    def first(self, comms):
+        c = self.ch
+        return c["alpha"], c["eta_a"], c["eta_b"], c["eta_c"]
+
+    def second(self, comms):
+        return self.ch["beta"]
+
+    def third(self, comms):
+        return self.ch["gamma"]
+
+    def opening(self, evals):
+        return self.ch["xi"]
+
+
+class FiatShamirChallenger:
+    """marlin/src/lib.rs:105-158: seed the rng with to_bytes![index_verifier_key, public_input]; before each verifier
+    round absorb the round's commitments and draw that round's message (ahp/verifier.rs:41-87); absorb the evaluations and
+    draw the 128-bit opening challenge (lib.rs:157-158)."""
+
+    def __init__(self, curve, domain_h_size: int, ivk: dict, public_input):
+        self.curve, self.hs = get_curve(curve), domain_h_size
+        self.rng = FiatShamirRng(index_verifier_key_bytes(ivk, self.curve) +
+                                 b"".join(fr_bytes(x, self.curve) for x in public_input))
+        self.ch = {}
+
+    def _absorb_comms(self, comms):
+        self.rng.absorb(b"".join(commitment_bytes(cm, self.curve) for cm in comms))
+
+    def first(self, comms):
+        self._absorb_comms(comms)
+        alpha = self.rng.sample_outside_domain(self.curve, self.hs)
+        ea, eb, ec = (self.rng.rand_fr(self.curve) for _ in range(3))
+        self.ch.update(alpha=alpha, eta_a=ea, eta_b=eb, eta_c=ec)
+        return alpha, ea, eb, ec
+
+    def second(self, comms):
+        self._absorb_comms(comms)
+        self.ch["beta"] = self.rng.sample_outside_domain(self.curve, self.hs)
+        return self.ch["beta"]
+
+    def third(self, comms):
+        self._absorb_comms(comms)
+        self.ch["gamma"] = self.rng.rand_fr(self.curve)
+        return self.ch["gamma"]
+
+    def opening(self, evals):
+        self.rng.absorb(b"".join(fr_bytes(e, self.curve) for e in evals))
+        self.ch["xi"] = self.rng.rand_u128()
+        return self.ch["xi"]

@@ -29,6 +29,7 @@ class CommitterKey:
     supported_degree: int
     host_g: tuple = None         # (xy, inf) kept for tests
     host_gamma_g: tuple = None
+    vk_g2: tuple = None          # (h, beta_h) canonical G2 points: the VerifierKey's G2 half (pc/data_structures.rs:100-109)
 
 
 def _device_powers(ctx: Context, c, n: int, beta: int, k: int) -> np.ndarray:
@@ -51,13 +52,17 @@ def _device_powers(ctx: Context, c, n: int, beta: int, k: int) -> np.ndarray:
     return out
 
 
-def setup(ctx: Context, curve, max_degree: int, beta: int, g_k: int = 1, gamma_k: int = 7) -> CommitterKey:
-    """KZG10::setup + trim with explicit toxic waste: powers_of_g[i] = beta^i * (g_k G), powers_of_gamma_g likewise."""
+def setup(ctx: Context, curve, max_degree: int, beta: int, g_k: int = 1, gamma_k: int = 7, h_k: int = 1) -> CommitterKey:
+    """KZG10::setup + trim with explicit toxic waste: powers_of_g[i] = beta^i * (g_k G), powers_of_gamma_g likewise;
+    h = h_k * G2, beta_h = beta * h (kzg10.rs:27-60)."""
     c = get_curve(curve)
     base, _ = codec.g1_to_mont([c.g1], c)
     g = ctx.fixed_base_mul(c, 1, base, _device_powers(ctx, c, max_degree + 1, beta, g_k))
     gg = ctx.fixed_base_mul(c, 1, base, _device_powers(ctx, c, max_degree + 1, beta, gamma_k))
-    return CommitterKey(c, ctx.upload_bases(c, 1, *g), ctx.upload_bases(c, 1, *gg), max_degree, g, gg)
+    base2, _ = codec.g2_to_mont([c.g2], c)
+    h_xy, h_inf = ctx.fixed_base_mul(c, 2, base2, codec.fr_canonical([h_k % c.r, h_k * beta % c.r], c))
+    vk_g2 = tuple(codec.g2_from_mont(h_xy, h_inf, c))
+    return CommitterKey(c, ctx.upload_bases(c, 1, *g), ctx.upload_bases(c, 1, *gg), max_degree, g, gg, vk_g2)
 
 
 def _leading_zeros(coeffs_mont: np.ndarray) -> int:

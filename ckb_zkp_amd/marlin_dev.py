@@ -340,6 +340,7 @@ class DeviceIndex:
         self.on_k = {m: {k: be.upload(S[m]["on_k"][k]) for k in ("row", "col", "val")} for m in "abc"}
         self.on_b = {m: {k: be.upload(S[m]["on_b"][k]) for k in ("row", "col", "val", "row_col")} for m in "abc"}
         self.polys = {f"{m}_{k}": be.upload(S[m]["polys"][k]) for m in "abc" for k in ("row", "col", "val", "row_col")}
+        self.num_non_zeros = max(sum(len(row) for row in idx[m]) for m in "abc")
         self._finish(xs, hs, idx["ks"], idx["bs"], len(idx["a"]))
         return self
 
@@ -400,10 +401,42 @@ class DeviceIndex:
         return out
 
 
+def index_verifier_key(didx: DeviceIndex, ck: kzg10.CommitterKey, index_comms: dict, vk_g2) -> dict:
+    """IndexVerifierKey (marlin/src/data_structures.rs:10-15) in the shape the transcript serialises (lib.rs:79-84):
+    index_info, the 12 index commitments in `Index::iter` order, VerifierKey {g, gamma_g, h, beta_h, supported_degree}.
+    vk_g2 = (h, beta_h): the G2 half of the SRS (never used by the prover except inside the transcript seed)."""
+    c = didx.curve
+    first = lambda q: codec.g1_from_mont(q[0][:1], q[1][:1], c)[0]
+    return dict(num_variables=didx.nrows, num_constraints=didx.nrows, num_non_zeros=didx.num_non_zeros,
+                index_comms=[index_comms[l] for l in INDEX_LABELS], g=first(ck.host_g), gamma_g=first(ck.host_gamma_g),
+                h=vk_g2[0], beta_h=vk_g2[1], supported_degree=didx.max_degree)
+
+
+def create_random_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, ivk: dict, circuit, rnd,
+                        timing: dict | None = None):
+    """marlin::create_random_proof (lib.rs:97-181): the verifier messages are DERIVED from the Fiat–Shamir transcript
+    (library FiatShamirRng seeded with to_bytes![ivk, public_input]).  circuit: a synthesizer or (formatted inputs incl.
+    the leading one, witness)."""
+    from .fs_rng import FiatShamirChallenger
+    if hasattr(circuit, "generate_constraints"):
+        cs = MarlinCS(didx.curve, assign=True)
+        circuit.generate_constraints(cs)
+        public = cs.input_assignment[1:]
+    else:
+        public = list(circuit[0])[1:]
+    chal = FiatShamirChallenger(didx.curve, didx.hs, ivk, public)
+    return create_proof(ctx, didx, ck, circuit, rnd, chal, timing)
+
+
 def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circuit, rnd, ch, timing: dict | None = None):
-    """Device-resident `create_random_proof` with explicit randomness / challenges (same dictionaries as
-    marlin.create_proof).  Returns commitments, evaluations (query order) and opening proofs as canonical integers."""
+    """Device-resident Marlin prover, round by round as lib.rs:97-181 prescribes: AHP round -> PC::commit of the round's
+    oracles (one batched MSM call) -> absorb -> next verifier message.  ch: a challenger (fs_rng.FiatShamirChallenger via
+    `create_random_proof`; fs_rng.FixedChallenger or a plain dict = test hook with supplied messages).  rnd: the zk
+    randomness (masks, blinders) as in marlin.create_proof.  Returns commitments, evaluations (query order), opening
+    proofs and the challenges used, as canonical integers."""
     import time
+    from .fs_rng import FixedChallenger
+    chal = FixedChallenger(ch) if isinstance(ch, dict) else ch
     c = didx.curve
     r = c.r
     be = DeviceBackend(ctx, c)
@@ -447,8 +480,52 @@ def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circui
         be.add_at(mask, 0, -be.element(mrem, 0))
         polys = dict(didx.polys)
         polys.update(w=w_poly, z_a=z_a, z_b=z_b, mask=mask)
+        # ---- PC::commit (pc/mod.rs:34-71) of one round's oracles: MSMs against the resident powers, one batched call per
+        # base vector (the MSMs of the round overlap on the context's MSM streams)
+        bounds = {"g_1": hs - 2, "g_2": ks - 2}
+        hide = lambda l: l in ("w", "z_a", "z_b", "g_1")
+        blind_dev = {l: be.upload(rnd["blind"][l]) for l in ("w", "z_a", "z_b", "g_1")}
+        blind_s_dev = {"g_1": be.upload(rnd["blind_shifted"]["g_1"])}
+        comms = {}
+        t_commit_acc = [0.0]
+
+        def to_affine(jac):
+            xy, inf = ctx.into_affine(c, 1, jac)
+            return codec.g1_from_mont(xy, [inf], c)[0]
+
+        def commit_round(labels):
+            tc0 = time.perf_counter()
+            jobs, slot = [], {}
+            for l in labels:
+                slot[(l, False)] = len(jobs)
+                jobs.append((polys[l].ptr, polys[l].n, 0))
+                if l in bounds:                                  # shifted_powers(bound) = powers[D - bound ..]
+                    slot[(l, True)] = len(jobs)
+                    jobs.append((polys[l].ptr, polys[l].n, D - bounds[l]))
+            jac = ck.powers_of_g.msm_mont_batch_dev(jobs)
+            bjobs, bslot = [], {}
+            for l in labels:
+                if hide(l):
+                    bslot[(l, False)] = len(bjobs)
+                    bjobs.append((blind_dev[l].ptr, 2, 0))
+                    if l in bounds:
+                        bslot[(l, True)] = len(bjobs)
+                        bjobs.append((blind_s_dev[l].ptr, 2, 0))
+            bjac = ck.powers_of_gamma_g.msm_mont_batch_dev(bjobs) if bjobs else []
+
+            def point(l, shifted):
+                j = jac[slot[(l, shifted)]]
+                if (l, shifted) in bslot:
+                    j = ctx.fold(c, 1, np.concatenate([j, bjac[bslot[(l, shifted)]]]))
+                return to_affine(j)
+
+            for l in labels:
+                comms[l] = (point(l, False), point(l, True) if l in bounds else None)
+            t_commit_acc[0] += time.perf_counter() - tc0
+            return [comms[l] for l in labels]
+
+        alpha, ea, eb, ec = chal.first(commit_round(LABELS_1))          # lib.rs:109-114
         # ---- second round (prover.rs:230-321)
-        alpha, ea, eb, ec, beta, gamma = ch["alpha"], ch["eta_a"], ch["eta_b"], ch["eta_c"], ch["beta"], ch["gamma"]
         m_poly = be.axpy(be.axpy(be.scale(be.pmul(z_a, z_b), ec), z_a, ea), z_b, eb)
         v_alpha = (pow(alpha, hs, r) - 1) % r
         r_alpha_on_h = be.scale(be.binv(be.addc(be.scale(didx.h_el, r - 1), alpha)), v_alpha)
@@ -464,6 +541,7 @@ def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circui
         q1 = be.axpy(be.ifft(prod, size), mask, 1)
         h1, xg1 = be.fold(q1, hs)
         polys.update(t=t_poly, g_1=xg1.view(1, hs), h_1=h1.view(0, 2 * hs))
+        beta = chal.second(commit_round(LABELS_2))                      # lib.rs:117-121
         # ---- third round (prover.rs:331-427)
         va, vb = v_alpha, (pow(beta, hs, r) - 1) % r
         acc = be.zeros(ks)
@@ -485,51 +563,14 @@ def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circui
         # degrees: a, b <= 3|K| - 3; t3 < |K|
         h2, _ = be.fold(be.sub(a_poly.view(0, 3 * ks - 2), be.pmul(b_poly.view(0, 3 * ks - 2), t3)), ks)
         polys.update(g_2=t3.view(1, ks), h_2=h2.view(0, 3 * ks - 3))
+        gamma = chal.third(commit_round(LABELS_3))                      # lib.rs:124-128
         ctx.sync()
         t_rounds = time.perf_counter()
-        # ---- PC::commit (pc/mod.rs:34-71): MSMs against the resident powers
-        bounds = {"g_1": hs - 2, "g_2": ks - 2}
-        hide = lambda l: l in ("w", "z_a", "z_b", "g_1")
-        blind_dev = {l: be.upload(rnd["blind"][l]) for l in ("w", "z_a", "z_b", "g_1")}
-        blind_s_dev = {"g_1": be.upload(rnd["blind_shifted"]["g_1"])}
-
-        def to_affine(jac):
-            xy, inf = ctx.into_affine(c, 1, jac)
-            return codec.g1_from_mont(xy, [inf], c)[0]
-
-        # one batched call per base vector: the MSMs overlap three at a time on the context's MSM streams
-        labels = LABELS_1 + LABELS_2 + LABELS_3
-        jobs, slot = [], {}
-        for l in labels:
-            slot[(l, False)] = len(jobs)
-            jobs.append((polys[l].ptr, polys[l].n, 0))
-            if l in bounds:                                  # shifted_powers(bound) = powers[D - bound ..]
-                slot[(l, True)] = len(jobs)
-                jobs.append((polys[l].ptr, polys[l].n, D - bounds[l]))
-        jac = ck.powers_of_g.msm_mont_batch_dev(jobs)
-        bjobs, bslot = [], {}
-        for l in labels:
-            if hide(l):
-                bslot[(l, False)] = len(bjobs)
-                bjobs.append((blind_dev[l].ptr, 2, 0))
-                if l in bounds:
-                    bslot[(l, True)] = len(bjobs)
-                    bjobs.append((blind_s_dev[l].ptr, 2, 0))
-        bjac = ck.powers_of_gamma_g.msm_mont_batch_dev(bjobs)
-
-        def point(l, shifted):
-            j = jac[slot[(l, shifted)]]
-            if (l, shifted) in bslot:
-                j = ctx.fold(c, 1, np.concatenate([j, bjac[bslot[(l, shifted)]]]))
-            return to_affine(j)
-
-        comms = {l: (point(l, False), point(l, True) if l in bounds else None) for l in labels}
-        ctx.sync()
-        t_commit = time.perf_counter()
+        t_commit = t_rounds
         # ---- evaluations + batch_open (lib.rs:147-165, pc/mod.rs:73-160)
         query = sorted([(l, beta) for l in LABELS_1 + LABELS_2] + [(l, gamma) for l in LABELS_3 + INDEX_LABELS])
         evals = [be.evaluate(polys[l], pt) for l, pt in query]
-        xi = ch["xi"]
+        xi = chal.opening(evals)                                        # lib.rs:157-158
         points = sorted({pt for _, pt in query})
         wjobs, rbs = [], []
         for pt in points:
@@ -563,8 +604,9 @@ def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circui
         ctx.sync()
         t_open = time.perf_counter()
         if timing is not None:
-            timing.update(synthesis_upload_s=t0 - t_start, rounds_s=t_rounds - t0, commit_s=t_commit - t_rounds,
+            timing.update(synthesis_upload_s=t0 - t_start, rounds_s=t_rounds - t0 - t_commit_acc[0], commit_s=t_commit_acc[0],
                           eval_open_s=t_open - t_commit, total_s=t_open - t0)
-        return dict(commitments=comms, evaluations=evals, opening_proofs=proofs, query=query)
+        return dict(commitments=comms, evaluations=evals, opening_proofs=proofs, query=query,
+                    challenges=dict(alpha=alpha, eta_a=ea, eta_b=eb, eta_c=ec, beta=beta, gamma=gamma, xi=xi))
     finally:
         be.release_all()

@@ -8,9 +8,10 @@ Follows /root/reference/marlin/src:
   ahp/verifier.rs:89-115,128-210           query set, verifier_equality_check
   pc/mod.rs:34-100,122-160,204-240         PC::commit / open / batch_open / accumulate_commitments_and_values
   lib.rs:97-181,184-250                    create_random_proof, verify_proof
-Everything the reference draws from an RNG (zk masks, commitment blinders) or from the Fiat–Shamir transcript
-(alpha, eta_*, beta, gamma, opening challenge) is an explicit input: the merlin/ChaCha transcript is out of scope
-(SURVEY.md §8(f)-4), so parity is per round for fixed challenges.
+What the reference draws from the zk RNG (masks, commitment blinders) is an explicit input.  The verifier messages
+(alpha, eta_*, beta, gamma, opening challenge) come from a `challenger`: either FiatShamirChallenger — the reference's
+transcript (fs_rng.rs; lib.rs:105-158: seed from index_verifier_key || public_input, absorb the round's commitments,
+squeeze) via oracle/pyref/fs_rng.py — or FixedChallenger (a dict; per-round parity tests).
 Polynomials are coefficient lists (low degree first) of canonical ints.
 """
 from __future__ import annotations
@@ -304,31 +305,126 @@ def hiding(label):
     return label in ("w", "z_a", "z_b", "g_1")
 
 
+class FixedChallenger:
+    """test hook: verifier messages supplied up front"""
+
+    def __init__(self, ch):
+        self.ch = dict(ch)
+
+    def first(self, comms):
+        c = self.ch
+        return c["alpha"], c["eta_a"], c["eta_b"], c["eta_c"]
+
+    def second(self, comms):
+        return self.ch["beta"]
+
+    def third(self, comms):
+        return self.ch["gamma"]
+
+    def opening(self, evals):
+        return self.ch["xi"]
+
+
+class FiatShamirChallenger:
+    """lib.rs:105-158 (prover) == lib.rs:190-215 (verifier): FiatShamirRng::from_seed(to_bytes![ivk, public_input]);
+    absorb(to_bytes![round commitments]) before each verifier round; absorb(&evaluations) before the opening challenge."""
+
+    def __init__(self, idx, ivk: dict, public_input):
+        from . import fs_rng as F
+        self.F, self.curve, self.hs = F, idx["curve"], idx["dh"].size
+        self.rng = F.FiatShamirRng(F.index_verifier_key_bytes(ivk, self.curve) +
+                                   b"".join(F.fr_bytes(x, self.curve) for x in public_input))
+        self.ch = {}
+
+    def _absorb_comms(self, comms):
+        self.rng.absorb(b"".join(self.F.commitment_bytes(cm, self.curve) for cm in comms))
+
+    def first(self, comms):
+        self._absorb_comms(comms)
+        alpha = self.rng.sample_outside_domain(self.curve, self.hs)              # ahp/verifier.rs:53
+        ea, eb, ec = (self.rng.rand_fr(self.curve) for _ in range(3))            # :54-56
+        self.ch.update(alpha=alpha, eta_a=ea, eta_b=eb, eta_c=ec)
+        return alpha, ea, eb, ec
+
+    def second(self, comms):
+        self._absorb_comms(comms)
+        self.ch["beta"] = self.rng.sample_outside_domain(self.curve, self.hs)    # :76
+        return self.ch["beta"]
+
+    def third(self, comms):
+        self._absorb_comms(comms)
+        self.ch["gamma"] = self.rng.rand_fr(self.curve)                          # :86
+        return self.ch["gamma"]
+
+    def opening(self, evals):
+        self.rng.absorb(b"".join(self.F.fr_bytes(e, self.curve) for e in evals))  # lib.rs:157
+        self.ch["xi"] = self.rng.rand_u128()                                      # lib.rs:158
+        return self.ch["xi"]
+
+
+def index_verifier_key(idx, pp, index_comms) -> dict:
+    """IndexVerifierKey (data_structures.rs:10-15) as the transcript sees it (lib.rs:79-84: comms in Index::iter order)"""
+    return dict(num_variables=idx["num_variables"], num_constraints=idx["num_constraints"],
+                num_non_zeros=idx["num_non_zeros"], index_comms=[index_comms[l] for l in INDEX_LABELS],
+                g=pp["g"], gamma_g=pp["gamma_g"], h=pp["h"], beta_h=pp["beta_h"], supported_degree=idx["max_degree"])
+
+
 def create_proof(idx, pp, circuit, rnd, ch):
-    """rnd: first-round masks + `blind[label]`, `blind_shifted[label]` (2 coeffs each, hiding bound 1);
-    ch: alpha, eta_a, eta_b, eta_c, beta, gamma, xi."""
+    """lib.rs:97-181.  rnd: first-round masks + `blind[label]`, `blind_shifted[label]` (2 coeffs each, hiding bound 1);
+    ch: a challenger (FiatShamirChallenger = the reference's create_random_proof) or a dict alpha, eta_a, eta_b, eta_c,
+    beta, gamma, xi (FixedChallenger)."""
+    chal = FixedChallenger(ch) if isinstance(ch, dict) else ch
     curve = idx["curve"]
     r = curve.r
     D = idx["max_degree"]
-    st = prover_init(idx, circuit)
-    o1 = first_round(idx, st, rnd)
-    o2 = second_round(idx, st, o1, ch["alpha"], ch["eta_a"], ch["eta_b"], ch["eta_c"])
-    o3 = third_round(idx, ch["alpha"], ch["eta_a"], ch["eta_b"], ch["eta_c"], ch["beta"])
-    polys = {f"{m}_{k}": idx["star"][m]["polys"][k] for m in "abc" for k in ("row", "col", "val", "row_col")}
-    polys.update({k: o1[k] for k in LABELS_1})
-    polys.update(o2)
-    polys.update(o3)
     bounds = degree_bounds(idx)
     blind = lambda l: rnd["blind"][l] if hiding(l) else None
     blind_s = lambda l: rnd["blind_shifted"][l] if (hiding(l) and l in bounds) else None
-    comms = {l: pc_commit(pp, D, polys[l], bounds.get(l), blind(l), blind_s(l)) for l in LABELS_1 + LABELS_2 + LABELS_3}
-    query = sorted([(l, ch["beta"]) for l in LABELS_1 + LABELS_2] + [(l, ch["gamma"]) for l in LABELS_3 + INDEX_LABELS])
+    polys = {f"{m}_{k}": idx["star"][m]["polys"][k] for m in "abc" for k in ("row", "col", "val", "row_col")}
+    comms = {}
+
+    def commit_round(labels):
+        for l in labels:
+            comms[l] = pc_commit(pp, D, polys[l], bounds.get(l), blind(l), blind_s(l))
+        return [comms[l] for l in labels]
+
+    st = prover_init(idx, circuit)
+    o1 = first_round(idx, st, rnd)
+    polys.update({k: o1[k] for k in LABELS_1})
+    alpha, ea, eb, ec = chal.first(commit_round(LABELS_1))
+    polys.update(second_round(idx, st, o1, alpha, ea, eb, ec))
+    beta = chal.second(commit_round(LABELS_2))
+    polys.update(third_round(idx, alpha, ea, eb, ec, beta))
+    gamma = chal.third(commit_round(LABELS_3))
+    query = sorted([(l, beta) for l in LABELS_1 + LABELS_2] + [(l, gamma) for l in LABELS_3 + INDEX_LABELS])
     evals = [K.evaluate(polys[l], pt, r) for l, pt in query]
+    xi = chal.opening(evals)
     proofs = []
     for pt in sorted({pt for _, pt in query}):
         labels = sorted(l for l, p in query if p == pt)
-        proofs.append(pc_open(pp, D, [(polys[l], bounds.get(l), blind(l), blind_s(l)) for l in labels], pt, ch["xi"]))
-    return dict(commitments=comms, evaluations=evals, opening_proofs=proofs, polys=polys, query=query)
+        proofs.append(pc_open(pp, D, [(polys[l], bounds.get(l), blind(l), blind_s(l)) for l in labels], pt, xi))
+    return dict(commitments=comms, evaluations=evals, opening_proofs=proofs, polys=polys, query=query,
+                challenges=dict(alpha=alpha, eta_a=ea, eta_b=eb, eta_c=ec, beta=beta, gamma=gamma, xi=xi))
+
+
+def create_random_proof(idx, pp, index_comms, circuit, rnd):
+    """marlin::create_random_proof (lib.rs:97-181): verifier messages derived from the Fiat–Shamir transcript."""
+    st = prover_init(idx, circuit)
+    chal = FiatShamirChallenger(idx, index_verifier_key(idx, pp, index_comms), st["x"][1:])
+    return create_proof(idx, pp, circuit, rnd, chal)
+
+
+def verify_random_proof(idx, pp, index_comms, proof, public_input) -> bool:
+    """marlin::verify_proof (lib.rs:184-250): replay the transcript on the proof's commitments / evaluations, then the
+    algebraic and pairing checks.  proof needs only commitments, evaluations, opening_proofs (query is rebuilt)."""
+    chal = FiatShamirChallenger(idx, index_verifier_key(idx, pp, index_comms), public_input)
+    cm = proof["commitments"]
+    chal.first([cm[l] for l in LABELS_1])
+    beta = chal.second([cm[l] for l in LABELS_2])
+    gamma = chal.third([cm[l] for l in LABELS_3])
+    chal.opening(proof["evaluations"])
+    query = sorted([(l, beta) for l in LABELS_1 + LABELS_2] + [(l, gamma) for l in LABELS_3 + INDEX_LABELS])
+    return verify_proof(idx, pp, index_comms, dict(proof, query=query), public_input, chal.ch)
 
 
 def index_commitments(idx, pp):

@@ -136,6 +136,20 @@ def test_device_resident_marlin_matches_oracle_and_verifies(ctx, curve, kind):
         ic = om.index_commitments(oidx, pp)
         assert om.verify_proof(oidx, pp, ic, proof, public, ch)
         assert timing["total_s"] > 0
+        # ---- create_random_proof: verifier messages DERIVED from the Fiat–Shamir transcript (lib.rs:105-158), by the
+        # library's FiatShamirRng on the device side and by the oracle's independent implementation on the other
+        assert didx.commit_index(ctx, ck) == ic
+        ivk = marlin_dev.index_verifier_key(didx, ck, ic, ck.vk_g2)
+        assert ivk == om.index_verifier_key(oidx, pp, ic)
+        rproof = marlin_dev.create_random_proof(ctx, didx, ck, ivk, pcirc_w, R)
+        oproof = om.create_random_proof(oidx, pp, ic, ocirc, R)
+        assert rproof["challenges"] == oproof["challenges"]
+        assert rproof["commitments"] == oproof["commitments"] and rproof["evaluations"] == oproof["evaluations"]
+        assert rproof["opening_proofs"] == oproof["opening_proofs"]
+        wire = dict(commitments=rproof["commitments"], evaluations=rproof["evaluations"], opening_proofs=rproof["opening_proofs"])
+        assert om.verify_random_proof(oidx, pp, ic, wire, public)          # marlin::verify_proof, challenges re-derived
+        assert not om.verify_random_proof(oidx, pp, ic, wire, [(p + 1) % c.r for p in public] or [5])
+        assert rproof["challenges"]["alpha"] != ch["alpha"]
     finally:
         ck.powers_of_g.free()
         ck.powers_of_gamma_g.free()
@@ -217,15 +231,23 @@ def test_marlin_config4_full_size_verifies(ctx):
         rnd = random.Random(44)
         R, ch = _rand_inputs(c, 1, seed=45)
         R["mask"] = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(3 * didx.hs)], c).reshape(-1, 4)
-        proof = marlin_dev.create_proof(ctx, didx, ck, (inst.z[:1], inst.z[1:]), R, ch)
         oc = OC[curve]
         G1, G2 = Group(oc, 1), Group(oc, 2)
         pp = dict(curve=oc, g=G1.gen, gamma_g=G1.mul(G1.gen, 7), h=G2.gen, beta_h=G2.mul(G2.gen, beta_srs))
-        oidx = dict(curve=oc, dh=Domain(oc, didx.hs), dk=Domain(oc, didx.ks), max_degree=didx.max_degree)
+        assert ck.vk_g2 == (pp["h"], pp["beta_h"])
+        oidx = dict(curve=oc, dh=Domain(oc, didx.hs), dk=Domain(oc, didx.ks), max_degree=didx.max_degree,
+                    num_variables=didx.nrows, num_constraints=didx.nrows, num_non_zeros=didx.num_non_zeros)
         ic = didx.commit_index(ctx, ck)
+        # create_random_proof: every verifier message derived from the transcript; the oracle's verifier re-derives them
+        ivk = marlin_dev.index_verifier_key(didx, ck, ic, ck.vk_g2)
+        proof = marlin_dev.create_random_proof(ctx, didx, ck, ivk, (inst.z[:1], inst.z[1:]), R)
+        wire = dict(commitments=proof["commitments"], evaluations=proof["evaluations"], opening_proofs=proof["opening_proofs"])
+        assert om.verify_random_proof(oidx, pp, ic, wire, [])
+        bad = dict(wire, evaluations=wire["evaluations"][:3] + [(wire["evaluations"][3] + 1) % c.r] + wire["evaluations"][4:])
+        assert not om.verify_random_proof(oidx, pp, ic, bad, [])
+        # and the fixed-challenge test hook still yields an accepting proof for the supplied messages
+        proof = marlin_dev.create_proof(ctx, didx, ck, (inst.z[:1], inst.z[1:]), R, ch)
         assert om.verify_proof(oidx, pp, ic, proof, [], ch)
-        bad = dict(proof, evaluations=proof["evaluations"][:3] + [(proof["evaluations"][3] + 1) % c.r] + proof["evaluations"][4:])
-        assert not om.verify_proof(oidx, pp, ic, bad, [], ch)
     finally:
         ck.powers_of_g.free()
         ck.powers_of_gamma_g.free()
