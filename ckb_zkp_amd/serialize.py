@@ -359,3 +359,124 @@ def parameters_from_bytes(b: bytes, curve, checked: bool = True) -> dict:
     if r.o != len(b):
         raise SerializationError("InvalidData")
     return out
+
+
+# ------------------------------------------------------------------ zkp-marlin (CanonicalSerialize derives)
+# marlin/src/pc/data_structures.rs:59-65 CommitterKey, :100-109 VerifierKey, :121-122 Comm, :137-141 Commitment,
+# :300-304 pc::Proof; marlin/src/ahp/indexer.rs:12-17 IndexInfo; marlin/src/data_structures.rs:10-15 IndexVerifierKey,
+# :43-48 Proof.  Derived impls write the fields in declaration order; `usize` as u64; `Option<T>` as a bool byte followed
+# by the value when present; `bool` as one byte (ark-serialize 0.2, restated — PARITY UNPINNED like the rest of this file).
+def _u64(v: int) -> bytes:
+    return struct.pack("<Q", v)
+
+
+def _option(v, enc) -> bytes:
+    return b"\x00" if v is None else b"\x01" + enc(v)
+
+
+def _read_option(r: _Reader, dec):
+    flag = r.take(1)[0]
+    if flag > 1:
+        raise SerializationError("InvalidData")
+    return dec() if flag else None
+
+
+def marlin_commitment_to_bytes(comm, curve) -> bytes:
+    """pc::Commitment { comm: Comm(G1Affine), shifted_comm: Option<Comm> }; comm = (point, shifted point or None)"""
+    c, shifted = comm
+    return g1_to_bytes(c, curve) + _option(shifted, lambda p: g1_to_bytes(p, curve))
+
+
+def _read_marlin_commitment(r: _Reader, c: CurveParams, checked: bool):
+    n = _fq_bytes(c)
+    cm = g1_from_bytes(r.take(n), c, checked=checked)
+    return cm, _read_option(r, lambda: ("some", g1_from_bytes(r.take(n), c, checked=checked)))
+
+
+def marlin_commitment_from_bytes(b: bytes, curve, checked: bool = True):
+    r = _Reader(b)
+    cm, sh = _read_marlin_commitment(r, get_curve(curve), checked)
+    if r.o != len(b):
+        raise SerializationError("InvalidData")
+    return cm, (sh[1] if sh else None)
+
+
+def marlin_committer_key_to_bytes(powers_of_g, powers_of_gamma_g, supported_degree: int, curve) -> bytes:
+    g1 = lambda p: g1_to_bytes(p, curve)
+    return _vec(powers_of_g, g1) + _vec(powers_of_gamma_g, g1) + _u64(supported_degree)
+
+
+def marlin_committer_key_from_bytes(b: bytes, curve, checked: bool = True) -> dict:
+    c = get_curve(curve)
+    n = _fq_bytes(c)
+    r = _Reader(b)
+    out = dict(powers_of_g=[g1_from_bytes(r.take(n), c, checked=checked) for _ in range(r.u64())])
+    out["powers_of_gamma_g"] = [g1_from_bytes(r.take(n), c, checked=checked) for _ in range(r.u64())]
+    out["supported_degree"] = r.u64()
+    if r.o != len(b):
+        raise SerializationError("InvalidData")
+    return out
+
+
+def marlin_verifier_key_to_bytes(vk: dict, curve) -> bytes:
+    """pc::VerifierKey { g, gamma_g, h, beta_h, supported_degree }"""
+    return (g1_to_bytes(vk["g"], curve) + g1_to_bytes(vk["gamma_g"], curve) + g2_to_bytes(vk["h"], curve) +
+            g2_to_bytes(vk["beta_h"], curve) + _u64(vk["supported_degree"]))
+
+
+def marlin_index_verifier_key_to_bytes(ivk: dict, curve) -> bytes:
+    """IndexVerifierKey { index_info { num_constraints, num_variables, num_non_zeros }, index_comms: Vec<Commitment>,
+    verifier_key }"""
+    return (_u64(ivk["num_constraints"]) + _u64(ivk["num_variables"]) + _u64(ivk["num_non_zeros"]) +
+            _vec(ivk["index_comms"], lambda cm: marlin_commitment_to_bytes(cm, curve)) + marlin_verifier_key_to_bytes(ivk, curve))
+
+
+def marlin_index_verifier_key_from_bytes(b: bytes, curve, checked: bool = True) -> dict:
+    c = get_curve(curve)
+    n = _fq_bytes(c)
+    r = _Reader(b)
+    out = dict(num_constraints=r.u64(), num_variables=r.u64(), num_non_zeros=r.u64())
+    comms = []
+    for _ in range(r.u64()):
+        cm, sh = _read_marlin_commitment(r, c, checked)
+        comms.append((cm, sh[1] if sh else None))
+    out["index_comms"] = comms
+    out["g"] = g1_from_bytes(r.take(n), c, checked=checked)
+    out["gamma_g"] = g1_from_bytes(r.take(n), c, checked=checked)
+    out["h"] = g2_from_bytes(r.take(2 * n), c, checked=checked)
+    out["beta_h"] = g2_from_bytes(r.take(2 * n), c, checked=checked)
+    out["supported_degree"] = r.u64()
+    if r.o != len(b):
+        raise SerializationError("InvalidData")
+    return out
+
+
+def marlin_proof_to_bytes(commitments, evaluations, opening_proofs, curve) -> bytes:
+    """marlin::Proof { commitments: Vec<Vec<Commitment>>, evaluations: Vec<Fr>, opening_proofs: Vec<pc::Proof> } with
+    pc::Proof { w: G1Affine, rand_v: Option<Fr> }.  commitments: the three rounds' lists of (point, shifted or None)."""
+    cm = lambda x: marlin_commitment_to_bytes(x, curve)
+    out = _vec(commitments, lambda rnd: _vec(rnd, cm))
+    out += _vec(evaluations, lambda e: fr_to_bytes(e, curve))
+    out += _vec(opening_proofs, lambda p: g1_to_bytes(p[0], curve) + _option(p[1], lambda v: fr_to_bytes(v, curve)))
+    return out
+
+
+def marlin_proof_from_bytes(b: bytes, curve, checked: bool = True):
+    c = get_curve(curve)
+    n, fr = _fq_bytes(c), _fr_bytes(c)
+    r = _Reader(b)
+    commitments = []
+    for _ in range(r.u64()):
+        rnd = []
+        for _ in range(r.u64()):
+            cm, sh = _read_marlin_commitment(r, c, checked)
+            rnd.append((cm, sh[1] if sh else None))
+        commitments.append(rnd)
+    evaluations = [fr_from_bytes(r.take(fr), c) for _ in range(r.u64())]
+    proofs = []
+    for _ in range(r.u64()):
+        w = g1_from_bytes(r.take(n), c, checked=checked)
+        proofs.append((w, _read_option(r, lambda: fr_from_bytes(r.take(fr), c))))
+    if r.o != len(b):
+        raise SerializationError("InvalidData")
+    return commitments, evaluations, proofs

@@ -141,3 +141,38 @@ def test_rejects_points_outside_the_prime_order_subgroup(curve, group):
         raw = ser.g1_to_bytes(g1[0], curve) + ser.g2_to_bytes(bad, curve) + ser.g1_to_bytes(g1[1], curve)
         with pytest.raises(ser.SerializationError):
             ser.proof_from_bytes(raw, curve)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_marlin_codecs_round_trip(curve):
+    """zkp-marlin wire objects (marlin/src/pc/data_structures.rs:59,100,137,300; data_structures.rs:10,43): CommitterKey,
+    IndexVerifierKey, Commitment (with and without the degree-bound shifted part), Proof — sizes, Option flags, round
+    trips, trailing-garbage and bad-flag rejection."""
+    c = get_curve(curve)
+    n = 32 if curve == "bn254" else 48
+    g1, g2 = _pts(curve, 1, 30, 7), _pts(curve, 2, 2, 8)
+    plain, bounded = (g1[0], None), (g1[1], g1[2])
+    assert len(ser.marlin_commitment_to_bytes(plain, curve)) == n + 1
+    assert len(ser.marlin_commitment_to_bytes(bounded, curve)) == 2 * n + 1
+    for cm in (plain, bounded, (None, None)):
+        assert ser.marlin_commitment_from_bytes(ser.marlin_commitment_to_bytes(cm, curve), curve) == cm
+    raw = ser.marlin_committer_key_to_bytes(g1[:5], g1[5:10], 4, curve)
+    assert len(raw) == 8 + 5 * n + 8 + 5 * n + 8
+    assert ser.marlin_committer_key_from_bytes(raw, curve) == dict(powers_of_g=g1[:5], powers_of_gamma_g=g1[5:10], supported_degree=4)
+    ivk = dict(num_constraints=16, num_variables=16, num_non_zeros=23, index_comms=[(p, None) for p in g1[10:22]],
+               g=g1[22], gamma_g=g1[23], h=g2[0], beta_h=g2[1], supported_degree=63)
+    raw = ser.marlin_index_verifier_key_to_bytes(ivk, curve)
+    assert len(raw) == 24 + 8 + 12 * (n + 1) + 2 * n + 4 * n + 8
+    assert ser.marlin_index_verifier_key_from_bytes(raw, curve) == ivk
+    rounds = [[(g1[0], None), (g1[1], None), (g1[2], None), (g1[3], None)], [(g1[4], None), (g1[5], g1[6]), (g1[7], None)],
+              [(g1[8], g1[9]), (g1[10], None)]]
+    evals = [5, c.r - 1, 0] + list(range(18))
+    opens = [(g1[11], 12345), (g1[12], None)]
+    raw = ser.marlin_proof_to_bytes(rounds, evals, opens, curve)
+    assert ser.marlin_proof_from_bytes(raw, curve) == (rounds, evals, opens)
+    with pytest.raises(ser.SerializationError):
+        ser.marlin_proof_from_bytes(raw + b"\x00", curve)
+    bad = bytearray(ser.marlin_commitment_to_bytes(plain, curve))
+    bad[-1] = 2                                             # Option flag must be 0 or 1
+    with pytest.raises(ser.SerializationError):
+        ser.marlin_commitment_from_bytes(bytes(bad), curve)
