@@ -49,6 +49,7 @@ struct zkp_groth16_pk {
   DevCsr m[3];
   uint64_t hA = 0, hB1 = 0, hB2 = 0, hH = 0, hL = 0;
   bool share_b_sort = false;     // b_g1_query / b_g2_query: same length, window configuration and identity pattern
+  bool share_z_sort = false;     // A, B1, B2 and L (stored index-aligned with z) all reuse ONE bucket sort of S = z ++ tail
   // Base-sharded key (BASELINE configs[4]): this rank holds elements [q_lo, q_lo + q_n) of every
   // (extended) query; world == 0 means the whole key.  Index order: A, B1, B2, H, L.
   int shard_rank = 0, shard_world = 0;
@@ -160,12 +161,19 @@ static void shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* cnt)
   *cnt = base + (r < rem ? 1 : 0);
 }
 // only elements [lo, lo + cnt) of the extended query are uploaded (the whole of it for an unsharded key)
+// `lead` identity points are put in front of the query (the L query is stored index-aligned with z: lead = num_inputs);
+// flags_out (optional) receives the identity flags of the uploaded slice
 static uint64_t upload_ext(zkp_ctx* ctx, int curve, int group, const uint64_t* q, const uint8_t* inf, size_t n,
-                           size_t limbs_per_point, const uint64_t* const tail[4], size_t lo, size_t cnt) {
+                           size_t limbs_per_point, const uint64_t* const tail[4], size_t lo, size_t cnt, size_t lead = 0,
+                           std::vector<uint8_t>* flags_out = nullptr) {
   std::vector<uint64_t> xy(std::max<size_t>(cnt, 1) * limbs_per_point, 0);
   std::vector<uint8_t> fl(std::max<size_t>(cnt, 1), 0);
   for (size_t j = 0; j < cnt; j++) {
-    const size_t i = lo + j;
+    if (lo + j < lead) {
+      fl[j] = 1;
+      continue;
+    }
+    const size_t i = lo + j - lead;
     if (i < n) {
       memcpy(xy.data() + j * limbs_per_point, q + i * limbs_per_point, limbs_per_point * 8);
       fl[j] = inf ? inf[i] : 0;
@@ -175,6 +183,7 @@ static uint64_t upload_ext(zkp_ctx* ctx, int curve, int group, const uint64_t* q
       fl[j] = 1;
     }
   }
+  if (flags_out) *flags_out = fl;
   return bases_upload(ctx, curve, group, xy.data(), fl.data(), cnt);
 }
 
@@ -219,10 +228,14 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
     pk->q_lo[1] = pk->q_lo[2] = pk->q_lo[0];
     pk->q_n[1] = pk->q_n[2] = pk->q_n[0];
     shard_bounds(h_used, rank, world, &pk->q_lo[3], &pk->q_n[3]);
-    shard_bounds((size_t)d->num_aux + 4, rank, world, &pk->q_lo[4], &pk->q_n[4]);
-    pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA, pk->q_lo[0], pk->q_n[0]);
-    pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1, pk->q_lo[1], pk->q_n[1]);
-    pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2, pk->q_lo[2], pk->q_n[2]);
+    // L is stored index-aligned with z (num_inputs leading identity points): its MSM then runs over the same scalar
+    // slice as A / B1 / B2 and can reuse their bucket sort
+    pk->q_lo[4] = pk->q_lo[0];
+    pk->q_n[4] = pk->q_n[0];
+    std::vector<uint8_t> fA, fB1, fB2, fL;
+    pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA, pk->q_lo[0], pk->q_n[0], 0, &fA);
+    pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1, pk->q_lo[1], pk->q_n[1], 0, &fB1);
+    pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2, pk->q_lo[2], pk->q_n[2], 0, &fB2);
     {
       // B1 reuses B2's bucket sort + task schedule (same scalars, window configuration and identity pattern): -0.55 ms of
       // memory-bound sort kernels per proof.  With 4 hardware queues this LOST 2 % (84.7 -> 83.0 proofs/s: the wait on
@@ -234,7 +247,21 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
     }
     pk->hH = bases_upload(ctx, d->curve, 1, d->h_query ? d->h_query + pk->q_lo[3] * 2 * fq : nullptr,
                           d->h_inf ? d->h_inf + pk->q_lo[3] : nullptr, world > 0 ? pk->q_n[3] : (size_t)d->h_len);
-    pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL, pk->q_lo[4], pk->q_n[4]);
+    pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL, pk->q_lo[4], pk->q_n[4],
+                        d->num_inputs, &fL);
+    {
+      // ONE bucket sort of S = z ++ [1, r, s, -rs] per proof serves A, B1, B2 and L (same scalars, same length, same
+      // windows): the scan drops a point only if it is the identity in all four queries; each MSM skips its own identities
+      // when it gathers them.  Saves three of the five digit scans + level-2 sorts + task schedules of a proof.
+      static const bool on = !(getenv("ZKP_SHARE_Z_SORT") && atoi(getenv("ZKP_SHARE_Z_SORT")) == 0);
+      pk->share_z_sort = on && bases_same_shape(ctx, pk->hA, pk->hB2) && bases_same_shape(ctx, pk->hB1, pk->hB2) &&
+                         bases_same_shape(ctx, pk->hL, pk->hB2) && pk->q_n[0] > 0;
+      if (pk->share_z_sort) {
+        std::vector<uint8_t> all(pk->q_n[0]);
+        for (size_t j = 0; j < all.size(); j++) all[j] = fA[j] & fB1[j] & fB2[j] & fL[j];
+        bases_set_sort_flags(ctx, pk->hB2, all.data(), all.size());
+      }
+    }
   }
   uint32_t* consts = pk->consts.as<uint32_t>(64);
   if (d->curve == ZKP_BN254) hipLaunchKernelGGL(qap_consts_kernel<Bn254Fr>, dim3(1), dim3(64), 0, ctx->cur->stream, consts, lg);
@@ -392,10 +419,11 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H | ws3: L, then part 1 after A, B1
     // (4 lanes x 4 streams = 16 streams = one hardware queue each under GPU_MAX_HW_QUEUES=16)
     run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2);                          // prover.rs:182-184
-    run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1);                           // prover.rs:164-167
-    run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 1, pk->share_b_sort ? 2 : -1);   // prover.rs:170-177 (B2's bucket sort reused)
+    const int zs = pk->share_z_sort ? 2 : -1;                                      // B2 (ws 2) owns the shared sort of S
+    run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1, zs);                       // prover.rs:164-167
+    run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 1, (pk->share_b_sort || pk->share_z_sort) ? 2 : -1);   // prover.rs:170-177
     static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
-    if (l_own) run(4, pk->hL, Sd + ((size_t)pk->num_inputs + pk->q_lo[4]) * 4, pk->q_n[4], 3);
+    if (l_own) run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 3, zs);            // prover.rs:189-190 (L index-aligned with z)
     ZKP_HIP(hipEventRecord(ctx->cur->ev_b1, ctx->cur->ws[1].stream));
     // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~4 ms single-wave chain: start them as soon as
     // A and B1 exist so they hide under the remaining MSMs
@@ -415,7 +443,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   run(3, pk->hH, reinterpret_cast<const uint64_t*>(h) + 4 * pk->q_lo[3], pk->q_n[3], 0);  // :186-187 (min(len) truncation in q_n)
   {
     static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
-    if (!(fan && l_own)) run(4, pk->hL, Sd + ((size_t)pk->num_inputs + pk->q_lo[4]) * 4, pk->q_n[4], 0);             // :189-190
+    if (!(fan && l_own)) run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 0);                                       // :189-190
   }
   if (fan) {
     for (int w = 1; w < zkp_ctx::N_WS; w++) {

@@ -37,6 +37,9 @@ double bench_mulmod(zkp_ctx* ctx, int curve, int field, bool unsaturated);
 // sort_src >= 0: reuse the bucket sort + task schedule that workspace `sort_src` of the same lane computed for the SAME
 // scalars, length, window configuration and identity flags (Groth16: b_g1_query / b_g2_query) instead of redoing it
 bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2);
+// flags (n bytes, host) the digit scan of `handle` uses instead of the entry's own identity flags when it sorts for a group
+// of MSMs over the same scalars (a point is dropped only if it is the identity in every member)
+void bases_set_sort_flags(zkp_ctx* ctx, uint64_t handle, const uint8_t* flags_host, size_t n);
 void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* offsets, const uint64_t* const* scalars_dev,
                    const size_t* ns, bool montgomery, uint64_t* out_xyz_host);
 void msm_run_multi(zkp_ctx* ctx, size_t count, const uint64_t* handles, const size_t* offsets,

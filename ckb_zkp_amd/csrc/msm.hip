@@ -62,9 +62,14 @@ struct BasesEntry {
   // entry (bucket w * 2^(c-1) + |d| - 1, point i) into W SEPARATE bucket sets, and the reduction weights window w by 2^(c*w).
   bool var = false;
   bool owns = true;            // false: table / inf live in context scratch
+  // Optional flags used ONLY by the digit scan when this entry owns a bucket sort that other MSMs reuse (Groth16: A, B1, B2
+  // and L share one sort of z): a point is skipped by the scan only if it is the identity in EVERY sharing query; each
+  // MSM's own identities are (0, 0) in its table and are skipped by its accumulate kernel.
+  uint8_t* sort_inf = nullptr;
   ~BasesEntry() {
     if (owns && table) (void)hipFree(table);
     if (owns && inf) (void)hipFree(inf);
+    if (sort_inf) (void)hipFree(sort_inf);
   }
 };
 
@@ -131,6 +136,16 @@ uint64_t bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t handle) {
   uint64_t h = dst->next_handle++;
   dst->bases[h] = e;
   return h;
+}
+void bases_set_sort_flags(zkp_ctx* ctx, uint64_t handle, const uint8_t* flags_host, size_t n) {
+  auto e = get_bases(ctx, handle);
+  ZKP_REQUIRE(n == e->n, ZKP_ERR_BAD_ARG);
+  if (e->sort_inf) (void)hipFree(e->sort_inf);
+  e->sort_inf = nullptr;
+  if (!flags_host || n == 0) return;
+  if (hipMalloc(&e->sort_inf, n) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+  ZKP_HIP(hipMemcpyAsync(e->sort_inf, flags_host, n, hipMemcpyHostToDevice, ctx->cur->stream));
+  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
 }
 bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2) {
   auto a = get_bases(ctx, h1), b = get_bases(ctx, h2);
@@ -562,22 +577,23 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     uint32_t* offs = hist + hist_n;
     uint32_t* start = sw.offsets.as<uint32_t>(2 * (size_t)nb);
     uint32_t* end = start + nb;
+    const uint8_t* scan_inf = be->sort_inf ? be->sort_inf : be->inf;     // see BasesEntry::sort_inf
     if (reuse) ZKP_HIP(hipStreamWaitEvent(st, sw.sorted, 0));
     else ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
     const bool timed_scan = ms_scan && ctx->profiling && !reuse;      // K5 "scalar scan": histogram pass + count scan + scatter pass
     if (timed_scan) ZKP_HIP(hipEventRecord(ctx->ev2, st));
     if (reuse) {
     } else if (be->curve == ZKP_BN254) {
-      hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
+      hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
                          nb_w, LB, nbins1, hist, nblocks, tile, var);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-      hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
+      hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
                          be->n, c, W, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
     } else {
-      hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont, c, W,
+      hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
                          nb_w, LB, nbins1, hist, nblocks, tile, var);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-      hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, be->inf, mont,
+      hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
                          be->n, c, W, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
     }
     if (timed_scan) {
