@@ -1,6 +1,6 @@
 // Measurement helpers behind bench.py's `valu_roof` entry ("mulmod/s vs a measured v_mad_u64_u32
 // microbenchmark peak"): the sustained rate of the library's own Montgomery multipliers — the saturated product-scanning
-// multiplier of field.cuh and the unsaturated-limb multiplier of unsat.cuh — with two independent dependency chains per
+// multiplier of field.cuh and the unsaturated-limb multiplier of unsat.cuh — with four independent dependency chains per
 // lane and every CU saturated.  This is the roof the bucket-accumulation and NTT kernels are bound by (integer VALU),
 // measured in the same process as the benchmark.  Not on any product path.
 #include "field.cuh"
@@ -13,29 +13,35 @@ template <class P, int UNSAT>
 __global__ __launch_bounds__(256) void mulmod_rate_kernel(uint32_t* __restrict__ out, int iters) {
   using F = Fp<P>;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  F a = F::one(), b = F::one();
-  a.v[0] ^= t * 2654435761u;                    // distinct, lane-dependent operands (values need not be reduced for a rate test)
-  b.v[1] ^= t * 40503u + 1;
-  a = F::reduce_once(a);
-  b = F::reduce_once(b);
+  constexpr int CH = 4;                            // independent dependency chains per lane (the EC formulas offer 2-4)
+  F a[CH];
+#pragma unroll
+  for (int k = 0; k < CH; k++) {
+    a[k] = F::one();
+    a[k].v[k & 1] ^= t * (2654435761u + 40503u * k) + k;   // distinct, lane-dependent operands
+    a[k] = F::reduce_once(a[k]);
+  }
   if constexpr (UNSAT != 0) {
     using U = Fu<P>;
-    const U ua = U::from_sat_reduced(a), ub = U::from_sat_reduced(b);
-    U c = ua, d = ub;
+    U ua[CH], c[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) c[k] = ua[k] = U::from_sat_reduced(a[k]);
     for (int i = 0; i < iters; i++) {
-      c = U::mul(c, ua);
-      d = U::mul(d, ub);
+#pragma unroll
+      for (int k = 0; k < CH; k++) c[k] = U::mul(c[k], ua[k]);
     }
-    U s = U::add(c, d);
+    U s = U::add(U::add(c[0], c[1]), U::add(c[2], c[3]));
 #pragma unroll
     for (int i = 0; i < P::N; i++) out[(size_t)t * P::N + i] = s.v[i];
   } else {
-    F c = a, d = b;
+    F c[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) c[k] = a[k];
     for (int i = 0; i < iters; i++) {
-      c = c * a;
-      d = d * b;
+#pragma unroll
+      for (int k = 0; k < CH; k++) c[k] = c[k] * a[k];
     }
-    (c + d).store(out + (size_t)t * P::N);
+    ((c[0] + c[1]) + (c[2] + c[3])).store(out + (size_t)t * P::N);
   }
 }
 
@@ -46,7 +52,7 @@ double bench_mulmod(zkp_ctx* ctx, int curve, int field, bool unsaturated) {
   int cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-  const int blocks = cus * 8, threads = 256, iters = 1500;
+  const int blocks = cus * 8, threads = 256, iters = 800;
   uint32_t* out = ctx->msm_misc.as<uint32_t>((size_t)blocks * threads * 12);
   auto launch = [&] {
     if (curve == ZKP_BN254 && field == 1) {
@@ -71,7 +77,7 @@ double bench_mulmod(zkp_ctx* ctx, int curve, int field, bool unsaturated) {
   ZKP_HIP(hipGetLastError());
   float ms = 0.f;
   ZKP_HIP(hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3));
-  return (double)blocks * threads * iters * 2.0 / (ms * 1e-3) / 1e9;
+  return (double)blocks * threads * iters * 4.0 / (ms * 1e-3) / 1e9;
 }
 
 }  // namespace zkp

@@ -49,7 +49,7 @@ struct zkp_groth16_pk {
   DevCsr m[3];
   uint64_t hA = 0, hB1 = 0, hB2 = 0, hH = 0, hL = 0;
   bool share_b_sort = false;     // b_g1_query / b_g2_query: same length, window configuration and identity pattern
-  bool share_z_sort = false;     // A, B1, B2 and L (stored index-aligned with z) all reuse ONE bucket sort of S = z ++ tail
+  bool share_al_sort = false;    // L (stored index-aligned with z) reuses A's bucket sort: same scalars, same identity pattern
   // Base-sharded key (BASELINE configs[4]): this rank holds elements [q_lo, q_lo + q_n) of every
   // (extended) query; world == 0 means the whole key.  Index order: A, B1, B2, H, L.
   int shard_rank = 0, shard_world = 0;
@@ -250,17 +250,17 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
     pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL, pk->q_lo[4], pk->q_n[4],
                         d->num_inputs, &fL);
     {
-      // ONE bucket sort of S = z ++ [1, r, s, -rs] per proof serves A, B1, B2 and L (same scalars, same length, same
-      // windows): the scan drops a point only if it is the identity in all four queries; each MSM skips its own identities
-      // when it gathers them.  Saves three of the five digit scans + level-2 sorts + task schedules of a proof.
-      static const bool on = !(getenv("ZKP_SHARE_Z_SORT") && atoi(getenv("ZKP_SHARE_Z_SORT")) == 0);
-      pk->share_z_sort = on && bases_same_shape(ctx, pk->hA, pk->hB2) && bases_same_shape(ctx, pk->hB1, pk->hB2) &&
-                         bases_same_shape(ctx, pk->hL, pk->hB2) && pk->q_n[0] > 0;
-      if (pk->share_z_sort) {
-        std::vector<uint8_t> all(pk->q_n[0]);
-        for (size_t j = 0; j < all.size(); j++) all[j] = fA[j] & fB1[j] & fB2[j] & fL[j];
-        bases_set_sort_flags(ctx, pk->hB2, all.data(), all.size());
-      }
+      // L reuses A's bucket sort + task schedule when both queries have the same identity pattern (L is stored
+      // index-aligned with z, so both MSMs run over the same scalar slice; L's num_inputs leading identity points are
+      // skipped by its accumulate kernel when it gathers them): one digit scan + level-2 sort + schedule less per proof.
+      // Queries with DIFFERENT identity patterns must not share a sort: a lane whose point is the identity idles while
+      // its wave-mates add (measured: B2 sharing a full-pattern sort ran 4.47 instead of 1.91 ms — half of the MiMC
+      // chain's B-query is identities — and the whole proof 11.8 instead of 9.4 ms).  ZKP_SHARE_AL_SORT=0 disables it.
+      static const bool on = !(getenv("ZKP_SHARE_AL_SORT") && atoi(getenv("ZKP_SHARE_AL_SORT")) == 0);
+      bool same = fA.size() == fL.size();
+      for (size_t j = 0; same && j < fA.size(); j++)
+        if (pk->q_lo[0] + j >= d->num_inputs && fA[j] != fL[j]) same = false;
+      pk->share_al_sort = on && same && bases_same_shape(ctx, pk->hL, pk->hA) && pk->q_n[0] > 0;
     }
   }
   uint32_t* consts = pk->consts.as<uint32_t>(64);
@@ -419,11 +419,10 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H | ws3: L, then part 1 after A, B1
     // (4 lanes x 4 streams = 16 streams = one hardware queue each under GPU_MAX_HW_QUEUES=16)
     run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2);                          // prover.rs:182-184
-    const int zs = pk->share_z_sort ? 2 : -1;                                      // B2 (ws 2) owns the shared sort of S
-    run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1, zs);                       // prover.rs:164-167
-    run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 1, (pk->share_b_sort || pk->share_z_sort) ? 2 : -1);   // prover.rs:170-177
+    run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1);                           // prover.rs:164-167
+    run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 1, pk->share_b_sort ? 2 : -1);   // prover.rs:170-177 (B2's bucket sort reused)
     static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
-    if (l_own) run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 3, zs);            // prover.rs:189-190 (L index-aligned with z)
+    if (l_own) run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 3, pk->share_al_sort ? 1 : -1);   // prover.rs:189-190 (A's sort reused)
     ZKP_HIP(hipEventRecord(ctx->cur->ev_b1, ctx->cur->ws[1].stream));
     // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~4 ms single-wave chain: start them as soon as
     // A and B1 exist so they hide under the remaining MSMs

@@ -642,7 +642,15 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       ZKP_HIP(hipEventElapsedTime(ms_accumulate, ctx->ev2, ctx->ev3));
     }
     vt->combine(st, long_list, tmeta + TM_NLONG, toff, task_partial, buckets);
-    if (n_entries) *n_entries = E;
+    if (n_entries) {
+      *n_entries = E;                                   // nominal: scalars x windows
+      if (ctx->profiling) {                             // exact: what the scan emitted (identity bases / zero digits dropped)
+        uint32_t emitted = 0;
+        ZKP_HIP(hipMemcpyAsync(&emitted, offs + hist_n - 1, 4, hipMemcpyDeviceToHost, st));
+        ZKP_HIP(hipStreamSynchronize(st));
+        *n_entries = emitted;
+      }
+    }
     if (var) {
       // K8, variable-base: the pairwise pyramid runs over all W bucket sets at once (pairs never straddle windows), c - 1
       // levels deep; two descriptor-driven segmented sums give R_t; 256 lanes weigh them by 2^t (<= 255 doublings each)

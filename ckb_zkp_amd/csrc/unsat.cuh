@@ -188,6 +188,39 @@ struct Fu {
     r.v[L - 1] = (uint32_t)acc;
     return r;
   }
+  // a*b + c*d with ONE Montgomery reduction (lazy reduction of a sum of two products): 2 L^2 + L^2 instead of 4 L^2 partial
+  // products.  A column holds <= 2L products < 2^(2B) plus <= L reduction products: 27 * 2^58 < 2^63 for L = 9, B = 29
+  // (BLS12-381: 42 * 2^56 < 2^62).  Value: (a*b + c*d) / R' + p < 2p when KA*KB + KC*KD <= MULCAP.
+  ZKP_DEV static Fu mul_add(const Fu& a, const Fu& b, const Fu& c, const Fu& d) {
+    uint32_t m[L];
+    Fu r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; k++) {
+#pragma unroll
+      for (int i = 0; i < L; i++) {
+        int j = k - i;
+        if (j >= 0 && j < L) {
+          acc += (uint64_t)a.v[i] * b.v[j];
+          acc += (uint64_t)c.v[i] * d.v[j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < L; i++) {
+        int j = k - i;
+        if (j >= 0 && j < L && i < k) acc += (uint64_t)m[i] * mp_limb(1, j);
+      }
+      if (k < L) {
+        m[k] = ((uint32_t)acc * ninv()) & MASK;
+        acc += (uint64_t)m[k] * mp_limb(1, 0);
+      } else {
+        r.v[k - L] = (uint32_t)acc & MASK;
+      }
+      acc >>= B;
+    }
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
+  }
   // (a dedicated squaring — cross terms once against a doubled operand, 45 instead of 81 products — measured no
   //  difference in the accumulate kernel and was dropped)
   ZKP_DEV Fu sqr() const { return mul(*this, *this); }
@@ -276,6 +309,21 @@ ZKP_DEV UB<P, 2> ub_mul(const UB<P, KA>& a, const UB<P, KB>& b) {
   static_assert((long)KA * KB <= UBLimits<P>::MULCAP, "product of unreduced operands exceeds the Montgomery slack");
   return {Fu<P>::mul(a.f, b.f)};
 }
+// a*b + c*d, one reduction
+template <class P, int KA, int KB, int KC, int KD>
+ZKP_DEV UB<P, 2> ub_mul_add(const UB<P, KA>& a, const UB<P, KB>& b, const UB<P, KC>& c, const UB<P, KD>& d) {
+  static_assert((long)KA * KB + (long)KC * KD <= UBLimits<P>::MULCAP, "sum of products exceeds the Montgomery slack");
+  return {Fu<P>::mul_add(a.f, b.f, c.f, d.f)};
+}
+// K*p - a  (a < K*p), normalised limbs: the negation that turns a difference of products into a sum
+template <int K, class P, int KA>
+ZKP_DEV UB<P, K> ub_neg(const UB<P, KA>& a) {
+  static_assert(KA <= K && K <= Fu<P>::KMAX, "no table entry for this multiple of p");
+  Fu<P> kp;
+#pragma unroll
+  for (int i = 0; i < Fu<P>::L; i++) kp.v[i] = Fu<P>::mp_limb(0, i);    // zero
+  return {Fu<P>::template sub<K>(kp, a.f)};
+}
 template <class P, int KA, int KB>
 ZKP_DEV UB<P, KA + KB> ub_sub(const UB<P, KA>& a, const UB<P, KB>& b) {
   static_assert(KB <= Fu<P>::KMAX, "no table entry for this multiple of p");
@@ -330,7 +378,12 @@ ZKP_DEV bool xyzz_madd_u(XYZZu<P>& acc, const Fu<P>& ux_, const Fu<P>& uy_) {
   const auto q = ub_mul(acc.x, pp);
   const auto t = ub_sub(ub_mul(rd, rd), ppp);              // (0, 4p)
   const UB<P, 8> x3 = ub_sub(t, ub_dbl(q));                // (0, 8p): the type of acc.x
+#ifdef ZKP_UNSAT_NO_LAZY_Y3
   const UB<P, 4> y3 = ub_sub(ub_mul(rd, ub_sub(q, x3)), ub_mul(acc.y, ppp));   // (0, 4p): the type of acc.y
+#else
+  // y3 = R (Q - X3) - Y1 PPP as ONE lazily reduced sum of two products: R (Q - X3) + Y1 (2p - PPP); bounds 6*10 + 4*2 = 68
+  const UB<P, 4> y3 = {ub_mul_add(rd, ub_sub(q, x3), acc.y, ub_neg<2>(ppp)).f};   // < 2p, stored as "< 4p"
+#endif
   acc.zz = ub_mul(acc.zz, pp);
   acc.zzz = ub_mul(acc.zzz, ppp);
   acc.x = x3;

@@ -295,7 +295,7 @@ typedef struct {
   uint64_t msm_scan_launches; /* MSMs that ran their own scan (B1 reuses B2's) */
   uint64_t msm_scan_bytes; /* algorithmic bytes of those scans: 2 x 32 B per scalar read + 8 B per entry written */
   float ms_msm_acc[5];     /* accumulate kernel per MSM (A, B1, B2, H, L) */
-  uint64_t msm_entries[5]; /* entries (= mixed additions) per MSM */
+  uint64_t msm_entries[5]; /* entries (= mixed additions: identity bases and zero digits are dropped by the scan) per MSM */
 } zkp_groth16_timing;
 int32_t zkp_groth16_last_timing(zkp_ctx* ctx, zkp_groth16_timing* out);
 int32_t zkp_set_profiling(zkp_ctx* ctx, int32_t enable); /* per-phase HIP events (adds sync points) */
