@@ -45,6 +45,27 @@ class Groth16Timing(C.Structure):
                 ("ms_msm_acc", C.c_float * 5), ("msm_entries", C.c_uint64 * 5)]
 
 
+class MarlinIndexDesc(C.Structure):
+    _fields_ = [("curve", C.c_int), ("num_inputs", C.c_uint32), ("n", C.c_uint32), ("pad_aux", C.c_uint32),
+                ("a", Csr), ("b", Csr), ("c", Csr)]
+
+
+class MarlinRand(C.Structure):
+    _fields_ = [("w", vp), ("z_a", vp), ("z_b", vp), ("mask", vp), ("mask_on_device", C.c_int32),
+                ("blind_w", vp), ("blind_z_a", vp), ("blind_z_b", vp), ("blind_g_1", vp), ("blind_shifted_g_1", vp)]
+
+
+MARLIN_NUM_EVALS = 21
+
+
+class MarlinProof(C.Structure):
+    _fields_ = [("comm", C.c_uint64 * (9 * 12)), ("comm_inf", C.c_uint8 * 9),
+                ("shifted", C.c_uint64 * (2 * 12)), ("shifted_inf", C.c_uint8 * 2),
+                ("evaluations", C.c_uint64 * (MARLIN_NUM_EVALS * 4)), ("num_opening_proofs", C.c_uint32),
+                ("opening_w", C.c_uint64 * (2 * 12)), ("opening_w_inf", C.c_uint8 * 2), ("opening_has_rand", C.c_uint8 * 2),
+                ("opening_rand_v", C.c_uint64 * (2 * 4)), ("challenges", C.c_uint64 * (7 * 4))]
+
+
 # name -> (restype, argtypes).  Must list every symbol declared in include/zkp_accel.h
 # (tests/test_abi.py parses the header and checks both directions).
 SIGNATURES = {
@@ -110,6 +131,12 @@ SIGNATURES = {
     "zkp_groth16_assemble": (C.c_int32, [vp, C.c_int, vp, vp, vp, vp, vp]),
     "zkp_groth16_last_timing": (C.c_int32, [vp, C.POINTER(Groth16Timing)]),
     "zkp_set_profiling": (C.c_int32, [vp, C.c_int32]),
+    "zkp_marlin_index_upload": (C.c_int32, [vp, C.POINTER(MarlinIndexDesc), C.POINTER(vp)]),
+    "zkp_marlin_index_free": (C.c_int32, [vp, vp]),
+    "zkp_marlin_index_info": (C.c_int32, [vp, u64p]),
+    "zkp_marlin_index_commit": (C.c_int32, [vp, vp, C.c_uint64, vp, vp]),
+    "zkp_marlin_prove": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, vp, C.c_size_t, vp, vp, C.c_size_t,
+                                     C.POINTER(MarlinRand), vp, C.POINTER(MarlinProof)]),
     "zkp_fs_rng_new": (C.c_int32, [vp, C.c_size_t, C.POINTER(vp)]),
     "zkp_fs_rng_free": (C.c_int32, [vp]),
     "zkp_fs_rng_absorb": (C.c_int32, [vp, vp, C.c_size_t]),

@@ -24,7 +24,8 @@ UNITS = [("ntt.hip", "ntt.o", ["-DZKP_INLINE_MUL"]),
          ("groth16.hip", "groth16.o", ["-DZKP_INLINE_MUL"]),
          ("capi.hip", "capi.o", []),
          ("bench_kern.hip", "bench_kern.o", ["-DZKP_INLINE_MUL"]),
-         ("fs_rng.cpp", "fs_rng.o", [])]
+         ("fs_rng.cpp", "fs_rng.o", []),
+         ("marlin.hip", "marlin.o", [])]
 for _c, _g in CONFIGS:
     _d = [f"-DZKP_CFG_CURVE={_c}", f"-DZKP_CFG_GROUP={_g}"]
     UNITS.append(("msm_group.hip", f"msm_group_c{_c}{_g}.o", _d + (["-DZKP_INLINE_MUL"] if (_c, _g) in ((0, 1), (0, 2), (1, 1)) else [])))

@@ -438,6 +438,35 @@ int32_t zkp_groth16_assemble(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* su
   if (!sums || !r || !s || !proof || !inf) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { groth16_assemble(ctx, curve, sums, r, s, proof, inf); });
 }
+int32_t zkp_marlin_index_upload(zkp_ctx* ctx, const zkp_marlin_index_desc* desc, zkp_marlin_index** out) {
+  if (!desc || !out) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { *out = marlin_index_upload(ctx, desc); });
+}
+int32_t zkp_marlin_index_free(zkp_ctx* ctx, zkp_marlin_index* index) {
+  if (!index) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { marlin_index_free(ctx, index); });
+}
+int32_t zkp_marlin_index_info(const zkp_marlin_index* index, uint64_t info[6]) {
+  if (!index || !info) return ZKP_ERR_BAD_ARG;
+  marlin_index_info(index, info);
+  return ZKP_OK;
+}
+int32_t zkp_marlin_index_commit(zkp_ctx* ctx, zkp_marlin_index* index, uint64_t powers_of_g, uint64_t* comms_xy,
+                                uint8_t* inf) {
+  if (!index || !comms_xy || !inf) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { marlin_index_commit(ctx, index, powers_of_g, comms_xy, inf); });
+}
+int32_t zkp_marlin_prove(zkp_ctx* ctx, zkp_marlin_index* index, uint64_t powers_of_g, uint64_t powers_of_gamma_g,
+                         const uint8_t* ivk_bytes, size_t ivk_len, const uint64_t* x, const uint64_t* w, size_t n_w,
+                         const zkp_marlin_rand* rnd, const uint64_t* fixed_challenges, zkp_marlin_proof* out) {
+  if (!index || !x || (n_w && !w) || !rnd || !out || (!fixed_challenges && !ivk_bytes)) return ZKP_ERR_BAD_ARG;
+  if (!rnd->w || !rnd->z_a || !rnd->z_b || !rnd->mask || !rnd->blind_w || !rnd->blind_z_a || !rnd->blind_z_b ||
+      !rnd->blind_g_1 || !rnd->blind_shifted_g_1)
+    return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    marlin_prove(ctx, index, powers_of_g, powers_of_gamma_g, ivk_bytes, ivk_len, x, w, n_w, rnd, fixed_challenges, out);
+  });
+}
 int32_t zkp_bench_mulmod(zkp_ctx* ctx, zkp_curve_t curve, int32_t field, int32_t unsaturated, double* out) {
   if (!out || (curve != ZKP_BN254 && curve != ZKP_BLS12_381) || field < 0 || field > 1) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { *out = bench_mulmod(ctx, curve, field, unsaturated != 0); });

@@ -71,4 +71,13 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
 void groth16_assemble(zkp_ctx* ctx, int curve, const uint64_t* sums_xyz, const uint64_t* r, const uint64_t* s,
                       uint64_t* proof_out, uint8_t* inf_out);
 
+// marlin.hip
+zkp_marlin_index* marlin_index_upload(zkp_ctx* ctx, const zkp_marlin_index_desc* d);
+void marlin_index_free(zkp_ctx* ctx, zkp_marlin_index* ix);
+void marlin_index_commit(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_t* comms_xy, uint8_t* inf);
+void marlin_index_info(const zkp_marlin_index* ix, uint64_t info[6]);
+void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_t powers_gamma_g, const uint8_t* ivk_bytes,
+                  size_t ivk_len, const uint64_t* x_mont, const uint64_t* w_mont, size_t n_w, const zkp_marlin_rand* rnd,
+                  const uint64_t* fixed_challenges, zkp_marlin_proof* out);
+
 }  // namespace zkp

@@ -507,6 +507,11 @@ zkp_marlin_index* marlin_index_upload(zkp_ctx* ctx, const zkp_marlin_index_desc*
   return ix.release();
 }
 
+void marlin_index_info(const zkp_marlin_index* ix, uint64_t info[6]) {
+  const uint64_t v[6] = {ix->xs, ix->hs, ix->ks, ix->bs, ix->max_degree, ix->nnz};
+  memcpy(info, v, sizeof v);
+}
+
 void marlin_index_free(zkp_ctx* ctx, zkp_marlin_index* ix) {
   ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   delete ix;
@@ -515,12 +520,12 @@ void marlin_index_free(zkp_ctx* ctx, zkp_marlin_index* ix) {
 // -> index_commitments[12] (affine Montgomery + identity flags), Index::iter order (lib.rs:77-83)
 void marlin_index_commit(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_t* comms_xy, uint8_t* inf) {
   const MsmVtbl* v1 = msm_vtbl(ix->curve, 1);
-  const size_t aw64 = (size_t)v1->fN, jw64 = 3 * (size_t)v1->fN / 2;
+  const size_t jw64 = 3 * (size_t)v1->fN / 2;
   for (int m = 0; m < 3; m++)
     for (int q = 0; q < 4; q++) {
       std::vector<uint64_t> jac(jw64);
       msm_run(ctx, powers_g, 0, ix->polys[m][q].p, ix->polys[m][q].n, true, jac.data());
-      point_into_affine(ctx, ix->curve, 1, jac.data(), comms_xy + (size_t)(4 * m + q) * aw64, inf + 4 * m + q);
+      point_into_affine(ctx, ix->curve, 1, jac.data(), comms_xy + (size_t)(4 * m + q) * 12, inf + 4 * m + q);
     }
 }
 
@@ -634,7 +639,8 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   if (ix->pad_aux) {
     DVec ones = be.zeros(ix->pad_aux);
     DVec tgt = z.view(ni + n_w, ix->n);
-    be.op(ZKP_VEC_ADDC, ones, nullptr, tgt, ix->pad_aux, [&] { static thread_local FrE o; o = F.one_(); return &o; }());
+    const FrE o = F.one_();
+    be.op(ZKP_VEC_ADDC, ones, nullptr, tgt, ix->pad_aux, &o);
   }
   DVec z_a_ev = be.spmv(ix->csr[0].rp, ix->csr[0].col, ix->csr[0].cf, z, ix->n);
   DVec z_b_ev = be.spmv(ix->csr[1].rp, ix->csr[1].col, ix->csr[1].cf, z, ix->n);

@@ -610,3 +610,107 @@ def create_proof(ctx: Context, didx: DeviceIndex, ck: kzg10.CommitterKey, circui
                     challenges=dict(alpha=alpha, eta_a=ea, eta_b=eb, eta_c=ec, beta=beta, gamma=gamma, xi=xi))
     finally:
         be.release_all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same prover behind the C ABI (csrc/marlin.hip): zkp_marlin_index_upload / zkp_marlin_prove.  The Python
+# orchestration above is the host mirror the C++ was ported from; `NativeIndex` / `prove_native` are what a Rust caller gets.
+class NativeIndex:
+    """zkp_marlin_index: the arithmetization resident in HBM, built by the library from the three square CSR matrices
+    (the index-manipulation half of AHP::index — make_matrices_square, balance_matrices, column sort — is `prepare_matrices`)."""
+
+    def __init__(self, ctx: Context, inst):
+        self.ctx, self.curve = ctx, get_curve(inst.curve)
+        n, pad_aux, mats = prepare_matrices(inst)
+        d = _lib.MarlinIndexDesc()
+        d.curve, d.num_inputs, d.n, d.pad_aux = self.curve.cid, inst.num_inputs, n, pad_aux
+        keep = []
+
+        def P(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        for name, (ptr, col, cf, _rows) in zip("abc", mats):
+            m = getattr(d, name)
+            m.row_ptr, m.col = P(ptr, np.uint32), P(col if len(col) else np.zeros(1), np.uint32)
+            m.coeff = P(cf if len(cf) else np.zeros((1, 4)), np.uint64)
+        h = C.c_void_p()
+        _lib.check(ctx.lib.zkp_marlin_index_upload(ctx.h, C.byref(d), C.byref(h)), "zkp_marlin_index_upload")
+        self.h = h
+        info = (C.c_uint64 * 6)()
+        _lib.check(ctx.lib.zkp_marlin_index_info(self.h, info), "zkp_marlin_index_info")
+        self.xs, self.hs, self.ks, self.bs, self.max_degree, self.num_non_zeros = (int(v) for v in info)
+        self.nrows, self.pad_aux, self.num_inputs = n, pad_aux, inst.num_inputs
+
+    def commit_index(self, ck: kzg10.CommitterKey) -> dict:
+        xy = np.zeros((12, 12), dtype=np.uint64)
+        inf = np.zeros(12, dtype=np.uint8)
+        _lib.check(self.ctx.lib.zkp_marlin_index_commit(self.ctx.h, self.h, ck.powers_of_g.handle, api._ptr(xy), api._ptr(inf)),
+                   "zkp_marlin_index_commit")
+        w = 2 * self.curve.fq_limbs
+        pts = codec.g1_from_mont(np.ascontiguousarray(xy[:, :w]), inf, self.curve)
+        return {l: (p, None) for l, p in zip(INDEX_LABELS, pts)}
+
+    def free(self):
+        if self.h:
+            _lib.check(self.ctx.lib.zkp_marlin_index_free(self.ctx.h, self.h), "zkp_marlin_index_free")
+            self.h = None
+
+
+def prove_native(ctx: Context, nidx: NativeIndex, ck: kzg10.CommitterKey, ivk: dict | None, x, w_mont, rnd, ch: dict | None = None):
+    """zkp_marlin_prove.  ivk: index verifier key dict (its to_bytes seeds the transcript) — create_random_proof; or
+    ch: dict of fixed verifier messages (test hook).  x: formatted inputs (ints, leading one included); w_mont: witness
+    (n_w, 4) Montgomery or list of ints.  Returns the same dictionary shape as `create_proof`."""
+    from .fs_rng import index_verifier_key_bytes
+    c = nidx.curve
+    mont = lambda v: np.ascontiguousarray(codec.fr_to_mont(list(v), c).reshape(-1, 4))
+    xm = mont(x)
+    wm = np.ascontiguousarray(w_mont if isinstance(w_mont, np.ndarray) else mont(w_mont))
+    keep = [xm, wm]
+    R = _lib.MarlinRand()
+
+    def P(a):
+        keep.append(a)
+        return a.ctypes.data
+
+    R.w, R.z_a, R.z_b = P(mont(rnd["w"])), P(mont(rnd["z_a"])), P(mont(rnd["z_b"]))
+    mask = rnd["mask"] if isinstance(rnd["mask"], np.ndarray) else mont(rnd["mask"])
+    R.mask, R.mask_on_device = P(np.ascontiguousarray(mask)), 0
+    R.blind_w, R.blind_z_a, R.blind_z_b = (P(mont(rnd["blind"][l])) for l in ("w", "z_a", "z_b"))
+    R.blind_g_1, R.blind_shifted_g_1 = P(mont(rnd["blind"]["g_1"])), P(mont(rnd["blind_shifted"]["g_1"]))
+    fixed = None
+    ivk_b = b""
+    if ch is not None:
+        fixed = mont([ch[k] for k in ("alpha", "eta_a", "eta_b", "eta_c", "beta", "gamma", "xi")])
+        keep.append(fixed)
+    else:
+        ivk_b = index_verifier_key_bytes(ivk, c)
+    ivk_buf = (C.c_uint8 * max(len(ivk_b), 1)).from_buffer_copy(ivk_b or b"\x00")
+    out = _lib.MarlinProof()
+    _lib.check(ctx.lib.zkp_marlin_prove(ctx.h, nidx.h, ck.powers_of_g.handle, ck.powers_of_gamma_g.handle,
+                                        C.cast(ivk_buf, C.c_void_p) if ch is None else None, len(ivk_b), api._ptr(xm),
+                                        api._ptr(wm), wm.shape[0], C.byref(R), None if fixed is None else api._ptr(fixed),
+                                        C.byref(out)), "zkp_marlin_prove")
+    w2 = 2 * c.fq_limbs
+    g1 = lambda words, inf: codec.g1_from_mont(np.array(words[:w2], dtype=np.uint64).reshape(1, w2), [inf], c)[0]
+    labels = LABELS_1 + LABELS_2 + LABELS_3
+    comm = np.array(out.comm, dtype=np.uint64).reshape(9, 12)
+    sh = np.array(out.shifted, dtype=np.uint64).reshape(2, 12)
+    comms = {}
+    for i, l in enumerate(labels):
+        s = None
+        if l == "g_1":
+            s = g1(sh[0], out.shifted_inf[0])
+        elif l == "g_2":
+            s = g1(sh[1], out.shifted_inf[1])
+        comms[l] = (g1(comm[i], out.comm_inf[i]), s)
+    chs = codec.fr_from_mont(np.array(out.challenges, dtype=np.uint64).reshape(7, 4), c)
+    chd = dict(zip(("alpha", "eta_a", "eta_b", "eta_c", "beta", "gamma", "xi"), chs))
+    evals = codec.fr_from_mont(np.array(out.evaluations, dtype=np.uint64).reshape(-1, 4), c)
+    query = sorted([(l, chd["beta"]) for l in LABELS_1 + LABELS_2] + [(l, chd["gamma"]) for l in LABELS_3 + INDEX_LABELS])
+    ow = np.array(out.opening_w, dtype=np.uint64).reshape(2, 12)
+    rv = codec.fr_from_mont(np.array(out.opening_rand_v, dtype=np.uint64).reshape(2, 4), c)
+    proofs = [(g1(ow[k], out.opening_w_inf[k]), rv[k] if out.opening_has_rand[k] else None)
+              for k in range(out.num_opening_proofs)]
+    return dict(commitments=comms, evaluations=evals, opening_proofs=proofs, query=query, challenges=chd)

@@ -282,6 +282,65 @@ int32_t zkp_merlin_oneshot(const uint8_t* label, size_t label_len, const uint8_t
                            const uint8_t* msg, size_t msg_len, const uint8_t* chal_label, size_t chal_label_len,
                            uint8_t* out, size_t out_len);
 
+/* ---- Marlin: replaces zkp_marlin::index (device half) and zkp_marlin::create_random_proof (marlin/src/lib.rs:69-181) ----
+ * The caller keeps synthesis and the index-manipulation half of AHP::index (make_matrices_square, balance_matrices, per-row
+ * column sort: ahp/constraint_systems.rs:9-31,100-133) and hands over the three square matrices as CSR; the library computes
+ * the arithmetization (row / col / val / row_col over K, their interpolations and evaluations over B: arithmetic.rs:98-172)
+ * on the device and keeps it resident.  `zkp_marlin_prove` runs prover_init and the three AHP rounds (ahp/prover.rs:86-427),
+ * PC::commit after each round (pc/mod.rs:34-71, MSMs on the resident SRS powers), the Fiat–Shamir transcript
+ * (fs_rng.rs; lib.rs:105-158), the 21 evaluations and PC::batch_open (pc/mod.rs:73-160).  The zk randomness the reference
+ * draws from `zk_rng` (mask polynomial, the three degree-0 masks, the hiding-bound-1 commitment blinders) is an input. */
+typedef struct zkp_marlin_index zkp_marlin_index;
+typedef struct {
+  zkp_curve_t curve;
+  uint32_t num_inputs; /* formatted public inputs incl. the leading one */
+  uint32_t n;          /* rows == columns after make_matrices_square */
+  uint32_t pad_aux;    /* dummy witness variables (value one) make_matrices_square appended */
+  zkp_csr a, b, c;     /* n rows each, balanced, columns ascending per row, col < n; coeffs Fr Montgomery */
+} zkp_marlin_index_desc;
+#define ZKP_MARLIN_NUM_EVALS 21
+typedef struct {
+  const uint64_t* w;   /* 1 Fr (Montgomery) each: the degree-0 masks of prover.rs:190,196,200 */
+  const uint64_t* z_a;
+  const uint64_t* z_b;
+  const uint64_t* mask;    /* 3|H| Fr: DensePolynomial::rand of prover.rs:202-203 (host, or device if mask_on_device) */
+  int32_t mask_on_device;
+  const uint64_t* blind_w; /* 2 Fr each: `Rand::rand(hiding_bound = 1)` of KZG10::commit for w, z_a, z_b, g_1 and g_1's shifted commitment */
+  const uint64_t* blind_z_a;
+  const uint64_t* blind_z_b;
+  const uint64_t* blind_g_1;
+  const uint64_t* blind_shifted_g_1;
+} zkp_marlin_rand;
+typedef struct {
+  /* commitments in oracle order w, z_a, z_b, mask | t, g_1, h_1 | g_2, h_2: G1 affine Montgomery in 12-u64 slots */
+  uint64_t comm[9 * 12];
+  uint8_t comm_inf[9];
+  uint64_t shifted[2 * 12]; /* degree-bound commitments of g_1 and g_2 */
+  uint8_t shifted_inf[2];
+  uint64_t evaluations[ZKP_MARLIN_NUM_EVALS * 4]; /* query-set order = labels ascending (lib.rs:147-156), Fr Montgomery */
+  uint32_t num_opening_proofs;                    /* 2 (1 if beta == gamma); query points ascending */
+  uint64_t opening_w[2 * 12];
+  uint8_t opening_w_inf[2];
+  uint8_t opening_has_rand[2];
+  uint64_t opening_rand_v[2 * 4];
+  uint64_t challenges[7 * 4]; /* alpha, eta_a, eta_b, eta_c, beta, gamma, opening challenge (Fr Montgomery) as used */
+} zkp_marlin_proof;
+int32_t zkp_marlin_index_upload(zkp_ctx* ctx, const zkp_marlin_index_desc* desc, zkp_marlin_index** out);
+int32_t zkp_marlin_index_free(zkp_ctx* ctx, zkp_marlin_index* index);
+/* info[6] = |X|, |H|, |K|, |B|, max_degree (= the SRS degree `index.max_degree()` needs), num_non_zeros */
+int32_t zkp_marlin_index_info(const zkp_marlin_index* index, uint64_t info[6]);
+/* the 12 index commitments (lib.rs:77-83; a_row, a_col, a_val, a_row_col, b_..., c_...): G1 affine Montgomery, 12-u64 slots */
+int32_t zkp_marlin_index_commit(zkp_ctx* ctx, zkp_marlin_index* index, uint64_t powers_of_g, uint64_t* comms_xy,
+                                uint8_t* inf);
+/* powers_of_g / powers_of_gamma_g: resident bases (zkp_bases_upload_g1) of the committer key, >= max_degree + 1 / >= 2 points.
+ * ivk_bytes = to_bytes![index_verifier_key] (the caller owns and serialises the key); x: num_inputs formatted inputs
+ * (leading one included), w: the witness without the make_matrices_square padding — Fr Montgomery, host.
+ * fixed_challenges == NULL: create_random_proof (messages derived from the transcript).  Non-NULL (7 Fr Montgomery: alpha,
+ * eta_a, eta_b, eta_c, beta, gamma, xi): TEST HOOK — the messages are taken as given, the transcript is not consulted. */
+int32_t zkp_marlin_prove(zkp_ctx* ctx, zkp_marlin_index* index, uint64_t powers_of_g, uint64_t powers_of_gamma_g,
+                         const uint8_t* ivk_bytes, size_t ivk_len, const uint64_t* x, const uint64_t* w, size_t n_w,
+                         const zkp_marlin_rand* rnd, const uint64_t* fixed_challenges, zkp_marlin_proof* out);
+
 /* ---- introspection for bench.py / rocprof bookkeeping ------------------------------------------ */
 typedef struct {
   float ms_total;          /* last zkp_groth16_prove*: stream time, HIP events */

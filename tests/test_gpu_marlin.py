@@ -253,3 +253,60 @@ def test_marlin_config4_full_size_verifies(ctx):
         ck.powers_of_gamma_g.free()
         marlin_dev.DeviceBackend.trim_pool(ctx)
         didx.free()
+
+
+@pytest.mark.parametrize("curve,samples,swap", [("bn254", 3, False), ("bls12_381", 2, False), ("bn254", 7, True)])
+def test_native_marlin_prover_matches_oracle(ctx, curve, samples, swap):
+    """zkp_marlin_index_upload / zkp_marlin_index_commit / zkp_marlin_prove (csrc/marlin.hip: the whole create_random_proof
+    behind the C ABI, no Python between the rounds) against the oracle: index commitments, the proof for supplied verifier
+    messages (test hook) and the proof with messages DERIVED from the Fiat–Shamir transcript are bit-identical to the
+    oracle's, and the oracle's verifier (which re-derives the messages) accepts; a wrong public input is rejected."""
+    from ckb_zkp_amd import marlin_dev
+    from ckb_zkp_amd.circuits import mimc_chain_instance
+    c = get_curve(curve)
+    inst = mimc_chain_instance(curve, samples, seed=91)
+    ocirc = og.MimcChain(OC[curve], inst.constants, inst.preimages)
+    if swap:
+        from ckb_zkp_amd.r1cs import R1csInstance
+        inst = R1csInstance(curve, inst.num_inputs, inst.num_aux, inst.num_constraints(), inst.csr("b"), inst.csr("a"),
+                            inst.csr("c"), inst.z)
+        ocirc = _SwapAB(ocirc)
+    oidx = om.index(OC[curve], ocirc)
+    nidx = marlin_dev.NativeIndex(ctx, inst)
+    assert (nidx.xs, nidx.hs, nidx.ks, nidx.bs, nidx.max_degree, nidx.num_non_zeros) == \
+        (oidx["dx"].size, oidx["dh"].size, oidx["dk"].size, oidx["db"].size, oidx["max_degree"], oidx["num_non_zeros"])
+    beta_srs = 0x13579BDF2468ACE
+    pp = okzg.setup(OC[curve], nidx.max_degree, beta_srs)
+    ck = kzg10.setup(ctx, curve, nidx.max_degree, beta_srs)
+    try:
+        ic = om.index_commitments(oidx, pp)
+        assert nidx.commit_index(ck) == ic
+        R, ch = _rand_inputs(c, nidx.hs, seed=57)
+        x, w = inst.z[:inst.num_inputs], inst.z[inst.num_inputs:]
+        # supplied verifier messages (test hook)
+        p = marlin_dev.prove_native(ctx, nidx, ck, None, x, w, R, ch)
+        o = om.create_proof(oidx, pp, ocirc, R, ch)
+        assert p["commitments"] == o["commitments"]
+        assert p["query"] == o["query"] and p["evaluations"] == o["evaluations"]
+        assert p["opening_proofs"] == o["opening_proofs"]
+        # create_random_proof: messages derived inside the library
+        ivk = om.index_verifier_key(oidx, pp, ic)
+        assert ck.vk_g2 == (pp["h"], pp["beta_h"])
+        p = marlin_dev.prove_native(ctx, nidx, ck, ivk, x, w, R)
+        o = om.create_random_proof(oidx, pp, ic, ocirc, R)
+        assert p["challenges"] == o["challenges"]
+        assert p["commitments"] == o["commitments"] and p["evaluations"] == o["evaluations"]
+        assert p["opening_proofs"] == o["opening_proofs"]
+        wire = dict(commitments=p["commitments"], evaluations=p["evaluations"], opening_proofs=p["opening_proofs"])
+        assert om.verify_random_proof(oidx, pp, ic, wire, x[1:])
+        assert not om.verify_random_proof(oidx, pp, ic, wire, [(v + 1) % c.r for v in x[1:]] or [3])
+        # a second proof on the same index (pooled scratch reused) with other randomness differs and verifies
+        R2, _ = _rand_inputs(c, nidx.hs, seed=58)
+        p2 = marlin_dev.prove_native(ctx, nidx, ck, ivk, x, w, R2)
+        assert p2["commitments"] != p["commitments"]
+        wire2 = dict(commitments=p2["commitments"], evaluations=p2["evaluations"], opening_proofs=p2["opening_proofs"])
+        assert om.verify_random_proof(oidx, pp, ic, wire2, x[1:])
+    finally:
+        nidx.free()
+        ck.powers_of_g.free()
+        ck.powers_of_gamma_g.free()
