@@ -675,8 +675,11 @@ def prove_native(ctx: Context, nidx: NativeIndex, ck: kzg10.CommitterKey, ivk: d
         return a.ctypes.data
 
     R.w, R.z_a, R.z_b = P(mont(rnd["w"])), P(mont(rnd["z_a"])), P(mont(rnd["z_b"]))
-    mask = rnd["mask"] if isinstance(rnd["mask"], np.ndarray) else mont(rnd["mask"])
-    R.mask, R.mask_on_device = P(np.ascontiguousarray(mask)), 0
+    if rnd.get("mask_dev"):                                  # the mask polynomial already resident in HBM (3|H| Fr)
+        R.mask, R.mask_on_device = rnd["mask_dev"], 1
+    else:
+        mask = rnd["mask"] if isinstance(rnd["mask"], np.ndarray) else mont(rnd["mask"])
+        R.mask, R.mask_on_device = P(np.ascontiguousarray(mask)), 0
     R.blind_w, R.blind_z_a, R.blind_z_b = (P(mont(rnd["blind"][l])) for l in ("w", "z_a", "z_b"))
     R.blind_g_1, R.blind_shifted_g_1 = P(mont(rnd["blind"]["g_1"])), P(mont(rnd["blind_shifted"]["g_1"]))
     fixed = None

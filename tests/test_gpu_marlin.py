@@ -246,8 +246,19 @@ def test_marlin_config4_full_size_verifies(ctx):
         bad = dict(wire, evaluations=wire["evaluations"][:3] + [(wire["evaluations"][3] + 1) % c.r] + wire["evaluations"][4:])
         assert not om.verify_random_proof(oidx, pp, ic, bad, [])
         # and the fixed-challenge test hook still yields an accepting proof for the supplied messages
-        proof = marlin_dev.create_proof(ctx, didx, ck, (inst.z[:1], inst.z[1:]), R, ch)
-        assert om.verify_proof(oidx, pp, ic, proof, [], ch)
+        proof2 = marlin_dev.create_proof(ctx, didx, ck, (inst.z[:1], inst.z[1:]), R, ch)
+        assert om.verify_proof(oidx, pp, ic, proof2, [], ch)
+        # the C entry point (zkp_marlin_index_upload + zkp_marlin_prove) at full size: same index commitments, the same
+        # proof as the Python-orchestrated device prover (same randomness, same transcript), accepted by the verifier
+        nidx = marlin_dev.NativeIndex(ctx, inst)
+        try:
+            assert nidx.commit_index(ck) == ic
+            nproof = marlin_dev.prove_native(ctx, nidx, ck, ivk, inst.z[:1], inst.z[1:], R)
+            assert nproof["challenges"] == proof["challenges"]
+            assert nproof["commitments"] == proof["commitments"] and nproof["evaluations"] == proof["evaluations"]
+            assert nproof["opening_proofs"] == proof["opening_proofs"]
+        finally:
+            nidx.free()
     finally:
         ck.powers_of_g.free()
         ck.powers_of_gamma_g.free()
