@@ -266,6 +266,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- single-proof latency: blocking zkp_groth16_prove_dev calls, one proof in flight (the latency-oriented stream plan)
+    latency = None
+    if rank == 0:
+        for _ in range(3):
+            step()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        latency = {"ms_per_proof": round((time.perf_counter() - t0) / 10 * 1e3, 3),
+                   "note": "one proof in flight: zkp_groth16_prove_dev blocking calls (witness resident), host time incl. the read-back"}
+
     # ---- roofline of the dominant kernel (bucket accumulation), measured live with HIP events on the ctx stream
     roofline = None
     phases = None
@@ -485,7 +496,7 @@ def main():
                        "curve": c.name, "log_domain": args.log_n, "parallelism": f"independent proofs x{world}",
                        "pipelining": "none" if args.no_pipeline else f"{os.environ.get('ZKP_LANES', '8 (4 above 2^22)')} proofs in flight per GPU (zkp_groth16_prove_batch_dev), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}"},
             "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_scan": roofline_scan, "valu_roof": valu_roof,
-            "with_h2d": with_h2d, "cpu_baseline": cpu_baseline, "msm_g1": msm_g1, "marlin_config4": marlin,
+            "with_h2d": with_h2d, "latency": latency, "cpu_baseline": cpu_baseline, "msm_g1": msm_g1, "marlin_config4": marlin,
             "phases_ms": phases,
         }
         print(json.dumps(out), flush=True)

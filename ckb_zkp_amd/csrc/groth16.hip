@@ -344,7 +344,7 @@ void groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, ui
 // part: 1 = copy the inputs (z, r, s) into the lane's buffers, 2 = everything else (the part a hipGraph captures), 3 = both
 template <class FrP>
 static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
-                               const uint64_t* s, int part, char* partial_out = nullptr) {
+                               const uint64_t* s, int part, char* partial_out = nullptr, bool latency_plan = false) {
   // partial_out != nullptr (base-sharded key): no assembly; the 5 XYZZ sums of this rank's slices (A | B1 | B2 | H | L,
   // G2-sized slots) are left at partial_out (device) for the all-gather
   ZKP_REQUIRE((pk->shard_world > 0) == (partial_out != nullptr), ZKP_ERR_BAD_ARG);
@@ -388,6 +388,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   const size_t slot = v2->xyzz_bytes;                  // uniform slot size
   char* res = reinterpret_cast<char*>(PL.results.get(6 * slot));
   const uint64_t* Sd = reinterpret_cast<const uint64_t*>(S);
+  bool l_done_in_fan = false;
   float acc_ms = 0.f, scan_ms = 0.f;
   uint64_t ent = 0, scan_bytes = 0, scan_runs = 0;
   // Schedule.  profiling: everything on the main stream, one MSM at a time, with per-phase events.
@@ -416,20 +417,37 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   if (fan) {
     ZKP_HIP(hipEventRecord(ctx->cur->ev_fork, st));                       // S is complete
     for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[w].stream, ctx->cur->ev_fork, 0));
+    static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
+    static const int lat_env = [] { const char* e = getenv("ZKP_LATENCY_PLAN"); return e ? atoi(e) : -1; }();
+    const bool lat = lat_env >= 0 ? lat_env != 0 : latency_plan;
+    if (lat) {
+      // ONE proof in flight (zkp_groth16_prove(_dev), the sharded step): minimise the critical path instead of packing the
+      // machine.   ws2: B2 | ws1: A -> L | ws3: B1 (B2's sort), then s*g_a + r*g1_b as soon as A exists | main: witness_map -> H
+      run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2);
+      run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1);
+      ZKP_HIP(hipEventRecord(ctx->cur->ev_a, ctx->cur->ws[1].stream));
+      run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 3, pk->share_b_sort ? 2 : -1);
+      run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 1);
+      if (!partial_out) {
+        ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_a, 0));
+        v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, proof_dev, flags_dev);
+      }
+    } else {
     // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H | ws3: L, then part 1 after A, B1
     // (4 lanes x 4 streams = 16 streams = one hardware queue each under GPU_MAX_HW_QUEUES=16)
     run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2);                          // prover.rs:182-184
     run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1);                           // prover.rs:164-167
     run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 1, pk->share_b_sort ? 2 : -1);   // prover.rs:170-177 (B2's bucket sort reused)
-    static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
     if (l_own) run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 3, pk->share_al_sort ? 1 : -1);   // prover.rs:189-190 (A's sort reused)
     ZKP_HIP(hipEventRecord(ctx->cur->ev_b1, ctx->cur->ws[1].stream));
-    // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~4 ms single-wave chain: start them as soon as
+    // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~2 ms single-lane chain each: start them as soon as
     // A and B1 exist so they hide under the remaining MSMs
     if (!partial_out) {
       ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_b1, 0));
       v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, proof_dev, flags_dev);
     }
+    }
+    l_done_in_fan = lat || l_own;
   }
   tic();
   uint32_t* h = witness_map_dev<FrP>(ctx, pk, S);
@@ -440,10 +458,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 0);
   }
   run(3, pk->hH, reinterpret_cast<const uint64_t*>(h) + 4 * pk->q_lo[3], pk->q_n[3], 0);  // :186-187 (min(len) truncation in q_n)
-  {
-    static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
-    if (!(fan && l_own)) run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 0);                                       // :189-190
-  }
+  if (!(fan && l_done_in_fan)) run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 0);                                 // :189-190
   if (fan) {
     for (int w = 1; w < zkp_ctx::N_WS; w++) {
       ZKP_HIP(hipEventRecord(ctx->cur->ws[w].done, ctx->cur->ws[w].stream));
@@ -507,13 +522,14 @@ static std::vector<const void*> lane_signature(zkp_ctx* ctx, zkp_groth16_pk* pk)
 // captured once per (key, lane) into a hipGraph and replayed; the inputs are copied in front of the graph launch.
 template <class FrP>
 static void prove_enqueue(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
-                          const uint64_t* s) {
+                          const uint64_t* s, bool latency_plan = false) {
   static const bool graph_on = getenv("ZKP_GRAPH") && atoi(getenv("ZKP_GRAPH")) != 0;
   static const bool single_stream = getenv("ZKP_SINGLE_STREAM") && atoi(getenv("ZKP_SINGLE_STREAM")) != 0;
   if (!graph_on || ctx->profiling || single_stream) {
-    prove_enqueue_part<FrP>(ctx, pk, z, z_on_device, r, s, 3);
+    prove_enqueue_part<FrP>(ctx, pk, z, z_on_device, r, s, 3, nullptr, latency_plan);
     return;
   }
+  // (graph replay always uses the throughput plan: a captured graph embeds its stream plan)
   zkp_groth16_pk::PerLane& PL = pk->lane[ctx->cur_idx];
   hipStream_t st = ctx->cur->stream;
   if (PL.graph_state == 2 && PL.sig == lane_signature(ctx, pk)) {
@@ -602,8 +618,8 @@ void groth16_prove_partials(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_
   ZKP_REQUIRE(pk->shard_world > 0, ZKP_ERR_BAD_ARG);
   ctx->cur = &ctx->lanes[0];
   ctx->cur_idx = 0;
-  if (pk->curve == ZKP_BN254) prove_enqueue_part<Bn254Fr>(ctx, pk, z_dev, true, r, s, 3, (char*)out_dev);
-  else prove_enqueue_part<Bls381Fr>(ctx, pk, z_dev, true, r, s, 3, (char*)out_dev);
+  if (pk->curve == ZKP_BN254) prove_enqueue_part<Bn254Fr>(ctx, pk, z_dev, true, r, s, 3, (char*)out_dev, true);
+  else prove_enqueue_part<Bls381Fr>(ctx, pk, z_dev, true, r, s, 3, (char*)out_dev, true);
   ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
 }
 
@@ -642,8 +658,8 @@ void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_o
   ZKP_REQUIRE(pk->shard_world == 0, ZKP_ERR_BAD_ARG);     // a sharded key yields partial sums only
   ctx->cur = &ctx->lanes[0];
   ctx->cur_idx = 0;
-  if (pk->curve == ZKP_BN254) prove_enqueue<Bn254Fr>(ctx, pk, z, z_on_device, r, s);
-  else prove_enqueue<Bls381Fr>(ctx, pk, z, z_on_device, r, s);
+  if (pk->curve == ZKP_BN254) prove_enqueue<Bn254Fr>(ctx, pk, z, z_on_device, r, s, true);
+  else prove_enqueue<Bls381Fr>(ctx, pk, z, z_on_device, r, s, true);
   prove_finish(ctx, pk, proof_out, inf_out);
 }
 

@@ -318,33 +318,70 @@ __global__ __launch_bounds__(128) void fixed_base_kernel(const uint32_t* base, c
 // (prover.rs:192-210 after the folding described in groth16.hip)
 namespace ZKP_CFG_SYM(cfg) {
 #if ZKP_CFG_GROUP == 1
-// part 1 — lanes 0/1: s*g_a and r*g1_b (double-and-add on the affine-normalised point); T = sum -> slot 5
-__global__ __launch_bounds__(64) void assemble_g1_part1_kernel(char* __restrict__ res, size_t slot,
-                                                               const uint32_t* __restrict__ rs,
-                                                               uint32_t* __restrict__ out,
-                                                               uint32_t* __restrict__ flags) {
+// part 1 — T = s*g_a + r*g1_b -> slot 5; proof.a = affine(g_a).  Two waves, one per scalar multiplication.  The 254
+// doublings of a dynamic point are an inherently serial chain; everything else is taken off it: lane 0 of each wave runs
+// ONLY the doubling chain (Jacobian dbl-2009-l, a = 0: 2M + 5S = 7 products per step instead of the 9 of the XYZZ doubling
+// plus ~5 of the conditional mixed addition) and publishes D_k = 2^k P to LDS; afterwards the 64 lanes of the wave sum the
+// D_k whose scalar bit is set (4 candidates per lane, then an LDS tree).  3.3 -> ~2 ms of single-lane latency.
+template <class F>
+__device__ __forceinline__ void jac_dbl(F& X, F& Y, F& Z) {
+  F A = X.sqr(), B = Y.sqr();
+  F C = B.sqr();
+  F D = ((X + B).sqr() - A - C).dbl();
+  F E = A.dbl() + A;
+  F Fq = E.sqr();
+  F Z3 = (Y * Z).dbl();
+  X = Fq - D.dbl();
+  Y = E * (D - X) - C.dbl().dbl().dbl();
+  Z = Z3;
+}
+__global__ __launch_bounds__(128) void assemble_g1_part1_kernel(char* __restrict__ res, size_t slot,
+                                                                const uint32_t* __restrict__ rs,
+                                                                uint32_t* __restrict__ out,
+                                                                uint32_t* __restrict__ flags) {
   using F = CfgF;
+  __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x;
-  XYZZ<F> acc = XYZZ<F>::inf();
-  if (t < 2) {
-    // t = 0: g_a (slot 0) times s ; t = 1: g1_b (slot 1) times r
-    XYZZ<F> p = XYZZ<F>::load(res + (size_t)t * slot);
+  constexpr int NB = CFG_BITS + 1;                             // bits 0 .. CFG_BITS of a canonical scalar
+  constexpr size_t JB = 3 * 4 * F::N;                          // bytes of a Jacobian point
+  const int t = threadIdx.x, chain = t >> 6, lane = t & 63;
+  char* D = smem + (size_t)chain * NB * JB;                    // D[k] = 2^k * P (Jacobian)
+  char* red = smem + 2 * NB * JB + (size_t)chain * 64 * XYZZ<F>::BYTES;
+  // chain 0: g_a (slot 0) times s ; chain 1: g1_b (slot 1) times r
+  Fp<CfgFr> k = Fp<CfgFr>::load(rs + (chain == 0 ? 8 : 0)).from_mont();
+  if (lane == 0) {
+    XYZZ<F> p = XYZZ<F>::load(res + (size_t)chain * slot);
     Affine<F> a = p.to_affine();
-    if (t == 0) {
-      a.store(out);                              // proof.a
+    if (chain == 0) {
+      a.store(out);                                            // proof.a
       flags[0] = p.is_inf() ? 1 : 0;
     }
-    Fp<CfgFr> k = Fp<CfgFr>::load(rs + (t == 0 ? 8 : 0)).from_mont();
-    for (int bit = CFG_BITS; bit >= 0; bit--) {
-      acc = acc.dbl();
-      if ((k.v[bit >> 5] >> (bit & 31)) & 1) acc.madd(a);
+    F X = a.x, Y = a.y, Z = p.is_inf() ? F::zero() : F::one();
+    for (int b = 0; b < NB; b++) {
+      X.store(D + (size_t)b * JB);
+      Y.store(D + (size_t)b * JB + 4 * F::N);
+      Z.store(D + (size_t)b * JB + 8 * F::N);
+      if (b + 1 < NB) jac_dbl(X, Y, Z);
     }
   }
-  acc.store(smem + t * XYZZ<F>::BYTES);
   __syncthreads();
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int b = lane; b < NB; b += 64)
+    if ((k.v[b >> 5] >> (b & 31)) & 1) acc.add(jac_to_xyzz<F>(reinterpret_cast<const uint32_t*>(D + (size_t)b * JB)));
+  acc.store(red + (size_t)lane * XYZZ<F>::BYTES);
+  __syncthreads();
+  for (int s2 = 32; s2 > 0; s2 >>= 1) {
+    if (lane < s2) {
+      XYZZ<F> o = XYZZ<F>::load(red + (size_t)(lane + s2) * XYZZ<F>::BYTES);
+      if (!o.is_inf() || !acc.is_inf()) {
+        acc.add(o);
+        acc.store(red + (size_t)lane * XYZZ<F>::BYTES);
+      }
+    }
+    __syncthreads();
+  }
   if (t == 0) {
-    acc.add(XYZZ<F>::load(smem + XYZZ<F>::BYTES));
+    acc.add(XYZZ<F>::load(smem + 2 * NB * JB + 64 * XYZZ<F>::BYTES));     // chain 1's sum
     acc.store(res + 5 * slot);
   }
 }
@@ -430,7 +467,8 @@ void l_fixed_base(hipStream_t s, const uint32_t* base, const uint32_t* scalars, 
 }
 #if ZKP_CFG_GROUP == 1
 void l_assemble_g1_p1(hipStream_t s, char* res, size_t slot, const uint32_t* rs, uint32_t* out, uint32_t* flags) {
-  hipLaunchKernelGGL(assemble_g1_part1_kernel, dim3(1), dim3(64), 64 * XB, s, res, slot, rs, out, flags);
+  const size_t lds = 2 * (size_t)(CFG_BITS + 1) * 3 * 4 * F::N + 2 * 64 * XB;
+  hipLaunchKernelGGL(assemble_g1_part1_kernel, dim3(1), dim3(128), lds, s, res, slot, rs, out, flags);
 }
 void l_assemble_g1_p2(hipStream_t s, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int c_off_words) {
   hipLaunchKernelGGL(assemble_g1_part2_kernel, dim3(1), dim3(64), 0, s, res, slot, out, flags, c_off_words);
