@@ -80,6 +80,8 @@ struct NttTables {
   uint32_t* full_inv[8] = {};
   uint32_t* full_g = nullptr;
   uint32_t* full_gi = nullptr;
+  uint32_t* g_hi_n = nullptr;     // g^(i<<h) / N: coset pre-scale with the inverse transform's 1/N folded in (fused ifft -> coset_fft)
+  uint32_t* full_g_n = nullptr;
   std::vector<void*> extra;
 };
 

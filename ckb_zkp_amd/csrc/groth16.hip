@@ -316,9 +316,18 @@ static uint32_t* witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint32_
     ntt_run_batch(ctx, pk->curve, bufs, 3, pk->log_n, ZKP_NTT_COSET_FFT);
   } else {
     for (int k = 0; k < 3; k++) {
-      ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_IFFT);
-      ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_COSET_FFT);
+      // ifft -> coset_fft as one chain of passes (1/N folded into the coset table, no odd-pass copies); falls back to the two
+      // separate transforms above the full-table domain limit
+      if (!ntt_ifft_coset_fft(ctx, pk->curve, bufs[k], pk->log_n)) {
+        ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_IFFT);
+        ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_COSET_FFT);
+      }
     }
+  }
+  // (a*b - c) / Z(g) fused into the first pass of coset_ifft; h lands in a or b
+  if (uint32_t* hq = ntt_qap_coset_ifft(ctx, pk->curve, a, b, c, pk->consts.as<uint32_t>(64), pk->log_n)) {
+    ZKP_HIP(hipGetLastError());
+    return hq;
   }
   hipLaunchKernelGGL(qap_pointwise_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, st, a, b, c,
                      pk->consts.as<uint32_t>(64), N);

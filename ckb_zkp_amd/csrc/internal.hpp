@@ -8,6 +8,10 @@ namespace zkp {
 void ntt_run(zkp_ctx* ctx, int curve, uint32_t* data_dev, int log_n, int op);
 // count <= 4 independent transforms of the same size and kind in the same launches (grid.y)
 void ntt_run_batch(zkp_ctx* ctx, int curve, uint32_t* const* data_dev, int count, int log_n, int op);
+// fused witness-map chains (ntt.hip); return false / nullptr when the fused form is unavailable (domain above the full-table
+// limit, ZKP_NTT_FUSE=0): the caller then uses the separate transforms
+bool ntt_ifft_coset_fft(zkp_ctx* ctx, int curve, uint32_t* data, int log_n);
+uint32_t* ntt_qap_coset_ifft(zkp_ctx* ctx, int curve, uint32_t* a, uint32_t* b, uint32_t* c, const uint32_t* zinv, int log_n);
 void ntt_free_tables(zkp_ctx* ctx);
 
 // poly.hip (all pointers device memory unless *_host)

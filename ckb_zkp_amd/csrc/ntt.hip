@@ -107,7 +107,7 @@ static NttTables& get_tables(zkp_ctx* ctx, int curve, int log_n) {
   int sub = std::min(log_n, NTT_SUB_LOG);
   size_t subn = sub > 0 ? ((size_t)1 << sub) / 2 : 1;
   if (subn == 0) subn = 1;
-  size_t words = (4 * (lo + hi) + 2 * subn + 16) * 8;
+  size_t words = (4 * (lo + hi) + hi + 2 * subn + 16) * 8;
   uint32_t* blk;
   if (hipMalloc(&blk, words * 4) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
   t.block = blk;
@@ -121,6 +121,7 @@ static NttTables& get_tables(zkp_ctx* ctx, int curve, int log_n) {
   t.g_hi = p; p += hi * 8;
   t.gi_lo = p; p += lo * 8;
   t.gi_hi = p; p += hi * 8;
+  t.g_hi_n = p; p += hi * 8;
   t.sub_fwd = p; p += subn * 8;
   t.sub_inv = p; p += subn * 8;
   t.n_inv = consts + 6 * 8;
@@ -137,6 +138,7 @@ static NttTables& get_tables(zkp_ctx* ctx, int curve, int log_n) {
   gen(t.g_hi, consts + 4 * 8, nullptr, hi);
   gen(t.gi_lo, consts + 10 * 8, nullptr, lo);
   gen(t.gi_hi, consts + 5 * 8, consts + 6 * 8, hi);   // g^-(i<<h) / N
+  gen(t.g_hi_n, consts + 4 * 8, consts + 6 * 8, hi);  // g^(i<<h) / N
   gen(t.sub_fwd, consts + 7 * 8, nullptr, subn);
   gen(t.sub_inv, consts + 8 * 8, nullptr, subn);
   ZKP_HIP(hipGetLastError());
@@ -163,6 +165,11 @@ struct NttPassArgs {
   const uint32_t* post_full;
   const uint32_t* in[NTT_MAX_BATCH];
   uint32_t* out[NTT_MAX_BATCH];
+  // optional (first pass of the witness map's coset_ifft): the input element is (in * fuse_b - fuse_c) * fuse_k, i.e. the
+  // pointwise step (a*b - c) / Z(g) of r1cs_to_qap.rs:150,164-168 fused into the load
+  const uint32_t* fuse_b;
+  const uint32_t* fuse_c;
+  const uint32_t* fuse_k;
 };
 
 // full tables: out[i] = hi[e >> h] * lo[e & mask] with e = i (coset factors) or the inter-pass exponent of output i
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
     uint32_t j1 = e >> logC, cc = e & (C - 1);
     uint32_t gidx = j1 * ncols + c0 + cc;
     F x = F::load(in + (size_t)gidx * 8);
+    if (a.fuse_b) x = (x * F::load(a.fuse_b + (size_t)gidx * 8) - F::load(a.fuse_c + (size_t)gidx * 8)) * F::load(a.fuse_k);
     if (a.pre_full) {
       x = x * F::load(a.pre_full + (size_t)gidx * 8);
     } else if (a.pre_lo) {
@@ -433,6 +441,114 @@ void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* const* data, int count, int lo
   if (in_scratch)
     for (int k = 0; k < count; k++)
       ZKP_HIP(hipMemcpyAsync(data[k], scratch + (size_t)k * N * 8, N * 32, hipMemcpyDeviceToDevice, ctx->cur->stream));
+}
+
+// One pass launch shared by the fused runners below.
+template <class P>
+static void launch_pass(zkp_ctx* ctx, NttTables& t, int log_n, const int* S, int np, int p, int logB, bool inverse,
+                        const uint32_t* in, uint32_t* out, NttPassArgs a) {
+  a.in[0] = in;
+  a.out[0] = out;
+  a.log_n = log_n;
+  a.S = S[p];
+  a.logB = logB;
+  const int logC = std::min(NTT_TILE_LOG - S[p], log_n - S[p]);
+  a.logC = logC;
+  a.sub_log = std::min(log_n, NTT_SUB_LOG);
+  a.last = (p == np - 1);
+  a.h = t.h;
+  a.tw_sub = inverse ? t.sub_inv : t.sub_fwd;
+  a.tw_lo = inverse ? t.wi_lo : t.w_lo;
+  a.tw_hi = inverse ? t.wi_hi : t.w_hi;
+  if (!a.last) a.tw_full = full_table<P>(ctx, t, inverse ? &t.full_inv[p] : &t.full_fwd[p], a.tw_lo, a.tw_hi, S[p], logB, 1);
+  const int tile = 1 << (S[p] + logC);
+  const size_t lds_bytes = (size_t)tile * 32 + ((size_t)1 << S[p]) / 2 * 32 + 32;
+  const uint32_t grid = (uint32_t)(((size_t)1 << log_n) >> (S[p] + logC));
+  hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid, 1), dim3(NTT_THREADS), lds_bytes, ctx->cur->stream, a);
+}
+
+// Witness map, first half (r1cs_to_qap.rs:144-148,161-162): ifft_in_place followed by coset_fft_in_place of the same vector
+// as ONE chain of 2*np passes: the inverse transform's 1/N is folded into the coset pre-scale table (g^j / N), the buffers
+// ping-pong data <-> scratch so that the result lands in `data` without the copy an odd pass count costs twice otherwise.
+template <class P>
+static bool ntt_ifft_coset_fft_t(zkp_ctx* ctx, int curve, uint32_t* data, int log_n) {
+  if (log_n < 2 || log_n > NTT_FULL_MAX_LOG) return false;
+  NttTables& t = get_tables<P>(ctx, curve, log_n);
+  uint32_t* pre = full_table<P>(ctx, t, &t.full_g_n, t.g_lo, t.g_hi_n, 0, 0, 0);
+  if (!pre) return false;
+  const size_t N = (size_t)1 << log_n;
+  uint32_t* scratch = ctx->cur->ntt_scratch.as<uint32_t>(N * 8);
+  int S[8], np;
+  ntt_plan(log_n, S, &np);
+  uint32_t* buf[2] = {data, scratch};
+  int cur = 0;
+  for (int half = 0; half < 2; half++) {
+    int logB = 0;
+    for (int p = 0; p < np; p++) {
+      NttPassArgs a{};
+      if (half == 1 && p == 0) a.pre_full = pre;                 // coset shift and 1/N in one product
+      launch_pass<P>(ctx, t, log_n, S, np, p, logB, half == 0, buf[cur], buf[cur ^ 1], a);
+      cur ^= 1;
+      logB += S[p];
+    }
+  }
+  ZKP_HIP(hipGetLastError());                                    // 2*np passes: back in `data`
+  return true;
+}
+
+// Witness map, second half (r1cs_to_qap.rs:150,164-169): h = coset_ifft((a*b - c) / Z(g)) with the pointwise step fused
+// into the first pass's load.  a, b, c: N elements each (destroyed).  Returns the buffer that holds h (a or b).
+template <class P>
+static uint32_t* ntt_qap_coset_ifft_t(zkp_ctx* ctx, int curve, uint32_t* a_, uint32_t* b_, uint32_t* c_, const uint32_t* zinv,
+                                      int log_n) {
+  if (log_n < 2 || log_n > NTT_FULL_MAX_LOG) return nullptr;
+  NttTables& t = get_tables<P>(ctx, curve, log_n);
+  uint32_t* post = full_table<P>(ctx, t, &t.full_gi, t.gi_lo, t.gi_hi, 0, 0, 0);
+  if (!post) return nullptr;
+  const size_t N = (size_t)1 << log_n;
+  uint32_t* scratch = ctx->cur->ntt_scratch.as<uint32_t>(N * 8);
+  int S[8], np;
+  ntt_plan(log_n, S, &np);
+  if (np < 2) return nullptr;
+  // pass 0: (a, b, c) -> scratch; then scratch <-> a; an odd pass count ends in b (free once pass 0 has read it)
+  const uint32_t* in = a_;
+  uint32_t* out = scratch;
+  int logB = 0;
+  for (int p = 0; p < np; p++) {
+    NttPassArgs a{};
+    if (p == 0) {
+      a.fuse_b = b_;
+      a.fuse_c = c_;
+      a.fuse_k = zinv;
+    }
+    if (p == np - 1) {
+      a.post_lo = t.gi_lo;
+      a.post_hi = t.gi_hi;
+      a.post_full = post;
+      if (out == scratch) out = b_;                              // odd np: do not finish in scratch
+    }
+    launch_pass<P>(ctx, t, log_n, S, np, p, logB, true, in, out, a);
+    in = out;
+    out = (out == scratch) ? a_ : scratch;
+    logB += S[p];
+  }
+  ZKP_HIP(hipGetLastError());
+  return const_cast<uint32_t*>(in);
+}
+
+bool ntt_ifft_coset_fft(zkp_ctx* ctx, int curve, uint32_t* data, int log_n) {
+  static const bool on = !(getenv("ZKP_NTT_FUSE") && atoi(getenv("ZKP_NTT_FUSE")) == 0);
+  if (!on) return false;
+  if (curve == ZKP_BN254) return ntt_ifft_coset_fft_t<Bn254Fr>(ctx, curve, data, log_n);
+  if (curve == ZKP_BLS12_381) return ntt_ifft_coset_fft_t<Bls381Fr>(ctx, curve, data, log_n);
+  throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+}
+uint32_t* ntt_qap_coset_ifft(zkp_ctx* ctx, int curve, uint32_t* a, uint32_t* b, uint32_t* c, const uint32_t* zinv, int log_n) {
+  static const bool on = !(getenv("ZKP_NTT_FUSE") && atoi(getenv("ZKP_NTT_FUSE")) == 0);
+  if (!on) return nullptr;
+  if (curve == ZKP_BN254) return ntt_qap_coset_ifft_t<Bn254Fr>(ctx, curve, a, b, c, zinv, log_n);
+  if (curve == ZKP_BLS12_381) return ntt_qap_coset_ifft_t<Bls381Fr>(ctx, curve, a, b, c, zinv, log_n);
+  throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
 }
 
 void ntt_run_batch(zkp_ctx* ctx, int curve, uint32_t* const* data, int count, int log_n, int op) {
