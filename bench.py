@@ -365,9 +365,9 @@ def main():
             a2 = 28.0 * e_g2 / (t_g2 * 1e-3) / 1e9 if t_g2 > 0 else 0.0     # 8 Karatsuba Fq2 products + 2 complex squarings
             valu_roof = {"unit": "1e9 Montgomery products/s",
                          "g1_accumulate": {"achieved": round(a1, 1), "ceiling": round(ceil_u, 1), "frac": round(a1 / ceil_u, 3),
-                                           "multiplier": "unsaturated 29/28-bit limbs (unsat.cuh)"},
+                                           "multiplier": "unsaturated 29/28-bit limbs (unsat_dev.hpp)"},
                          "g2_accumulate": {"achieved": round(a2, 1), "ceiling": round(ceil_s, 1), "frac": round(a2 / ceil_s, 3),
-                                           "multiplier": "saturated 32-bit limbs, product-scanning asm (field.cuh)"},
+                                           "multiplier": "saturated 32-bit limbs, product-scanning asm (field_dev.hpp)"},
                          "ntt": {"achieved": roofline_ntt["valu"]["gmulmod_per_s"], "ceiling": round(ceil_fr, 1),
                                  "frac": round(roofline_ntt["valu"]["gmulmod_per_s"] / ceil_fr, 3),
                                  "multiplier": "saturated Fr"},

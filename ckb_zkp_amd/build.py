@@ -29,7 +29,7 @@ UNITS = [("ntt.hip", "ntt.o", ["-DZKP_INLINE_MUL"]),
 for _c, _g in CONFIGS:
     _d = [f"-DZKP_CFG_CURVE={_c}", f"-DZKP_CFG_GROUP={_g}"]
     UNITS.append(("msm_group.hip", f"msm_group_c{_c}{_g}.o", _d + (["-DZKP_INLINE_MUL"] if (_c, _g) in ((0, 1), (0, 2), (1, 1)) else [])))
-    UNITS.append(("msm_acc.hip", f"msm_acc_c{_c}{_g}.o", _d + ["-DZKP_INLINE_MUL"] + ([] if os.environ.get("ZKP_BUILD_SATURATED_ACC") or _g != 1 else ["-DZKP_ACC_UNSAT"])))   # G1: unsaturated-limb accumulator (unsat.cuh)
+    UNITS.append(("msm_acc.hip", f"msm_acc_c{_c}{_g}.o", _d + ["-DZKP_INLINE_MUL"] + ([] if os.environ.get("ZKP_BUILD_SATURATED_ACC") or _g != 1 else ["-DZKP_ACC_UNSAT"])))   # G1: unsaturated-limb accumulator (unsat_dev.hpp)
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed",
          "-ffp-contract=off"]
 
@@ -51,7 +51,7 @@ def _newer(target: Path, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> Path:
     LIBDIR.mkdir(exist_ok=True)
     OBJDIR.mkdir(exist_ok=True)
-    headers = sorted(CSRC.glob("*.cuh")) + sorted(CSRC.glob("*.hpp")) + sorted(CSRC.glob("*.inc")) + \
+    headers = sorted(CSRC.glob("*.hpp")) + sorted(CSRC.glob("*.inc")) + \
         [ROOT.parent / "include" / "zkp_accel.h"]
     hipcc = _hipcc()
 

@@ -1,11 +1,11 @@
 // Measurement helpers behind bench.py's `valu_roof` entry ("mulmod/s vs a measured v_mad_u64_u32
 // microbenchmark peak"): the sustained rate of the library's own Montgomery multipliers — the saturated product-scanning
-// multiplier of field.cuh and the unsaturated-limb multiplier of unsat.cuh — with four independent dependency chains per
+// multiplier of field_dev.hpp and the unsaturated-limb multiplier of unsat_dev.hpp — with four independent dependency chains per
 // lane and every CU saturated.  This is the roof the bucket-accumulation and NTT kernels are bound by (integer VALU),
 // measured in the same process as the benchmark.  Not on any product path.
-#include "field.cuh"
+#include "field_dev.hpp"
 #include "internal.hpp"
-#include "unsat.cuh"
+#include "unsat_dev.hpp"
 
 namespace zkp {
 

@@ -12,7 +12,7 @@
 //   acc = inf, P = inf, acc == P (-> doubling), acc == -P (-> inf).
 // Affine identity is encoded as (0, 0), which is on neither curve (b != 0).
 #pragma once
-#include "field.cuh"
+#include "field_dev.hpp"
 
 namespace zkp {
 

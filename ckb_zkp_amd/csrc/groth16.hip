@@ -28,7 +28,7 @@
 #include <cstring>
 #include <vector>
 
-#include "field.cuh"
+#include "field_dev.hpp"
 #include "internal.hpp"
 #include "msm_vtbl.hpp"
 

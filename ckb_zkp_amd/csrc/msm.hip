@@ -32,7 +32,7 @@
 #include <mutex>
 #include <vector>
 
-#include "field.cuh"
+#include "field_dev.hpp"
 #include "internal.hpp"
 #include "msm_vtbl.hpp"
 

@@ -9,9 +9,9 @@
 // (reference call sites: /root/reference/groth16/src/prover.rs:187,190,220).
 #include <cstdlib>
 
-#include "ec.cuh"
+#include "ec_dev.hpp"
 #include "msm_vtbl.hpp"
-#include "unsat.cuh"
+#include "unsat_dev.hpp"
 
 namespace zkp {
 
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   const uint32_t d = task_dst[id];
   char* out = (d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * XYZZ<F>::BYTES : buckets + (size_t)d * XYZZ<F>::BYTES;
 #if ZKP_CFG_GROUP == 1 && defined(ZKP_ACC_UNSAT)
-  // G1: accumulate on unsaturated limbs (unsat.cuh); the window table and the buckets keep the saturated layout
+  // G1: accumulate on unsaturated limbs (unsat_dev.hpp); the window table and the buckets keep the saturated layout
   XYZZu<CfgFq> acc;
   acc.inf = true;
   for (uint32_t e = e0; e < e1; e++) {

@@ -1,7 +1,7 @@
 // Per-configuration MSM kernels (everything except the hot bucket-accumulate loop, which lives in
 // msm_acc.hip): table pre-computation, log-depth bucket reduction, point utilities, Groth16 assembly.
 // Compiled once per (curve, group): -DZKP_CFG_CURVE={0,1} -DZKP_CFG_GROUP={1,2}.  See msm.hip for the design.
-#include "ec.cuh"
+#include "ec_dev.hpp"
 #include "msm_vtbl.hpp"
 
 #ifndef ZKP_CFG_CURVE

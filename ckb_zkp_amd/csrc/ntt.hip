@@ -25,7 +25,7 @@
 #include <cstdlib>
 
 #include "ctx.hpp"
-#include "field.cuh"
+#include "field_dev.hpp"
 
 namespace zkp {
 

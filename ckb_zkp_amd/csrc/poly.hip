@@ -12,7 +12,7 @@
 // a short scan over chunk heads with z^CHUNK, then a per-chunk replay — 3 products per coefficient, log depth.
 #include <algorithm>
 
-#include "field.cuh"
+#include "field_dev.hpp"
 #include "internal.hpp"
 
 namespace zkp {

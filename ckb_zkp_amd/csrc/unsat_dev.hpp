@@ -1,6 +1,6 @@
 // Unsaturated-limb field arithmetic for the bucket-accumulation kernel (the hot loop of the whole prover).
 //
-// field.cuh multiplies on saturated 32-bit limbs: every 32x32 partial product is a v_mad_u64_u32 PLUS a v_addc_co_u32
+// field_dev.hpp multiplies on saturated 32-bit limbs: every 32x32 partial product is a v_mad_u64_u32 PLUS a v_addc_co_u32
 // that banks the carry, and every column of the product scan costs two v_mov.  Here a field element is L limbs of B bits
 // (9 x 29 for the 254-bit BN254 fields, 14 x 28 for the 381-bit BLS12-381 base field): a whole column (<= 2L partial
 // products < 2^(2B)) fits the 64-bit accumulator, so a partial product is ONE instruction and the column hand-over is a
@@ -12,8 +12,8 @@
 // X = x*2^(32N) (what the window tables and buckets hold in HBM) enters this form by a pure bit shift:
 // (X << (L*B - 32N)) = x * R' (mod p), < 32p (< 256p); it leaves by one product with 2^(32N) mod p.
 #pragma once
-#include "ec.cuh"
-#include "field.cuh"
+#include "ec_dev.hpp"
+#include "field_dev.hpp"
 
 namespace zkp {
 

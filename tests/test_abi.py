@@ -57,7 +57,7 @@ def test_desc_struct_layout_matches_header():
 def test_product_does_not_import_oracle():
     """The product path must not reach into oracle/ (it is the checker, never the thing shipped)."""
     for f in (ROOT / "ckb_zkp_amd").rglob("*"):
-        if f.suffix in (".py", ".hip", ".cuh", ".hpp", ".cpp", ".h") and f.is_file():
+        if f.suffix in (".py", ".hip", ".hpp", ".cpp", ".h", ".inc") and f.is_file():
             txt = f.read_text()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
             assert "libzkp_oracle" not in txt and "cpu_oracle" not in txt and "pyref" not in txt, f

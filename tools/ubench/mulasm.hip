@@ -1,10 +1,10 @@
 // Experiment: product-scanning Montgomery multiplication with an explicit (64-bit acc, overflow counter) pair and
-// v_mad_u64_u32 + v_addc_co_u32 MACs in inline asm, vs the C (CIOS) version in field.cuh.  Checks equality and speed.
+// v_mad_u64_u32 + v_addc_co_u32 MACs in inline asm, vs the C (CIOS) version in field_dev.hpp.  Checks equality and speed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #define ZKP_INLINE_MUL
-#include "field.cuh"
+#include "field_dev.hpp"
 using namespace zkp;
 
 #define MACV(acc, ovf, x, y) asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(ovf) : "v"(x), "v"(y) : "vcc")

@@ -6,7 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #define ZKP_INLINE_MUL
-#include "field.cuh"
+#include "field_dev.hpp"
 using namespace zkp;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)

@@ -1,17 +1,17 @@
 // Experiment: Montgomery multiplication on UNSATURATED limbs (9 x 29 bit for the 254-bit BN254 fields, 14 x 28 bit for
-// the 381-bit BLS12-381 base field) versus the saturated product-scanning multiplier of field.cuh.
+// the 381-bit BLS12-381 base field) versus the saturated product-scanning multiplier of field_dev.hpp.
 // With limbs < 2^29 a column of the product scan (<= 18 partial products < 2^58) fits a 64-bit accumulator, so each
 // 32x32 product is ONE v_mad_u64_u32 — no v_addc_co_u32 carry bank, no per-column register shuffling — at the price of
 // (L/N)^2 more products.  R' = 2^(L*B) leaves p/R' <= 2^-7, so results stay < 2p WITHOUT a final subtraction and
 // additions can be left unreduced.  Saturated Montgomery values X = x*2^256 map to this form by a 5-bit (11-bit) shift:
-// 32*X = x*2^261 (mod p).  Checks equality against field.cuh and measures throughput.
+// 32*X = x*2^261 (mod p).  Checks equality against field_dev.hpp and measures throughput.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 
 #include <vector>
 #define ZKP_INLINE_MUL
-#include "field.cuh"
+#include "field_dev.hpp"
 using namespace zkp;
 
 template <class P, int L_, int B_>
