@@ -371,7 +371,7 @@ def main():
                          "ntt": {"achieved": roofline_ntt["valu"]["gmulmod_per_s"], "ceiling": round(ceil_fr, 1),
                                  "frac": round(roofline_ntt["valu"]["gmulmod_per_s"] / ceil_fr, 3),
                                  "multiplier": "saturated Fr"},
-                         "note": "ceilings = zkp_bench_mulmod (four independent product chains per lane, 8 workgroups per CU), "
+                         "note": "ceilings = zkp_bench_mulmod (better of 2 and 4 independent product chains per lane, 8 workgroups per CU), "
                                  "measured in this process; the accumulate / NTT kernels are bound by this roof, not by HBM"}
         # (iv) with the witness on the HOST: each proof's assignment crosses PCIe in front of its proof (pinned buffer)
         try:

@@ -3,17 +3,18 @@
 // multiplier of field_dev.hpp and the unsaturated-limb multiplier of unsat_dev.hpp — with four independent dependency chains per
 // lane and every CU saturated.  This is the roof the bucket-accumulation and NTT kernels are bound by (integer VALU),
 // measured in the same process as the benchmark.  Not on any product path.
+#include <algorithm>
+
 #include "field_dev.hpp"
 #include "internal.hpp"
 #include "unsat_dev.hpp"
 
 namespace zkp {
 
-template <class P, int UNSAT>
+template <class P, int UNSAT, int CH>               // CH independent dependency chains per lane (the EC formulas offer 2-4)
 __global__ __launch_bounds__(256) void mulmod_rate_kernel(uint32_t* __restrict__ out, int iters) {
   using F = Fp<P>;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  constexpr int CH = 4;                            // independent dependency chains per lane (the EC formulas offer 2-4)
   F a[CH];
 #pragma unroll
   for (int k = 0; k < CH; k++) {
@@ -30,7 +31,9 @@ __global__ __launch_bounds__(256) void mulmod_rate_kernel(uint32_t* __restrict__
 #pragma unroll
       for (int k = 0; k < CH; k++) c[k] = U::mul(c[k], ua[k]);
     }
-    U s = U::add(U::add(c[0], c[1]), U::add(c[2], c[3]));
+    U s = c[0];
+#pragma unroll
+    for (int k = 1; k < CH; k++) s = U::add(s, c[k]);
 #pragma unroll
     for (int i = 0; i < P::N; i++) out[(size_t)t * P::N + i] = s.v[i];
   } else {
@@ -41,7 +44,10 @@ __global__ __launch_bounds__(256) void mulmod_rate_kernel(uint32_t* __restrict__
 #pragma unroll
       for (int k = 0; k < CH; k++) c[k] = c[k] * a[k];
     }
-    ((c[0] + c[1]) + (c[2] + c[3])).store(out + (size_t)t * P::N);
+    F s = c[0];
+#pragma unroll
+    for (int k = 1; k < CH; k++) s = s + c[k];
+    s.store(out + (size_t)t * P::N);
   }
 }
 
@@ -54,30 +60,42 @@ double bench_mulmod(zkp_ctx* ctx, int curve, int field, bool unsaturated) {
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   const int blocks = cus * 8, threads = 256, iters = 800;
   uint32_t* out = ctx->msm_misc.as<uint32_t>((size_t)blocks * threads * 12);
-  auto launch = [&] {
-    if (curve == ZKP_BN254 && field == 1) {
-      if (unsaturated) hipLaunchKernelGGL((mulmod_rate_kernel<Bn254Fq, 1>), dim3(blocks), dim3(threads), 0, st, out, iters);
-      else hipLaunchKernelGGL((mulmod_rate_kernel<Bn254Fq, 0>), dim3(blocks), dim3(threads), 0, st, out, iters);
-    } else if (curve == ZKP_BN254) {
-      ZKP_REQUIRE(!unsaturated, ZKP_ERR_BAD_ARG);
-      hipLaunchKernelGGL((mulmod_rate_kernel<Bn254Fr, 0>), dim3(blocks), dim3(threads), 0, st, out, iters);
-    } else if (field == 1) {
-      if (unsaturated) hipLaunchKernelGGL((mulmod_rate_kernel<Bls381Fq, 1>), dim3(blocks), dim3(threads), 0, st, out, iters);
-      else hipLaunchKernelGGL((mulmod_rate_kernel<Bls381Fq, 0>), dim3(blocks), dim3(threads), 0, st, out, iters);
-    } else {
-      ZKP_REQUIRE(!unsaturated, ZKP_ERR_BAD_ARG);
-      hipLaunchKernelGGL((mulmod_rate_kernel<Bls381Fr, 0>), dim3(blocks), dim3(threads), 0, st, out, iters);
-    }
-  };
-  launch();                                                        // warm-up (code load, clocks)
-  ZKP_HIP(hipEventRecord(ctx->ev2, st));
-  launch();
-  ZKP_HIP(hipEventRecord(ctx->ev3, st));
-  ZKP_HIP(hipEventSynchronize(ctx->ev3));
-  ZKP_HIP(hipGetLastError());
-  float ms = 0.f;
-  ZKP_HIP(hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3));
-  return (double)blocks * threads * iters * 4.0 / (ms * 1e-3) / 1e9;
+  // two variants (2 and 4 chains per lane): the 14-limb BLS12-381 operands spill with 4 chains, the 8/9-limb BN254 ones gain
+  // from them; the ceiling is the better of the two
+  double best = 0.0;
+  for (int ch : {2, 4}) {
+    auto launch = [&] {
+#define ZKP_RATE(PP, UU)                                                                                             \
+  do {                                                                                                               \
+    if (ch == 2) hipLaunchKernelGGL((mulmod_rate_kernel<PP, UU, 2>), dim3(blocks), dim3(threads), 0, st, out, iters); \
+    else hipLaunchKernelGGL((mulmod_rate_kernel<PP, UU, 4>), dim3(blocks), dim3(threads), 0, st, out, iters);         \
+  } while (0)
+      if (curve == ZKP_BN254 && field == 1) {
+        if (unsaturated) ZKP_RATE(Bn254Fq, 1);
+        else ZKP_RATE(Bn254Fq, 0);
+      } else if (curve == ZKP_BN254) {
+        ZKP_REQUIRE(!unsaturated, ZKP_ERR_BAD_ARG);
+        ZKP_RATE(Bn254Fr, 0);
+      } else if (field == 1) {
+        if (unsaturated) ZKP_RATE(Bls381Fq, 1);
+        else ZKP_RATE(Bls381Fq, 0);
+      } else {
+        ZKP_REQUIRE(!unsaturated, ZKP_ERR_BAD_ARG);
+        ZKP_RATE(Bls381Fr, 0);
+      }
+#undef ZKP_RATE
+    };
+    launch();                                                        // warm-up (code load, clocks)
+    ZKP_HIP(hipEventRecord(ctx->ev2, st));
+    launch();
+    ZKP_HIP(hipEventRecord(ctx->ev3, st));
+    ZKP_HIP(hipEventSynchronize(ctx->ev3));
+    ZKP_HIP(hipGetLastError());
+    float ms = 0.f;
+    ZKP_HIP(hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3));
+    best = std::max(best, (double)blocks * threads * iters * (double)ch / (ms * 1e-3) / 1e9);
+  }
+  return best;
 }
 
 }  // namespace zkp
