@@ -272,33 +272,24 @@ static void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out
 // ------------------------------------------------------------------------------------------- K6 bucket sort
 // Hand-written two-level counting sort of the (bucket, point) entries — it only has to GROUP entries by bucket
 // (order inside a bucket is irrelevant: EC addition commutes), which is cheaper than a general radix sort:
-//   level 1  bins = top 10-13 bits of the bucket id.  ONE kernel per tile of >= 2048 scalars: LDS histogram of the tile's
-//            digits, LDS scan, then the tile's entries — grouped by bin — go to the tile's own region of `kv`
-//            (sort_tile_kernel; round 1 used three launches and a global (bin x tile) offset scan).
-//   level 2  one workgroup per bin (~16 K entries, <= 1024 distinct low keys): gathers the bin's run from every tile,
-//            LDS histogram, LDS scan — which directly yields start/end of every bucket of the bin — and an LDS-atomic
-//            scatter of the values.
+//   level 1  bins = top <= 10 bits of the bucket id.  Per 8192-entry tile: LDS histogram (one pass over the
+//            keys), global exclusive scan of the (bin, tile) counts, then a scatter pass in which an LDS atomic
+//            hands every entry its slot inside its bin's region.
+//   level 2  one workgroup per bin (~16 K entries, <= 1024 distinct low keys): LDS histogram, LDS scan — which
+//            directly yields start/end of every bucket of the bin — and an LDS-atomic scatter of the values.
 // LDS atomics resolve same-bucket conflicts inside a wave in hardware; no global atomics on the data path.
 constexpr int SORT_H1_MAX = 13;        // level-1 bins <= 8192 (static LDS histogram, 32 KiB)
 constexpr uint32_t SORT_BIN_TARGET = 16384;   // entries per level-1 bin the level-2 kernel stages in LDS
 constexpr int SORT_L_MAX = 13;         // level-2 keys per bin <= 8192 (dynamic LDS)
 constexpr int SORT_SCALARS = 2048;    // default; larger MSMs use larger tiles (runtime `tile`) to keep the tile count ~1200
 constexpr int SORT_SCALARS_UNUSED_ = 0;     // scalars per workgroup in the level-1 passes (8 per lane): larger tiles = smaller (bin x tile) count matrix and longer contiguous runs per bin in the scatter (512 -> 2048: +2 % proofs/s)
-// Level 1, ONE kernel per tile (round 2; replaces histogram kernel + global count scan + scatter kernel): the tile counts
-// its digits per bin in LDS, scans the counts in LDS, and scatters its entries — grouped by bin — into its OWN contiguous
-// region of `kv` (tile t owns kv[t * cap, (t + 1) * cap), cap = tile * W).  The scalars are read twice (the second time from
-// L2), the digits are recomputed instead of stored.  Because a tile writes into a region of a few hundred KiB that it
-// fills completely during its lifetime, the 8-byte stores are merged in L2 instead of reaching HBM as partial lines (the
-// global-offset scatter of round 1 wrote 386 MiB for 125 MiB of entries).  tile_off[t][b] = start of bin b inside tile t's
-// region; bin_total[b] accumulates the bin sizes for level 2.
 template <class FrP>
-__global__ __launch_bounds__(256) void sort_tile_kernel(const uint32_t* __restrict__ scalars, size_t n, size_t offset,
-                                                        const uint8_t* __restrict__ inf, int montgomery, size_t ntab,
-                                                        int c, int W, uint32_t nb, int L, uint32_t nbins1, uint32_t tile,
-                                                        int var, uint32_t* __restrict__ tile_off,
-                                                        uint32_t* __restrict__ bin_total, uint64_t* __restrict__ kv) {
+__global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restrict__ scalars, size_t n, size_t offset,
+                                                        const uint8_t* __restrict__ inf, int montgomery, int c, int W,
+                                                        uint32_t nb, int L, uint32_t nbins1,
+                                                        uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t tile,
+                                                        int var) {
   __shared__ uint32_t cnt[(1 << SORT_H1_MAX) + 1];
-  __shared__ uint32_t part[256];
   for (uint32_t i = threadIdx.x; i <= nbins1; i += 256) cnt[i] = 0;
   __syncthreads();
   for (uint32_t rep = 0; rep < tile / 256; rep++) {
@@ -313,39 +304,19 @@ __global__ __launch_bounds__(256) void sort_tile_kernel(const uint32_t* __restri
     }
   }
   __syncthreads();
-  // exclusive scan of the nbins1 counters: `per` consecutive counters per thread + Hillis-Steele over the partials
-  {
-    const uint32_t per = (nbins1 + 255) / 256;
-    uint32_t acc = 0;
-    for (uint32_t k = 0; k < per; k++) {
-      uint32_t idx = threadIdx.x * per + k;
-      if (idx < nbins1) acc += cnt[idx];
-    }
-    part[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-      uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-      __syncthreads();
-      part[threadIdx.x] += add;
-      __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - acc;
-    uint32_t* row = tile_off + (size_t)blockIdx.x * (nbins1 + 1);
-    for (uint32_t k = 0; k < per; k++) {
-      uint32_t idx = threadIdx.x * per + k;
-      if (idx < nbins1) {
-        uint32_t v = cnt[idx];
-        row[idx] = run;
-        if (v) atomicAdd(&bin_total[idx], v);
-        cnt[idx] = run;                                   // cursor
-        run += v;
-      }
-    }
-    if (threadIdx.x == 255) row[nbins1] = part[255];       // entries of this tile
-  }
+  for (uint32_t i = threadIdx.x; i < nbins1; i += 256) hist[(size_t)i * nblocks + blockIdx.x] = cnt[i];
+}
+template <class FrP>
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __restrict__ scalars, size_t n,
+                                                           size_t offset, const uint8_t* __restrict__ inf,
+                                                           int montgomery, size_t ntab, int c, int W, uint32_t nb,
+                                                           int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
+                                                           uint32_t nblocks, uint32_t tile,
+                                                           uint64_t* __restrict__ kv, int var) {   // (low key << 32) | val
+  __shared__ uint32_t cur[(1 << SORT_H1_MAX) + 1];
+  for (uint32_t i = threadIdx.x; i < nbins1; i += 256) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
   __syncthreads();
   const uint32_t lmask = (1u << L) - 1;
-  uint64_t* mine = kv + (size_t)blockIdx.x * ((size_t)tile * W);
   for (uint32_t rep = 0; rep < tile / 256; rep++) {
     size_t i = (size_t)blockIdx.x * tile + rep * 256 + threadIdx.x;
     if (i < n && !(inf && inf[offset + i])) {
@@ -355,20 +326,27 @@ __global__ __launch_bounds__(256) void sort_tile_kernel(const uint32_t* __restri
         it.next(w, c, nb, key, neg);
         if (key < nb) {                                // zero digits are dropped here
           const uint32_t fk = var ? ((uint32_t)w << (c - 1)) | key : key;     // variable-base: one bucket set per window
-          uint32_t pos = atomicAdd(&cnt[fk >> L], 1u);
+          uint32_t pos = atomicAdd(&cur[fk >> L], 1u);
           uint32_t val = (uint32_t)((var ? (size_t)0 : (size_t)w * ntab) + offset + i) | (neg << 31);
-          mine[pos] = ((uint64_t)(fk & lmask) << 32) | val;
+          kv[pos] = ((uint64_t)(fk & lmask) << 32) | val;   // one 8-B store per entry
         }
       }
     }
   }
 }
+// (an LDS-staged variant of the level-1 scatter — entries grouped by bin in LDS, then written in coalesced runs — lost 4 %
+//  end to end: 92 KiB of LDS left one workgroup per CU; removed)
+// (round 2: level 1 as ONE kernel per tile — LDS histogram, LDS scan, entries scattered into the tile's own contiguous region
+//  of kv so that the 8-byte stores merge in L2, level 2 gathering one run per tile — was built, bit-exact, and measured:
+//  the level-1 kernel alone took 0.26 ms, as much as histogram + count scan + scatter together before (the passes are bound
+//  by the LDS atomics on ~1000 random bins and the digit extraction, not by the store amplification), and level 2 got slower
+//  reading 1200 short runs per bin: A-query MSM 2.66 vs 2.37 ms, 106-108 vs 113 proofs/s.  Reverted; commit 'Level-1 bucket
+//  sort as ONE kernel per tile' holds the code.)
 constexpr uint32_t SORT_BIN_THREADS = 1024;
 constexpr uint32_t SORT_BIN_STAGE = 20480;      // values staged in LDS (80 KiB) so the output is written fully coalesced
 __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64_t* __restrict__ kv,
-                                                                    const uint32_t* __restrict__ tile_off,
-                                                                    const uint32_t* __restrict__ bin_base,
-                                                                    uint32_t nblocks, size_t cap, uint32_t nbins1, int L,
+                                                                    const uint32_t* __restrict__ offs,
+                                                                    uint32_t nblocks, int L,
                                                                     uint32_t* __restrict__ vout,
                                                                     uint32_t* __restrict__ start,
                                                                     uint32_t* __restrict__ end) {
@@ -378,18 +356,11 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
   uint32_t* cnt = sm;
   uint32_t* stage = sm + nk;
   const uint32_t b = blockIdx.x, T = SORT_BIN_THREADS, t = threadIdx.x;
-  const uint32_t lo = bin_base[b], hi = bin_base[b + 1];
+  const uint32_t lo = offs[(size_t)b * nblocks], hi = offs[(size_t)(b + 1) * nblocks];
   const bool staged = hi - lo <= SORT_BIN_STAGE;       // block-uniform
-  const uint32_t wave = t >> 6, lane = t & 63, nwaves = T >> 6;
   for (uint32_t i = t; i < nk; i += T) cnt[i] = 0;
   __syncthreads();
-  // the bin's entries are one run per tile (level 1): a wave per tile, lanes over the run
-  for (uint32_t tl = wave; tl < nblocks; tl += nwaves) {
-    const uint32_t* row = tile_off + (size_t)tl * (nbins1 + 1);
-    const uint32_t s = row[b], e = row[b + 1];
-    const uint64_t* src = kv + (size_t)tl * cap;
-    for (uint32_t i = s + lane; i < e; i += 64) atomicAdd(&cnt[(uint32_t)(src[i] >> 32)], 1u);
-  }
+  for (uint32_t i = lo + t; i < hi; i += T) atomicAdd(&cnt[(uint32_t)(kv[i] >> 32)], 1u);
   __syncthreads();
   // exclusive scan of the nk counters: `per` consecutive counters per thread + Hillis-Steele over the partials
   {
@@ -420,16 +391,11 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
     }
   }
   __syncthreads();
-  for (uint32_t tl = wave; tl < nblocks; tl += nwaves) {
-    const uint32_t* row = tile_off + (size_t)tl * (nbins1 + 1);
-    const uint32_t s = row[b], e = row[b + 1];
-    const uint64_t* src = kv + (size_t)tl * cap;
-    for (uint32_t i = s + lane; i < e; i += 64) {
-      const uint64_t x = src[i];
-      uint32_t pos = atomicAdd(&cnt[(uint32_t)(x >> 32)], 1u);
-      if (staged) stage[pos] = (uint32_t)x;
-      else vout[lo + pos] = (uint32_t)x;                // oversized bin (skewed scalars): direct scatter
-    }
+  for (uint32_t i = lo + t; i < hi; i += T) {
+    const uint64_t x = kv[i];
+    uint32_t pos = atomicAdd(&cnt[(uint32_t)(x >> 32)], 1u);
+    if (staged) stage[pos] = (uint32_t)x;
+    else vout[lo + pos] = (uint32_t)x;                  // oversized bin (skewed scalars): direct scatter
   }
   if (staged) {
     __syncthreads();
@@ -595,6 +561,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     const size_t E = n * (size_t)W;
     ZKP_REQUIRE(E < 2147483000ull, ZKP_ERR_BAD_ARG);
     uint32_t* vals = sw.vals.as<uint32_t>(E);                        // values grouped by bucket (level-2 output)
+    uint64_t* kv = sw.keys2.as<uint64_t>(E);                         // level-1 output: (low key, val) pairs
     const uint32_t* sc = reinterpret_cast<const uint32_t*>(scalars_dev);
     const int mont = montgomery ? 1 : 0;
     // K6: group entries by bucket (two-level counting sort); sorted values land back in `vals`
@@ -611,38 +578,38 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     uint32_t tile = SORT_SCALARS;
     while ((n + tile - 1) / tile > 1536) tile += 256;
     const uint32_t nblocks = (uint32_t)((n + tile - 1) / tile);
-    // level-1 bookkeeping: tile_off[nblocks][nbins1 + 1], bin_total[nbins1 + 1] -> bin_base (exclusive scan; [nbins1] = entries)
-    const size_t cap = (size_t)tile * W;                               // entries a tile can emit = its region of kv
-    const size_t toff_n = (size_t)nblocks * (nbins1 + 1);
-    uint32_t* tile_off = sw.sort_tmp.as<uint32_t>(toff_n + 2 * ((size_t)nbins1 + 2));
-    uint32_t* bin_total = tile_off + toff_n;
-    uint32_t* bin_base = bin_total + (nbins1 + 2);
-    uint64_t* kv = sw.keys2.as<uint64_t>((size_t)nblocks * cap);        // level-1 output: (low key, val) pairs, tile-major
+    const size_t hist_n = (size_t)nbins1 * nblocks + 1;                // + total (== number of non-zero digits)
+    uint32_t* hist = sw.sort_tmp.as<uint32_t>(2 * hist_n);
+    uint32_t* offs = hist + hist_n;
     uint32_t* start = sw.offsets.as<uint32_t>(2 * (size_t)nb);
     uint32_t* end = start + nb;
     const uint8_t* scan_inf = be->sort_inf ? be->sort_inf : be->inf;     // see BasesEntry::sort_inf
     if (reuse) ZKP_HIP(hipStreamWaitEvent(st, sw.sorted, 0));
-    else ZKP_HIP(hipMemsetAsync(bin_total, 0, ((size_t)nbins1 + 2) * 4, st));
-    const bool timed_scan = ms_scan && ctx->profiling && !reuse;      // K5 "scalar scan": the level-1 kernel (digits + grouping by bin)
+    else ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
+    const bool timed_scan = ms_scan && ctx->profiling && !reuse;      // K5 "scalar scan": histogram pass + count scan + scatter pass
     if (timed_scan) ZKP_HIP(hipEventRecord(ctx->ev2, st));
     if (reuse) {
     } else if (be->curve == ZKP_BN254) {
-      hipLaunchKernelGGL(sort_tile_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, be->n,
-                         c, W, nb_w, LB, nbins1, tile, var, tile_off, bin_total, kv);
+      hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
+                         nb_w, LB, nbins1, hist, nblocks, tile, var);
+      exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
+      hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
+                         be->n, c, W, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
     } else {
-      hipLaunchKernelGGL(sort_tile_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, be->n,
-                         c, W, nb_w, LB, nbins1, tile, var, tile_off, bin_total, kv);
+      hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
+                         nb_w, LB, nbins1, hist, nblocks, tile, var);
+      exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
+      hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
+                         be->n, c, W, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
     }
     if (timed_scan) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
       ZKP_HIP(hipEventSynchronize(ctx->ev3));
       ZKP_HIP(hipEventElapsedTime(ms_scan, ctx->ev2, ctx->ev3));
     }
-    if (!reuse) {
-      exclusive_scan_u32(st, bin_total, bin_base, (size_t)nbins1 + 1, ws.scan_tmp);
+    if (!reuse)
       hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(SORT_BIN_THREADS), ((size_t)4 << LB) + 4 * (size_t)SORT_BIN_STAGE, st,
-                         kv, tile_off, bin_base, nblocks, cap, nbins1, LB, vals, start, end);
-    }
+                         kv, offs, nblocks, LB, vals, start, end);
     uint32_t* const sorted_vals = vals;
     // K7 scheduling: buckets -> tasks (<= CAP entries), ordered by length
     const uint32_t max_tasks = nb + (uint32_t)(E / MSM_TASK_CAP) + 1;
@@ -685,7 +652,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       *n_entries = E;                                   // nominal: scalars x windows
       if (ctx->profiling) {                             // exact: what the scan emitted (identity bases / zero digits dropped)
         uint32_t emitted = 0;
-        ZKP_HIP(hipMemcpyAsync(&emitted, bin_base + nbins1, 4, hipMemcpyDeviceToHost, st));
+        ZKP_HIP(hipMemcpyAsync(&emitted, offs + hist_n - 1, 4, hipMemcpyDeviceToHost, st));
         ZKP_HIP(hipStreamSynchronize(st));
         *n_entries = emitted;
       }
