@@ -29,7 +29,12 @@ UNITS = [("ntt.hip", "ntt.o", ["-DZKP_INLINE_MUL"]),
 for _c, _g in CONFIGS:
     _d = [f"-DZKP_CFG_CURVE={_c}", f"-DZKP_CFG_GROUP={_g}"]
     UNITS.append(("msm_group.hip", f"msm_group_c{_c}{_g}.o", _d + (["-DZKP_INLINE_MUL"] if (_c, _g) in ((0, 1), (0, 2), (1, 1)) else [])))
-    UNITS.append(("msm_acc.hip", f"msm_acc_c{_c}{_g}.o", _d + ["-DZKP_INLINE_MUL"] + ([] if os.environ.get("ZKP_BUILD_SATURATED_ACC") or _g != 1 else ["-DZKP_ACC_UNSAT"])))   # G1: unsaturated-limb accumulator (unsat_dev.hpp)
+    _acc = []
+    if _g == 1 and not os.environ.get("ZKP_BUILD_SATURATED_ACC"):
+        _acc = ["-DZKP_ACC_UNSAT"]                    # G1: unsaturated-limb accumulator (unsat_dev.hpp)
+    if (_c, _g) == (0, 2) and not os.environ.get("ZKP_BUILD_SATURATED_G2"):
+        _acc = ["-DZKP_ACC_UNSAT_G2"]                 # BN254 G2: Fq2 on unsaturated limbs, lazily reduced schoolbook products
+    UNITS.append(("msm_acc.hip", f"msm_acc_c{_c}{_g}.o", _d + ["-DZKP_INLINE_MUL"] + _acc))
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed",
          "-ffp-contract=off"]
 

@@ -70,6 +70,31 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   }
   if (acc.inf) XYZZ<F>::inf().store(out);
   else XYZZ<F>{acc.x.f.to_sat(), acc.y.f.to_sat(), acc.zz.f.to_sat(), acc.zzz.f.to_sat()}.store(out);
+#elif ZKP_CFG_GROUP == 2 && defined(ZKP_ACC_UNSAT_G2)
+  // G2 (BN254): Fq2 accumulator on unsaturated limbs, schoolbook products with lazily reduced sums (unsat_dev.hpp)
+  XYZZu2<CfgFq> acc;
+  acc.inf = true;
+  for (uint32_t e = e0; e < e1; e++) {
+    uint32_t v = vals[e];
+    Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
+    if (p.is_inf()) continue;
+    if (v >> 31) p.y = p.y.neg();
+    using U = Fu<CfgFq>;
+    if (!xyzz_madd_u2<CfgFq>(acc, U::from_sat(p.x.c0), U::from_sat(p.x.c1), U::from_sat(p.y.c0), U::from_sat(p.y.c1))) {
+      redo[1 + atomicAdd(redo, 1u)] = id;
+      return;
+    }
+  }
+  if (acc.inf) {
+    XYZZ<F>::inf().store(out);
+  } else {
+    XYZZ<F> r;
+    r.x = {acc.x.c0.f.to_sat(), acc.x.c1.f.to_sat()};
+    r.y = {acc.y.c0.f.to_sat(), acc.y.c1.f.to_sat()};
+    r.zz = {acc.zz.c0.f.to_sat(), acc.zz.c1.f.to_sat()};
+    r.zzz = {acc.zzz.c0.f.to_sat(), acc.zzz.c1.f.to_sat()};
+    r.store(out);
+  }
 #else
   XYZZ<F> acc = XYZZ<F>::inf();
   // (a software-pipelined gather of entry e+1 was tried twice — G1: +20 VGPRs -> spills; G2 after the redo split:

@@ -221,6 +221,63 @@ struct Fu {
     r.v[L - 1] = (uint32_t)acc;
     return r;
   }
+  // a*b + c*d + e*f + g*h with ONE reduction (an Fq2 combination such as R (Q - X3) - Y1 PPP): a column holds <= 4L products
+  // < 2^(2B) plus <= L reduction products: 45 * 2^58 < 2^64 for L = 9, B = 29.  Value < 2p when the four K-products sum
+  // to <= MULCAP.  (Only instantiated for the 254-bit fields.)
+  ZKP_DEV static Fu mul_add4(const Fu& a, const Fu& b, const Fu& c, const Fu& d, const Fu& e, const Fu& f, const Fu& g,
+                             const Fu& h) {
+    static_assert(5 * L * ((uint64_t)1 << (2 * B - 32)) < ((uint64_t)1 << 32), "column accumulator would overflow");
+    uint32_t m[L];
+    Fu r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; k++) {
+#pragma unroll
+      for (int i = 0; i < L; i++) {
+        int j = k - i;
+        if (j >= 0 && j < L) {
+          acc += (uint64_t)a.v[i] * b.v[j];
+          acc += (uint64_t)c.v[i] * d.v[j];
+          acc += (uint64_t)e.v[i] * f.v[j];
+          acc += (uint64_t)g.v[i] * h.v[j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < L; i++) {
+        int j = k - i;
+        if (j >= 0 && j < L && i < k) acc += (uint64_t)m[i] * mp_limb(1, j);
+      }
+      if (k < L) {
+        m[k] = ((uint32_t)acc * ninv()) & MASK;
+        acc += (uint64_t)m[k] * mp_limb(1, 0);
+      } else {
+        r.v[k - L] = (uint32_t)acc & MASK;
+      }
+      acc >>= B;
+    }
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
+  }
+  // a >= M*p ? a - M*p : a   (normalised limbs in, normalised limbs out): halves a value bound without a product
+  template <int M>
+  ZKP_DEV static Fu csub(const Fu& a) {
+    Fu r;
+    int32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int32_t t = (int32_t)a.v[i] - (int32_t)mp_limb(M, i) + carry;
+      if (i < L - 1) {
+        r.v[i] = (uint32_t)t & MASK;
+        carry = t >> B;
+      } else {
+        r.v[i] = (uint32_t)t;
+      }
+    }
+    const bool neg = (int32_t)r.v[L - 1] < 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.v[i] = neg ? a.v[i] : r.v[i];
+    return r;
+  }
   // (a dedicated squaring — cross terms once against a doubled operand, 45 instead of 81 products — measured no
   //  difference in the accumulate kernel and was dropped)
   ZKP_DEV Fu sqr() const { return mul(*this, *this); }
@@ -388,6 +445,90 @@ ZKP_DEV bool xyzz_madd_u(XYZZu<P>& acc, const Fu<P>& ux_, const Fu<P>& uy_) {
   acc.zzz = ub_mul(acc.zzz, ppp);
   acc.x = x3;
   acc.y = y3;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fq2 = Fq[u]/(u^2 + 1) on the bounded types, for the BN254 G2 accumulator (round 2).  Products are SCHOOLBOOK with one
+// lazily reduced sum of two products per component (c0 = a0 b0 + a1 (Kp - b1), c1 = a0 b1 + a1 b0: 2 * (2 * 81 + 81) = 486
+// v_mad_u64_u32 — the same multiplier work as three separate products, but no additions of unreduced operands, so the
+// 2^-7 slack of the 254-bit field suffices: KA*KB + KA*KB <= 128 holds for every product of the mixed addition once x3 is
+// brought below 4p by one conditional subtraction).
+template <class P, int K>
+struct UB2 {
+  UB<P, K> c0, c1;
+};
+template <class P, int KA, int KB>
+ZKP_DEV UB2<P, 2> ub2_mul(const UB2<P, KA>& a, const UB2<P, KB>& b) {
+  return {ub_mul_add(a.c0, b.c0, a.c1, ub_neg<KB>(b.c1)), ub_mul_add(a.c0, b.c1, a.c1, b.c0)};
+}
+template <class P, int KA>
+ZKP_DEV UB2<P, 4> ub2_sqr(const UB2<P, KA>& a) {
+  const UB<P, 2> c0 = ub_mul_add(a.c0, a.c0, a.c1, ub_neg<KA>(a.c1));
+  const UB<P, 4> c1 = ub_dbl(ub_mul(a.c0, a.c1));
+  return {UB<P, 4>{c0.f}, c1};
+}
+template <class P, int KA, int KB>
+ZKP_DEV UB2<P, KA + KB> ub2_sub(const UB2<P, KA>& a, const UB2<P, KB>& b) {
+  return {ub_sub(a.c0, b.c0), ub_sub(a.c1, b.c1)};
+}
+template <class P, int KA>
+ZKP_DEV UB2<P, 2 * KA> ub2_dbl(const UB2<P, KA>& a) {
+  return {ub_dbl(a.c0), ub_dbl(a.c1)};
+}
+
+template <class P>
+struct XYZZu2 {
+  UB2<P, 4> x;
+  UB2<P, 2> y, zz, zzz;
+  bool inf;
+};
+
+// acc += P for G2 (Fq2 coordinates); (ux, uy) = from_sat of the gathered affine point's components.  Same contract as
+// xyzz_madd_u: returns false WITHOUT touching acc when P may equal +-acc.
+template <class P>
+ZKP_DEV bool xyzz_madd_u2(XYZZu2<P>& acc, const Fu<P>& ux0, const Fu<P>& ux1, const Fu<P>& uy0, const Fu<P>& uy1) {
+  using U = Fu<P>;
+  constexpr int KIN = 1 << U::SHIFT;                       // 32: the integers 2^SHIFT * X, < 32p
+  static_assert(2 * KIN * 2 <= UBLimits<P>::MULCAP, "table operand times a reduced Fq2 element exceeds the slack");
+  const UB2<P, KIN> ux{{ux0}, {ux1}}, uy{{uy0}, {uy1}};
+  const UB<P, 1> one{U::one()};
+  if (acc.inf) {
+    acc.x = {UB<P, 4>{ub_mul(ux.c0, one).f}, UB<P, 4>{ub_mul(ux.c1, one).f}};
+    acc.y = {ub_mul(uy.c0, one), ub_mul(uy.c1, one)};
+    acc.zz = {UB<P, 2>{one.f}, UB<P, 2>{U::zero()}};
+    acc.zzz = acc.zz;
+    acc.inf = false;
+    return true;
+  }
+  const auto u2 = ub2_mul(ux, acc.zz);                      // < 2p          (32*2 + 32*2 = 128)
+  const auto s2 = ub2_mul(uy, acc.zzz);
+  const auto pd = ub2_sub(u2, acc.x);                       // (0, 6p)
+  const auto rd = ub2_sub(s2, acc.y);                       // (0, 4p)
+  if (pd.c0.f.template maybe_multiple_of_p<6>() && pd.c1.f.template maybe_multiple_of_p<6>()) return false;
+  const UB2<P, 2> pp = [&] {                                // pd^2: 36 + 36 = 72
+    const UB<P, 2> c0 = ub_mul_add(pd.c0, pd.c0, pd.c1, ub_neg<6>(pd.c1));
+    const UB<P, 2> c1 = ub_mul_add(pd.c0, pd.c1, pd.c0, pd.c1);        // 2 pd0 pd1 as one lazily reduced sum: < 2p
+    return UB2<P, 2>{c0, c1};
+  }();
+  const auto ppp = ub2_mul(pd, pp);                         // 6*2 + 6*2 = 24
+  const auto q = ub2_mul(acc.x, pp);                        // 4*2 + 4*2 = 16
+  const UB2<P, 2> rr = [&] {                                // rd^2: 16 + 16 = 32
+    const UB<P, 2> c0 = ub_mul_add(rd.c0, rd.c0, rd.c1, ub_neg<4>(rd.c1));
+    const UB<P, 2> c1 = ub_mul_add(rd.c0, rd.c1, rd.c0, rd.c1);
+    return UB2<P, 2>{c0, c1};
+  }();
+  const auto x3w = ub2_sub(ub2_sub(rr, ppp), ub2_dbl(q));   // (0, 8p)
+  const UB2<P, 4> x3 = {UB<P, 4>{U::template csub<4>(x3w.c0.f)}, UB<P, 4>{U::template csub<4>(x3w.c1.f)}};   // < 4p
+  const auto t = ub2_sub(q, x3);                            // (0, 6p)
+  // y3 = rd * t - y * ppp, each component ONE lazily reduced sum of four products: 4*6 + 4*6 + 2*2 + 2*2 = 56
+  static_assert(4 * 6 * 2 + 2 * 2 * 2 <= UBLimits<P>::MULCAP, "y3 exceeds the slack");
+  const UB<P, 2> y30{U::mul_add4(rd.c0.f, t.c0.f, rd.c1.f, ub_neg<6>(t.c1).f, acc.y.c0.f, ub_neg<2>(ppp.c0).f, acc.y.c1.f, ppp.c1.f)};
+  const UB<P, 2> y31{U::mul_add4(rd.c0.f, t.c1.f, rd.c1.f, t.c0.f, acc.y.c0.f, ub_neg<2>(ppp.c1).f, acc.y.c1.f, ub_neg<2>(ppp.c0).f)};
+  acc.zz = ub2_mul(acc.zz, pp);                             // 2*2 + 2*2 = 8
+  acc.zzz = ub2_mul(acc.zzz, ppp);
+  acc.x = x3;
+  acc.y = {y30, y31};
   return true;
 }
 
