@@ -541,7 +541,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
   const bool reuse = sort_src >= 0 && sort_src != ws_idx;
   MsmWorkspace& sw = reuse ? ctx->cur->ws[sort_src] : ws;          // owner of the sorted entries and the task schedule
   hipStream_t st = ws_idx == 0 ? ctx->cur->stream : ws.stream;
-  const size_t XB = vt->xyzz_bytes;
+  const size_t XB = vt->bucket_bytes;                                // buckets, partial sums, pyramid levels
   const size_t jac_words = 3 * (size_t)vt->fN;
   uint32_t* out_jac = ws.out.as<uint32_t>(64 * 4);
   if (ms_accumulate) *ms_accumulate = 0.f;

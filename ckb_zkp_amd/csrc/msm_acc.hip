@@ -9,6 +9,7 @@
 // (reference call sites: /root/reference/groth16/src/prover.rs:187,190,220).
 #include <cstdlib>
 
+#include "bucket_dev.hpp"
 #include "ec_dev.hpp"
 #include "msm_vtbl.hpp"
 #include "unsat_dev.hpp"
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   const uint32_t id = order[t];
   const uint32_t e0 = task_start[id], e1 = e0 + task_len[id];
   const uint32_t d = task_dst[id];
-  char* out = (d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * XYZZ<F>::BYTES : buckets + (size_t)d * XYZZ<F>::BYTES;
+  // buckets and partial sums are BkPoint<F> (unsaturated layout): the accumulator is stored as it stands
+  char* out = (d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * BkPoint<F>::BYTES : buckets + (size_t)d * BkPoint<F>::BYTES;
 #if ZKP_CFG_GROUP == 1 && defined(ZKP_ACC_UNSAT)
   // G1: accumulate on unsaturated limbs (unsat_dev.hpp); the window table and the buckets keep the saturated layout
   XYZZu<CfgFq> acc;
@@ -68,8 +70,9 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
       return;
     }
   }
-  if (acc.inf) XYZZ<F>::inf().store(out);
-  else XYZZ<F>{acc.x.f.to_sat(), acc.y.f.to_sat(), acc.zz.f.to_sat(), acc.zzz.f.to_sat()}.store(out);
+  BkPoint<F> r;
+  r.v = acc;
+  r.store(out);
 #elif ZKP_CFG_GROUP == 2 && defined(ZKP_ACC_UNSAT_G2)
   // G2 (BN254): Fq2 accumulator on unsaturated limbs, schoolbook products with lazily reduced sums (unsat_dev.hpp)
   XYZZu2<CfgFq> acc;
@@ -85,16 +88,9 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
       return;
     }
   }
-  if (acc.inf) {
-    XYZZ<F>::inf().store(out);
-  } else {
-    XYZZ<F> r;
-    r.x = {acc.x.c0.f.to_sat(), acc.x.c1.f.to_sat()};
-    r.y = {acc.y.c0.f.to_sat(), acc.y.c1.f.to_sat()};
-    r.zz = {acc.zz.c0.f.to_sat(), acc.zz.c1.f.to_sat()};
-    r.zzz = {acc.zzz.c0.f.to_sat(), acc.zzz.c1.f.to_sat()};
-    r.store(out);
-  }
+  BkPoint<F> r;
+  r.v = acc;
+  r.store(out);
 #else
   XYZZ<F> acc = XYZZ<F>::inf();
   // (a software-pipelined gather of entry e+1 was tried twice — G1: +20 VGPRs -> spills; G2 after the redo split:
@@ -108,7 +104,7 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
       return;
     }
   }
-  acc.store(out);
+  BkPoint<F>::from_sat(acc).store(out);
 #endif
 }
 // exact (saturated, all exceptional cases) accumulation of the tasks listed in redo[1 .. redo[0]]
@@ -131,7 +127,8 @@ __global__ __launch_bounds__(64) void accumulate_redo_kernel(const char* __restr
       acc.madd(p);
     }
     const uint32_t d = task_dst[id];
-    acc.store((d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * XYZZ<F>::BYTES : buckets + (size_t)d * XYZZ<F>::BYTES);
+    BkPoint<F>::from_sat(acc).store((d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * BkPoint<F>::BYTES
+                                              : buckets + (size_t)d * BkPoint<F>::BYTES);
   }
 }
 }  // namespace ZKP_CFG_SYM(cfg)

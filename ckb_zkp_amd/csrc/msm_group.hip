@@ -1,6 +1,7 @@
 // Per-configuration MSM kernels (everything except the hot bucket-accumulate loop, which lives in
 // msm_acc.hip): table pre-computation, log-depth bucket reduction, point utilities, Groth16 assembly.
 // Compiled once per (curve, group): -DZKP_CFG_CURVE={0,1} -DZKP_CFG_GROUP={1,2}.  See msm.hip for the design.
+#include "bucket_dev.hpp"
 #include "ec_dev.hpp"
 #include "msm_vtbl.hpp"
 
@@ -60,9 +61,9 @@ __global__ __launch_bounds__(256) void pair_kernel(const char* __restrict__ in, 
   __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= count) return;
-  XYZZ<F> a = XYZZ<F>::load(in + (size_t)(2 * k) * XYZZ<F>::BYTES);
-  a.add(XYZZ<F>::load(in + (size_t)(2 * k + 1) * XYZZ<F>::BYTES));
-  a.store(out + (size_t)k * XYZZ<F>::BYTES);
+  BkPoint<F> a = BkPoint<F>::load(in + (size_t)(2 * k) * BkPoint<F>::BYTES);
+  a.add(BkPoint<F>::load(in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES));
+  a.store(out + (size_t)k * BkPoint<F>::BYTES);
 }
 
 
@@ -77,23 +78,23 @@ __global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ ba
   uint32_t chunk = blockIdx.x - plan.first_block[l];
   uint32_t lo = chunk * SEG_CHUNK;
   uint32_t hi = min(plan.count[l], lo + SEG_CHUNK);
-  XYZZ<F> acc = XYZZ<F>::inf();
+  BkPoint<F> acc = BkPoint<F>::inf();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
-    acc.add(XYZZ<F>::load(base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * XYZZ<F>::BYTES));
+    acc.add(BkPoint<F>::load(base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * BkPoint<F>::BYTES));
   // LDS tree
-  acc.store(smem + threadIdx.x * XYZZ<F>::BYTES);
+  acc.store(smem + threadIdx.x * BkPoint<F>::BYTES);
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
-      XYZZ<F> o = XYZZ<F>::load(smem + (threadIdx.x + s) * XYZZ<F>::BYTES);
+      BkPoint<F> o = BkPoint<F>::load(smem + (threadIdx.x + s) * BkPoint<F>::BYTES);
       if (!o.is_inf() || !acc.is_inf()) {
         acc.add(o);
-        acc.store(smem + threadIdx.x * XYZZ<F>::BYTES);
+        acc.store(smem + threadIdx.x * BkPoint<F>::BYTES);
       }
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) acc.store(partial + (size_t)blockIdx.x * XYZZ<F>::BYTES);
+  if (threadIdx.x == 0) acc.store(partial + (size_t)blockIdx.x * BkPoint<F>::BYTES);
 }
 
 // Buckets split into a handful of tasks (the common case: the thinly populated top window gives ~77 entries = 2
@@ -111,9 +112,9 @@ __global__ __launch_bounds__(256) void combine_small_kernel(const uint32_t* __re
     const uint32_t b = long_list[w];
     const uint32_t p0 = toff[b], p1 = toff[b + 1];
     if (p1 - p0 > COMBINE_SMALL) continue;
-    XYZZ<F> acc = XYZZ<F>::load(partial + (size_t)p0 * XYZZ<F>::BYTES);
-    for (uint32_t i = p0 + 1; i < p1; i++) acc.add(XYZZ<F>::load(partial + (size_t)i * XYZZ<F>::BYTES));
-    acc.store(buckets + (size_t)b * XYZZ<F>::BYTES);
+    BkPoint<F> acc = BkPoint<F>::load(partial + (size_t)p0 * BkPoint<F>::BYTES);
+    for (uint32_t i = p0 + 1; i < p1; i++) acc.add(BkPoint<F>::load(partial + (size_t)i * BkPoint<F>::BYTES));
+    acc.store(buckets + (size_t)b * BkPoint<F>::BYTES);
   }
 }
 
@@ -125,28 +126,28 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
                                                       const char* __restrict__ partial, char* __restrict__ buckets) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  char* my = smem + (size_t)wv * 64 * XYZZ<F>::BYTES;
+  char* my = smem + (size_t)wv * 64 * BkPoint<F>::BYTES;
   const uint32_t n_long = *n_long_dev;
   for (uint32_t w = blockIdx.x * 4 + wv; w < n_long; w += gridDim.x * 4) {
     const uint32_t b = long_list[w];
     const uint32_t p0 = toff[b], p1 = toff[b + 1];
     if (p1 - p0 <= COMBINE_SMALL) continue;            // handled by combine_small_kernel (wave-uniform branch)
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t i = p0 + lane; i < p1; i += 64) acc.add(XYZZ<F>::load(partial + (size_t)i * XYZZ<F>::BYTES));
-    acc.store(my + lane * XYZZ<F>::BYTES);
+    BkPoint<F> acc = BkPoint<F>::inf();
+    for (uint32_t i = p0 + lane; i < p1; i += 64) acc.add(BkPoint<F>::load(partial + (size_t)i * BkPoint<F>::BYTES));
+    acc.store(my + lane * BkPoint<F>::BYTES);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     for (int s = 32; s > 0; s >>= 1) {
       __builtin_amdgcn_wave_barrier();
       if (lane < s) {
-        XYZZ<F> o = XYZZ<F>::load(my + (lane + s) * XYZZ<F>::BYTES);
+        BkPoint<F> o = BkPoint<F>::load(my + (lane + s) * BkPoint<F>::BYTES);
         if (!o.is_inf()) {
           acc.add(o);
-          acc.store(my + lane * XYZZ<F>::BYTES);
+          acc.store(my + lane * BkPoint<F>::BYTES);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (lane == 0) acc.store(buckets + (size_t)b * XYZZ<F>::BYTES);
+    if (lane == 0) acc.store(buckets + (size_t)b * BkPoint<F>::BYTES);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -158,28 +159,29 @@ __global__ __launch_bounds__(64) void final_kernel(const char* __restrict__ O, i
   __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int t = threadIdx.x;
-  XYZZ<F> acc = XYZZ<F>::inf();
+  BkPoint<F> acc = BkPoint<F>::inf();
   if (t < L) {
-    acc = XYZZ<F>::load(O + (size_t)t * XYZZ<F>::BYTES);
+    acc = BkPoint<F>::load(O + (size_t)t * BkPoint<F>::BYTES);
     for (int k = 0; k < t; k++) acc = acc.dbl();
   } else if (t == L) {
-    acc = XYZZ<F>::load(root);
+    acc = BkPoint<F>::load(root);
   }
-  acc.store(smem + t * XYZZ<F>::BYTES);
+  acc.store(smem + t * BkPoint<F>::BYTES);
   __syncthreads();
   for (int s = 32; s > 0; s >>= 1) {
     if (t < s) {
-      XYZZ<F> o = XYZZ<F>::load(smem + (t + s) * XYZZ<F>::BYTES);
+      BkPoint<F> o = BkPoint<F>::load(smem + (t + s) * BkPoint<F>::BYTES);
       if (!o.is_inf() || !acc.is_inf()) {
         acc.add(o);
-        acc.store(smem + t * XYZZ<F>::BYTES);
+        acc.store(smem + t * BkPoint<F>::BYTES);
       }
     }
     __syncthreads();
   }
   if (t == 0) {
-    if (out_xyzz) acc.store(out_xyzz);
-    if (out_jac) acc.store_jacobian(out_jac);
+    const XYZZ<F> res = acc.to_sat();                      // the pyramid lives in the unsaturated layout; results do not
+    if (out_xyzz) res.store(out_xyzz);
+    if (out_jac) res.store_jacobian(out_jac);
   }
 }
 
@@ -190,22 +192,22 @@ __global__ __launch_bounds__(256) void segsum_desc_kernel(const char* __restrict
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const SegDesc d = descs[blockIdx.x];
-  XYZZ<F> acc = XYZZ<F>::inf();
+  BkPoint<F> acc = BkPoint<F>::inf();
   for (uint32_t i = threadIdx.x; i < d.count; i += 256)
-    acc.add(XYZZ<F>::load(base + ((size_t)d.off + (size_t)i * d.stride) * XYZZ<F>::BYTES));
-  acc.store(smem + threadIdx.x * XYZZ<F>::BYTES);
+    acc.add(BkPoint<F>::load(base + ((size_t)d.off + (size_t)i * d.stride) * BkPoint<F>::BYTES));
+  acc.store(smem + threadIdx.x * BkPoint<F>::BYTES);
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
-      XYZZ<F> o = XYZZ<F>::load(smem + (threadIdx.x + s) * XYZZ<F>::BYTES);
+      BkPoint<F> o = BkPoint<F>::load(smem + (threadIdx.x + s) * BkPoint<F>::BYTES);
       if (!o.is_inf() || !acc.is_inf()) {
         acc.add(o);
-        acc.store(smem + threadIdx.x * XYZZ<F>::BYTES);
+        acc.store(smem + threadIdx.x * BkPoint<F>::BYTES);
       }
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) acc.store(out + (size_t)d.out * XYZZ<F>::BYTES);
+  if (threadIdx.x == 0) acc.store(out + (size_t)d.out * BkPoint<F>::BYTES);
 }
 
 // out = sum_{t < 256} 2^t R[t] + sum_w 2^(c w) roots[w]: lane t adds the window root where t = c*w, doubles t times,
@@ -217,25 +219,26 @@ __global__ __launch_bounds__(256) void final_var_kernel(const char* __restrict__
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
-  XYZZ<F> acc = XYZZ<F>::load(R + (size_t)t * XYZZ<F>::BYTES);
-  if (t % c == 0 && t / c < W) acc.add(XYZZ<F>::load(roots + (size_t)(t / c) * XYZZ<F>::BYTES));
+  BkPoint<F> acc = BkPoint<F>::load(R + (size_t)t * BkPoint<F>::BYTES);
+  if (t % c == 0 && t / c < W) acc.add(BkPoint<F>::load(roots + (size_t)(t / c) * BkPoint<F>::BYTES));
   if (!acc.is_inf())
     for (int k = 0; k < t; k++) acc = acc.dbl();
-  acc.store(smem + t * XYZZ<F>::BYTES);
+  acc.store(smem + t * BkPoint<F>::BYTES);
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if (t < s) {
-      XYZZ<F> o = XYZZ<F>::load(smem + (t + s) * XYZZ<F>::BYTES);
+      BkPoint<F> o = BkPoint<F>::load(smem + (t + s) * BkPoint<F>::BYTES);
       if (!o.is_inf() || !acc.is_inf()) {
         acc.add(o);
-        acc.store(smem + t * XYZZ<F>::BYTES);
+        acc.store(smem + t * BkPoint<F>::BYTES);
       }
     }
     __syncthreads();
   }
   if (t == 0) {
-    if (out_xyzz) acc.store(out_xyzz);
-    if (out_jac) acc.store_jacobian(out_jac);
+    const XYZZ<F> res = acc.to_sat();                      // the pyramid lives in the unsaturated layout; results do not
+    if (out_xyzz) res.store(out_xyzz);
+    if (out_jac) res.store_jacobian(out_jac);
   }
 }
 
@@ -417,7 +420,8 @@ void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t, const char*, const uint32_t
 
 namespace {
 using F = CfgF;
-constexpr size_t XB = XYZZ<F>::BYTES;
+constexpr size_t XB = XYZZ<F>::BYTES;        // canonical (saturated) XYZZ: results, assembly slots
+constexpr size_t BB = BkPoint<F>::BYTES;     // bucket / pyramid points (unsaturated layout, bucket_dev.hpp)
 void l_ingest(hipStream_t s, char* table, const uint8_t* inf, size_t n) {
   hipLaunchKernelGGL(ingest_kernel<F>, dim3((n + 255) / 256), dim3(256), 0, s, table, inf, n);
 }
@@ -427,16 +431,16 @@ void l_precompute(hipStream_t s, char* table, size_t n, int c, int W) {
 void l_combine(hipStream_t s, const uint32_t* long_list, const uint32_t* n_long_dev, const uint32_t* toff,
                const char* partial, char* buckets) {
   hipLaunchKernelGGL(combine_small_kernel<F>, dim3(256), dim3(256), 0, s, long_list, n_long_dev, toff, partial, buckets);
-  hipLaunchKernelGGL(combine_kernel<F>, dim3(512), dim3(256), 256 * XB, s, long_list, n_long_dev, toff, partial, buckets);
+  hipLaunchKernelGGL(combine_kernel<F>, dim3(512), dim3(256), 256 * BB, s, long_list, n_long_dev, toff, partial, buckets);
 }
 void l_pair(hipStream_t s, const char* in, char* out, uint32_t count) {
   hipLaunchKernelGGL(pair_kernel<F>, dim3((count + 255) / 256), dim3(256), 0, s, in, out, count);
 }
 void l_segsum(hipStream_t s, const char* base, const SegPlan* plan, char* partial, uint32_t blocks) {
-  hipLaunchKernelGGL(segsum_kernel<F>, dim3(blocks), dim3(256), 256 * XB, s, base, *plan, partial);
+  hipLaunchKernelGGL(segsum_kernel<F>, dim3(blocks), dim3(256), 256 * BB, s, base, *plan, partial);
 }
 void l_final(hipStream_t s, const char* O, int L, const char* root, char* out_xyzz, uint32_t* out_jac) {
-  hipLaunchKernelGGL(final_kernel<F>, dim3(1), dim3(64), 64 * XB, s, O, L, root, out_xyzz, out_jac);
+  hipLaunchKernelGGL(final_kernel<F>, dim3(1), dim3(64), 64 * BB, s, O, L, root, out_xyzz, out_jac);
 }
 void l_identity(hipStream_t s, char* out_xyzz, uint32_t* out_jac) {
   hipLaunchKernelGGL(write_identity_kernel<F>, dim3(1), dim3(64), 0, s, out_xyzz, out_jac);
@@ -445,10 +449,10 @@ void l_fold(hipStream_t s, const uint32_t* pts, int k, uint32_t* out_jac) {
   hipLaunchKernelGGL(fold_kernel<F>, dim3(1), dim3(64), 0, s, pts, k, out_jac);
 }
 void l_segsum_desc(hipStream_t s, const char* base, const SegDesc* descs, uint32_t n_desc, char* out) {
-  if (n_desc) hipLaunchKernelGGL(segsum_desc_kernel<F>, dim3(n_desc), dim3(256), 256 * XB, s, base, descs, out);
+  if (n_desc) hipLaunchKernelGGL(segsum_desc_kernel<F>, dim3(n_desc), dim3(256), 256 * BB, s, base, descs, out);
 }
 void l_final_var(hipStream_t s, const char* R, const char* roots, int c, int W, char* out_xyzz, uint32_t* out_jac) {
-  hipLaunchKernelGGL(final_var_kernel<F>, dim3(1), dim3(256), 256 * XB, s, R, roots, c, W, out_xyzz, out_jac);
+  hipLaunchKernelGGL(final_var_kernel<F>, dim3(1), dim3(256), 256 * BB, s, R, roots, c, W, out_xyzz, out_jac);
 }
 void l_fold_slots(hipStream_t s, const char* gathered, size_t rank_stride, int world, size_t slot, uint32_t mask,
                   char* res) {
@@ -482,7 +486,7 @@ void l_assemble_g2(hipStream_t s, const char* res, size_t slot, uint32_t* out, u
 
 const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
   static const MsmVtbl v = {
-      F::N, Affine<F>::BYTES, XYZZ<F>::BYTES, CFG_BITS,
+      F::N, Affine<F>::BYTES, XYZZ<F>::BYTES, BkPoint<F>::BYTES, CFG_BITS,
       l_ingest, l_precompute, ZKP_CFG_SYM(msm_accumulate_launch), l_combine, l_pair, l_segsum, l_final, l_identity, l_fold,
       l_into_affine, l_from_jacobian, l_fixed_base, l_segsum_desc, l_final_var, l_fold_slots,
 #if ZKP_CFG_GROUP == 1

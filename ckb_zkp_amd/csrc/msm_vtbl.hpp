@@ -26,6 +26,7 @@ struct SegDesc {
 struct MsmVtbl {
   int fN;                      // 32-bit words per coordinate (8 / 16 / 12 / 24)
   size_t aff_bytes, xyzz_bytes;
+  size_t bucket_bytes;         // one bucket / partial / pyramid point (unsaturated XYZZ layout, bucket_dev.hpp)
   int scalar_bits;
   void (*ingest)(hipStream_t, char* table, const uint8_t* inf, size_t n);
   void (*precompute)(hipStream_t, char* table, size_t n, int c, int W);
