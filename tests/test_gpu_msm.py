@@ -314,3 +314,28 @@ def test_msm_var_equals_resident_msm_and_known_dlog(ctx, curve, group, log_n):
         assert jac_limbs_to_affine_oracle(curve, group, bases.msm(k)) == got
     finally:
         bases.free()
+
+
+@pytest.mark.parametrize("curve,group", CFG)
+def test_msm_reduction_pyramid_exceptional_cases(ctx, curve, group):
+    """Equal / opposite BUCKET sums meeting in the reduction pyramid (adjacent buckets holding Q and Q, or Q and -Q): the
+    pairwise level must double / cancel exactly (bucket_dev.hpp hands P = +-Q to the exact formulas), in the resident-table
+    path and in the variable-base path; plus sums that collide only at a higher level of the pyramid."""
+    c = get_curve(curve)
+    G = Group(OC[curve], group)
+    Q, R = random_points(curve, group, 2, seed=77 + group)
+    cases = [([Q, Q], [1, 2]),                       # buckets 0 and 1 both hold Q: level-0 pair is a doubling
+             ([Q, G.neg(Q)], [1, 2]),                # Q and -Q: the pair cancels to the identity
+             ([Q, R, Q, R], [1, 2, 3, 4]),           # (Q + R) meets (Q + R) one level up
+             ([Q, R, G.neg(Q), G.neg(R)], [1, 2, 3, 4]),
+             ([Q, Q, Q, Q, Q, Q, Q, Q], [1, 2, 3, 4, 5, 6, 7, 8])]   # every bucket holds the same point
+    for pts, ks in cases:
+        exp = G.msm_naive(pts, ks)
+        xy, inf = to_abi_points(curve, group, pts)
+        sc = codec.fr_canonical(ks, c).reshape(-1, 4)
+        bases = ctx.upload_bases(c, group, xy, inf)
+        try:
+            assert jac_limbs_to_affine_oracle(curve, group, bases.msm(sc)) == exp, ks
+        finally:
+            bases.free()
+        assert jac_limbs_to_affine_oracle(curve, group, ctx.msm_var(c, group, xy, inf, sc)) == exp, ks
