@@ -339,3 +339,29 @@ def test_msm_reduction_pyramid_exceptional_cases(ctx, curve, group):
         finally:
             bases.free()
         assert jac_limbs_to_affine_oracle(curve, group, ctx.msm_var(c, group, xy, inf, sc)) == exp, ks
+
+
+@pytest.mark.parametrize("curve,group,log_n,distinct", [("bn254", 2, 18, 256), ("bn254", 1, 18, 256), ("bn254", 2, 19, 8192),
+                                                         ("bls12_381", 2, 16, 64), ("bn254", 2, 20, 2048)])
+def test_msm_many_long_buckets(ctx, curve, group, log_n, distinct):
+    """Hundreds / thousands of buckets that are each split into many tasks (what the lowest buckets of a 2^24-point MSM look
+    like: the short top window piles ~1500 entries onto each of them): scalars drawn from `distinct` small values, so
+    `distinct` buckets of window 0 receive n / distinct entries each — the wave-per-bucket combine path on many waves at once.
+    Known-discrete-log expectation."""
+    c = get_curve(curve)
+    G = Group(OC[curve], group)
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n * 31 + group)
+    d = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    d[:, 3] >>= np.uint64(4)
+    g_xy, _ = to_abi_points(curve, group, [G.gen])
+    xy, inf = ctx.fixed_base_mul(c, group, g_xy, d)
+    k = np.zeros((n, 4), dtype=np.uint64)
+    k[:, 0] = rng.integers(1, distinct + 1, size=n, dtype=np.uint64)
+    bases = ctx.upload_bases(c, group, xy, inf)
+    try:
+        got = jac_limbs_to_affine_oracle(curve, group, bases.msm(k))
+        e = sum(a * int(b) for a, b in zip(codec.limbs_to_ints(d), k[:, 0])) % c.r
+        assert got == G.mul(G.gen, e)
+    finally:
+        bases.free()
