@@ -480,6 +480,23 @@ __global__ __launch_bounds__(256) void task_order_kernel(const uint32_t* __restr
   if (live) order[base[l] + rank] = t;
 }
 
+// ZKP_DEBUG_MSM=1: consistency check of the task schedule (one line per MSM on stdout), with a device sync either side
+__global__ void sched_check_kernel(const uint32_t* toff, const uint32_t* long_list, const uint32_t* tmeta, uint32_t nb,
+                                   uint32_t max_tasks, uint32_t* rep) {
+  const uint32_t n_long = tmeta[TM_NLONG], n_tasks = toff[nb];
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+    if (toff[b + 1] < toff[b]) atomicAdd(&rep[0], 1u);
+    atomicMax(&rep[1], toff[b + 1] - toff[b]);
+  }
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_long; w += gridDim.x * blockDim.x)
+    if (long_list[w] >= nb) atomicAdd(&rep[2], 1u);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    rep[3] = n_long;
+    rep[4] = n_tasks;
+    rep[5] = n_tasks > max_tasks;
+  }
+}
+
 static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, const uint64_t* scalars_dev, size_t n,
                           bool montgomery, uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate,
                           uint64_t* n_entries, int ws_idx, int sort_src, float* ms_scan);
@@ -647,7 +664,25 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       ZKP_HIP(hipEventSynchronize(ctx->ev3));
       ZKP_HIP(hipEventElapsedTime(ms_accumulate, ctx->ev2, ctx->ev3));
     }
-    vt->combine(st, long_list, tmeta + TM_NLONG, toff, task_partial, buckets);
+    static const int dbg = [] { const char* e = getenv("ZKP_DEBUG_MSM"); return e ? atoi(e) : 0; }();
+    if (dbg) {
+      uint32_t* rep = ws.redo.as<uint32_t>((size_t)max_tasks + 1);     // accumulate is done with it
+      ZKP_HIP(hipStreamSynchronize(st));
+      ZKP_HIP(hipMemsetAsync(rep, 0, 32, st));
+      hipLaunchKernelGGL(sched_check_kernel, dim3(256), dim3(256), 0, st, toff, long_list, tmeta, nb, max_tasks, rep);
+      uint32_t h[8];
+      ZKP_HIP(hipMemcpyAsync(h, rep, 32, hipMemcpyDeviceToHost, st));
+      ZKP_HIP(hipStreamSynchronize(st));
+      printf("[msm] group=%d n=%zu nb=%u max_tasks=%u: toff inversions=%u max tasks/bucket=%u bad long_list=%u n_long=%u n_tasks=%u overflow=%u\n",
+             be->group, n, nb, max_tasks, h[0], h[1], h[2], h[3], h[4], h[5]);
+      fflush(stdout);
+    }
+    if (dbg != 2) vt->combine(st, long_list, tmeta + TM_NLONG, toff, task_partial, buckets);
+    if (dbg) {
+      hipError_t e = hipStreamSynchronize(st);
+      printf("[msm] combine: %s\n", hipGetErrorString(e));
+      fflush(stdout);
+    }
     if (n_entries) {
       *n_entries = E;                                   // nominal: scalars x windows
       if (ctx->profiling) {                             // exact: what the scan emitted (identity bases / zero digits dropped)

@@ -118,20 +118,26 @@ __global__ __launch_bounds__(256) void combine_small_kernel(const uint32_t* __re
   }
 }
 
-// buckets[b] = sum of the partial sums of a bucket that was split into several tasks; one wave per bucket
+// buckets[b] = sum of the partial sums of a bucket that was split into several tasks; one wave per bucket.
+// The bucket walk is kept in SGPRs (readfirstlane): the loop and the "few tasks" skip are then scalar branches, and the only
+// exec-masked regions are the two `if (lane ...)` bodies.  With the walk in VGPRs, hipcc 7.2 merged the exec restore after
+// `if (lane == 0)` into the one of the enclosing per-lane `if` and then placed a register reload in between — executed by
+// lane 0 only, so the other lanes entered the next bucket with a clobbered index register (a memory fault as soon as one wave
+// combined two buckets; tests/test_gpu_msm.py::test_msm_many_long_buckets pins it).
 template <class F>
 __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict__ long_list,
                                                       const uint32_t* __restrict__ n_long_dev,
                                                       const uint32_t* __restrict__ toff,
                                                       const char* __restrict__ partial, char* __restrict__ buckets) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   char* my = smem + (size_t)wv * 64 * BkPoint<F>::BYTES;
   const uint32_t n_long = *n_long_dev;
-  for (uint32_t w = blockIdx.x * 4 + wv; w < n_long; w += gridDim.x * 4) {
-    const uint32_t b = long_list[w];
-    const uint32_t p0 = toff[b], p1 = toff[b + 1];
-    if (p1 - p0 <= COMBINE_SMALL) continue;            // handled by combine_small_kernel (wave-uniform branch)
+  for (uint32_t w = blockIdx.x * nw + wv; w < n_long; w += gridDim.x * nw) {
+    const uint32_t b = __builtin_amdgcn_readfirstlane(long_list[w]);
+    const uint32_t p0 = __builtin_amdgcn_readfirstlane(toff[b]), p1 = __builtin_amdgcn_readfirstlane(toff[b + 1]);
+    if (p1 - p0 <= COMBINE_SMALL) continue;            // handled by combine_small_kernel
     BkPoint<F> acc = BkPoint<F>::inf();
     for (uint32_t i = p0 + lane; i < p1; i += 64) acc.add(BkPoint<F>::load(partial + (size_t)i * BkPoint<F>::BYTES));
     acc.store(my + lane * BkPoint<F>::BYTES);
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (lane == 0) acc.store(buckets + (size_t)b * BkPoint<F>::BYTES);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
 }
