@@ -9,8 +9,10 @@
 // library (proof assembly, C ABI) uses.
 //
 // The identity is all-zero limbs (zz == 0), so a zeroed bucket array is an array of identities.  The additions are
-// complete: when the x-difference may be a multiple of p (P = +-Q: doubling / cancellation) the exact saturated formulas of
-// ec_dev.hpp decide, out of line.
+// complete: when the x-difference is a multiple of p (P = +-Q; a two-limb filter, then an exact limb-wise comparison — normalised
+// limbs are unique) the y-difference decides between the doubling formulas and the identity, all in the unsaturated domain.
+// (Round 2 first called the saturated formulas out of line for this: the callee's 214 / 264 VGPRs and 0.6 / 1.4 KB of scratch
+// became the register budget of every pyramid kernel.)
 //
 // Replaces, like ec_dev.hpp, the `add_assign` / `double_in_place` calls inside ark-ec 0.2
 // `VariableBaseMSM::multi_scalar_mul` (reference call sites: /root/reference/groth16/src/prover.rs:187,190,220).
@@ -49,9 +51,6 @@ ZKP_DEV void fu_store(void* p, const Fu<P>& a) {
 
 template <class F>
 struct BkPoint;
-
-template <class F>
-__device__ __noinline__ void bk_add_exact(BkPoint<F>& a, const BkPoint<F>& b);
 
 // ------------------------------------------------------------------------------------------------ G1
 template <class P>
@@ -116,11 +115,11 @@ struct BkPoint<Fp<P>> {
     const auto s1 = ub_mul(v.y, o.v.zzz);                  // 4*2
     const auto s2 = ub_mul(o.v.y, v.zzz);
     const auto pd = ub_sub(u2, u1);                        // (0, 4p)
-    if (pd.f.template maybe_multiple_of_p<4>()) {
-      bk_add_exact<F>(*this, o);
+    const auto rd = ub_sub(s2, s1);                        // (0, 4p)
+    if (pd.f.template maybe_multiple_of_p<4>() && pd.f.template is_multiple_of_p<4>()) {   // same x: P = +-Q
+      *this = rd.f.template is_multiple_of_p<4>() ? dbl() : inf();
       return;
     }
-    const auto rd = ub_sub(s2, s1);                        // (0, 4p)
     const auto pp = ub_mul(pd, pd);                        // 16
     const auto ppp = ub_mul(pd, pp);
     const auto q = ub_mul(u1, pp);
@@ -234,11 +233,12 @@ struct BkPoint<Fp2<P>> {
     const auto s1 = ub2_mul(v.y, o.v.zzz);
     const auto s2 = ub2_mul(o.v.y, v.zzz);
     const auto pd = ub2_sub(u2, u1);                       // (0, 4p)
-    if (pd.c0.f.template maybe_multiple_of_p<4>() && pd.c1.f.template maybe_multiple_of_p<4>()) {
-      bk_add_exact<F>(*this, o);
+    const auto rd = ub2_sub(s2, s1);                       // (0, 4p)
+    if (pd.c0.f.template maybe_multiple_of_p<4>() && pd.c1.f.template maybe_multiple_of_p<4>() &&
+        pd.c0.f.template is_multiple_of_p<4>() && pd.c1.f.template is_multiple_of_p<4>()) {           // same x: P = +-Q
+      *this = rd.c0.f.template is_multiple_of_p<4>() && rd.c1.f.template is_multiple_of_p<4>() ? dbl() : inf();
       return;
     }
-    const auto rd = ub2_sub(s2, s1);                       // (0, 4p)
     const auto pp = sqr_lazy(pd);                          // 16 + 16
     const auto ppp = ub2_mul(pd, pp);                      // 4*2 + 4*2
     const auto q = ub2_mul(u1, pp);
@@ -277,13 +277,5 @@ struct BkPoint<Fp2<P>> {
     return r;
   }
 };
-
-// P = +-Q inside the pyramid (possible only for crafted inputs): decide with the exact saturated formulas
-template <class F>
-__device__ __noinline__ void bk_add_exact(BkPoint<F>& a, const BkPoint<F>& b) {
-  XYZZ<F> x = a.to_sat();
-  x.add(b.to_sat());
-  a = BkPoint<F>::from_sat(x);
-}
 
 }  // namespace zkp

@@ -340,6 +340,19 @@ struct Fu {
     for (int k = 1; k < KMAX; k++) hit |= (v[0] == (mp_limb(k, 0) & MASK)) & (v[1] == (mp_limb(k, 1) & MASK));
     return hit;
   }
+  // exact: normalised limbs are a unique representation, so "value in {p, 2p, .., (KMAX-1)p}" is a limb-wise comparison
+  template <int KMAX>
+  ZKP_DEV bool is_multiple_of_p() const {
+    bool hit = false;
+#pragma unroll
+    for (int k = 1; k < KMAX; k++) {
+      bool eq = true;
+#pragma unroll
+      for (int i = 0; i < L; i++) eq &= v[i] == mp_limb(k, i);
+      hit |= eq;
+    }
+    return hit;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
