@@ -250,17 +250,27 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
     pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL, pk->q_lo[4], pk->q_n[4],
                         d->num_inputs, &fL);
     {
-      // L reuses A's bucket sort + task schedule when both queries have the same identity pattern (L is stored
-      // index-aligned with z, so both MSMs run over the same scalar slice; L's num_inputs leading identity points are
-      // skipped by its accumulate kernel when it gathers them): one digit scan + level-2 sort + schedule less per proof.
-      // Queries with DIFFERENT identity patterns must not share a sort: a lane whose point is the identity idles while
-      // its wave-mates add (measured: B2 sharing a full-pattern sort ran 4.47 instead of 1.91 ms — half of the MiMC
-      // chain's B-query is identities — and the whole proof 11.8 instead of 9.4 ms).  ZKP_SHARE_AL_SORT=0 disables it.
+      // L reuses A's bucket sort + task schedule (L is stored index-aligned with z, so both MSMs run over the same scalar
+      // slice): one digit scan + level-2 sort + schedule less per proof.  The shared sort drops a base only if it is the
+      // identity in BOTH queries (A's scan then uses the intersection of the two flag vectors, bases_set_sort_flags); a base
+      // that is the identity in one query only stays in the list and the accumulate kernel skips it when it gathers it.
+      // That is only worth it when such bases are rare: a lane whose point is the identity idles while its wave-mates add
+      // (measured: B2 sharing a full-pattern sort ran 4.47 instead of 1.91 ms — half of the MiMC chain's B-query is
+      // identities).  In the MiMC chain A has three identity bases that L does not have, plus L's num_inputs leading ones.
+      // ZKP_SHARE_AL_SORT=0 disables it.
       static const bool on = !(getenv("ZKP_SHARE_AL_SORT") && atoi(getenv("ZKP_SHARE_AL_SORT")) == 0);
-      bool same = fA.size() == fL.size();
-      for (size_t j = 0; same && j < fA.size(); j++)
-        if (pk->q_lo[0] + j >= d->num_inputs && fA[j] != fL[j]) same = false;
-      pk->share_al_sort = on && same && bases_same_shape(ctx, pk->hL, pk->hA) && pk->q_n[0] > 0;
+      bool same = fA.size() == fL.size() && pk->q_lo[0] == pk->q_lo[4];
+      size_t differ = 0;
+      std::vector<uint8_t> both(fA.size());
+      for (size_t k = 0; same && k < fA.size(); k++) {
+        both[k] = fA[k] & fL[k];
+        differ += fA[k] != fL[k];
+      }
+      pk->share_al_sort = on && same && differ <= fA.size() / 4 && bases_same_shape(ctx, pk->hL, pk->hA) && pk->q_n[0] > 0;
+      if (pk->share_al_sort && differ) bases_set_sort_flags(ctx, pk->hA, both.data(), both.size());
+      if (getenv("ZKP_DEBUG_MSM"))
+        fprintf(stderr, "[groth16] A/L sort sharing: %d (flags differ at %zu of %zu bases), B1/B2: %d\n", (int)pk->share_al_sort,
+                differ, fA.size(), (int)pk->share_b_sort);
     }
   }
   uint32_t* consts = pk->consts.as<uint32_t>(64);
@@ -438,7 +448,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
       run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1);
       ZKP_HIP(hipEventRecord(ctx->cur->ev_a, ctx->cur->ws[1].stream));
       run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 3, pk->share_b_sort ? 2 : -1);
-      run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 1);
+      run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 1, pk->share_al_sort ? 1 : -1);   // A's sort, still in this workspace
       if (!partial_out) {
         ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_a, 0));
         v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, proof_dev, flags_dev);

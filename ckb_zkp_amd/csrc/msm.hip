@@ -555,7 +555,9 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
                           uint64_t* n_entries, int ws_idx, int sort_src, float* ms_scan) {
   const MsmVtbl* vt = be->vt;
   MsmWorkspace& ws = ctx->cur->ws[ws_idx];
-  const bool reuse = sort_src >= 0 && sort_src != ws_idx;
+  // sort_src: workspace whose sorted entries + task schedule this MSM reuses (same scalars, window configuration and identity
+  // pattern); sort_src == ws_idx = the MSM that ran on this workspace just before (A -> L on one stream)
+  const bool reuse = sort_src >= 0;
   MsmWorkspace& sw = reuse ? ctx->cur->ws[sort_src] : ws;          // owner of the sorted entries and the task schedule
   hipStream_t st = ws_idx == 0 ? ctx->cur->stream : ws.stream;
   const size_t XB = vt->bucket_bytes;                                // buckets, partial sums, pyramid levels
@@ -601,7 +603,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     uint32_t* start = sw.offsets.as<uint32_t>(2 * (size_t)nb);
     uint32_t* end = start + nb;
     const uint8_t* scan_inf = be->sort_inf ? be->sort_inf : be->inf;     // see BasesEntry::sort_inf
-    if (reuse) ZKP_HIP(hipStreamWaitEvent(st, sw.sorted, 0));
+    if (reuse && sort_src != ws_idx) ZKP_HIP(hipStreamWaitEvent(st, sw.sorted, 0));
     else ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
     const bool timed_scan = ms_scan && ctx->profiling && !reuse;      // K5 "scalar scan": histogram pass + count scan + scatter pass
     if (timed_scan) ZKP_HIP(hipEventRecord(ctx->ev2, st));
