@@ -51,6 +51,11 @@ ZKP_DEV void fu_store(void* p, const Fu<P>& a) {
 
 template <class F>
 struct BkPoint;
+// P = +-Q inside an addition (same x): doubling or the identity.  Out of line — one copy of the doubling formulas per
+// translation unit instead of one per call site of add() (the BLS12-381 G2 unit took 5 minutes to compile with it inline);
+// the callee needs fewer registers than add() itself, so it does not raise the callers' register budget.
+template <class F>
+__device__ __noinline__ void bk_same_x(BkPoint<F>& a, bool same_y);
 
 // ------------------------------------------------------------------------------------------------ G1
 template <class P>
@@ -117,7 +122,7 @@ struct BkPoint<Fp<P>> {
     const auto pd = ub_sub(u2, u1);                        // (0, 4p)
     const auto rd = ub_sub(s2, s1);                        // (0, 4p)
     if (pd.f.template maybe_multiple_of_p<4>() && pd.f.template is_multiple_of_p<4>()) {   // same x: P = +-Q
-      *this = rd.f.template is_multiple_of_p<4>() ? dbl() : inf();
+      bk_same_x<F>(*this, rd.f.template is_multiple_of_p<4>());
       return;
     }
     const auto pp = ub_mul(pd, pd);                        // 16
@@ -236,7 +241,7 @@ struct BkPoint<Fp2<P>> {
     const auto rd = ub2_sub(s2, s1);                       // (0, 4p)
     if (pd.c0.f.template maybe_multiple_of_p<4>() && pd.c1.f.template maybe_multiple_of_p<4>() &&
         pd.c0.f.template is_multiple_of_p<4>() && pd.c1.f.template is_multiple_of_p<4>()) {           // same x: P = +-Q
-      *this = rd.c0.f.template is_multiple_of_p<4>() && rd.c1.f.template is_multiple_of_p<4>() ? dbl() : inf();
+      bk_same_x<F>(*this, rd.c0.f.template is_multiple_of_p<4>() && rd.c1.f.template is_multiple_of_p<4>());
       return;
     }
     const auto pp = sqr_lazy(pd);                          // 16 + 16
@@ -277,5 +282,10 @@ struct BkPoint<Fp2<P>> {
     return r;
   }
 };
+
+template <class F>
+__device__ __noinline__ void bk_same_x(BkPoint<F>& a, bool same_y) {
+  a = same_y ? a.dbl() : BkPoint<F>::inf();
+}
 
 }  // namespace zkp
