@@ -8,7 +8,7 @@
 
 namespace zkp {
 
-constexpr int SEG_CHUNK = 1024;
+constexpr int SEG_CHUNK = 4096;   // entries per block of the segmented sums: 15 serial additions per thread + an 8-level LDS tree (1024: 122.3, 2048: 122.7, 4096: 124.0, 8192: 123.5 proofs/s; single-proof latency 10.3 / 10.35 / 10.5 / 10.7 ms)
 constexpr uint32_t MSM_TASK_CAP = 64;      // max entries one lane accumulates before the bucket is split
 struct SegPlan {
   int L;                       // number of segments
