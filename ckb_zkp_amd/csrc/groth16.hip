@@ -256,7 +256,9 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
       // that is the identity in one query only stays in the list and the accumulate kernel skips it when it gathers it.
       // That is only worth it when such bases are rare: a lane whose point is the identity idles while its wave-mates add
       // (measured: B2 sharing a full-pattern sort ran 4.47 instead of 1.91 ms — half of the MiMC chain's B-query is
-      // identities).  In the MiMC chain A has three identity bases that L does not have, plus L's num_inputs leading ones.
+      // identities).  In the MiMC chain A and L each have ~210 K identity bases of 1.26 M that the other does not: sharing
+      // made both accumulate kernels 20 % longer (1.02 -> 1.25 ms) for one sort less, 122.2 vs 121.0 proofs/s and + 0.2 ms
+      // single-proof latency — not taken: the limit is 1/16 of the bases.
       // ZKP_SHARE_AL_SORT=0 disables it.
       static const bool on = !(getenv("ZKP_SHARE_AL_SORT") && atoi(getenv("ZKP_SHARE_AL_SORT")) == 0);
       bool same = fA.size() == fL.size() && pk->q_lo[0] == pk->q_lo[4];
@@ -266,7 +268,7 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
         both[k] = fA[k] & fL[k];
         differ += fA[k] != fL[k];
       }
-      pk->share_al_sort = on && same && differ <= fA.size() / 4 && bases_same_shape(ctx, pk->hL, pk->hA) && pk->q_n[0] > 0;
+      pk->share_al_sort = on && same && differ <= fA.size() / 16 && bases_same_shape(ctx, pk->hL, pk->hA) && pk->q_n[0] > 0;
       if (pk->share_al_sort && differ) bases_set_sort_flags(ctx, pk->hA, both.data(), both.size());
       if (getenv("ZKP_DEBUG_MSM"))
         fprintf(stderr, "[groth16] A/L sort sharing: %d (flags differ at %zu of %zu bases), B1/B2: %d\n", (int)pk->share_al_sort,

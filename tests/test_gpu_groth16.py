@@ -251,3 +251,62 @@ def test_create_random_proof_and_no_zk_pass_the_reference_verifier(ctx, curve):
         assert verify_proof(OC[curve], vk, og.Proof(p3.a, p3.b, p3.c), [10])
     finally:
         pk.free()
+
+
+class _DenseChain:
+    """t_i = (x_i + x_{i+1} + t_{i-1}) * x_i: every auxiliary variable but the last product occurs in an A row, so the A and L
+    queries have (almost) the same identity pattern — the case in which L reuses A's bucket sort (groth16.hip share_al_sort)."""
+
+    def __init__(self, curve, xs):
+        self.r = OC[curve].r
+        self.xs = xs
+
+    def generate_constraints(self, cs):
+        r = self.r
+        out = cs.alloc_input(lambda: 7)
+        xv = [cs.alloc(lambda v=v: v) for v in self.xs]
+        cs.enforce(lambda lc: lc + out, lambda lc: lc + cs.one(), lambda lc: lc + (7, cs.one()))
+        t_var, t_val = None, 0
+        for i in range(len(self.xs) - 1):
+            a_val = (self.xs[i] + self.xs[i + 1] + t_val) % r
+            new_val = a_val * self.xs[i] % r
+            new_var = cs.alloc(lambda v=new_val: v)
+            prev = t_var
+            cs.enforce(lambda lc: (lc + xv[i] + xv[i + 1]) if prev is None else (lc + xv[i] + xv[i + 1] + prev),
+                       lambda lc: lc + xv[i], lambda lc: lc + new_var)
+            t_var, t_val = new_var, new_val
+
+
+def test_l_reuses_a_sort_when_identity_patterns_agree(ctx, capfd, monkeypatch):
+    """Proof == trapdoor-expected proof on a circuit whose A and L queries differ in one identity base (sort shared)."""
+    from ckb_zkp_amd.r1cs import ConstraintSystem
+    from oracle.pyref.curves import Group
+    curve = "bn254"
+    rnd = random.Random(21)
+    circ = _DenseChain(curve, [rnd.randrange(OC[curve].r) for _ in range(300)])
+    params = groth16.generate_parameters(ctx, curve, circ, **TOXIC)
+    monkeypatch.setenv("ZKP_DEBUG_MSM", "0")
+    pk = groth16.ProvingKey(ctx, params, circ)
+    try:
+        assert "A/L sort sharing: 1" in capfd.readouterr().err
+        c = params.curve
+        cs = ConstraintSystem(curve, True)
+        circ.generate_constraints(cs)
+        zi = cs.full_assignment()
+        z = codec.fr_to_mont(zi, c).reshape(-1, 4)
+        h = codec.fr_from_mont(pk.witness_map(z), c)
+        t, r, ni = params.toxic, c.r, 2
+        for r_, s_ in ((0x1234567, 0x7654321), (0, 0)):
+            out, inf = pk.prove_raw(z, codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0])
+            proof = pk.decode_proof(out, inf)
+            A = (t["alpha"] + sum(x * y for x, y in zip(zi, t["a"])) + r_ * t["delta"]) % r
+            B = (t["beta"] + sum(x * y for x, y in zip(zi, t["b"])) + s_ * t["delta"]) % r
+            L = sum(x * y for x, y in zip(zi[ni:], t["l"][ni:])) % r
+            H = sum(x * y for x, y in zip(h, t["h"])) % r
+            Cc = (s_ * A + r_ * B - r_ * s_ % r * t["delta"] + L + H) % r
+            G1, G2 = Group(OC[curve], 1), Group(OC[curve], 2)
+            assert proof.a == G1.mul(G1.gen, A)
+            assert proof.b == G2.mul(G2.gen, B)
+            assert proof.c == G1.mul(G1.gen, Cc)
+    finally:
+        pk.free()
