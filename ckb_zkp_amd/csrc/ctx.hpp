@@ -128,6 +128,7 @@ struct zkp_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // zkp_timer_*
   hipEvent_t ev2 = nullptr, ev3 = nullptr;   // internal per-kernel timing
   bool profiling = false;
+  bool batch_mode = false;     // inside zkp_groth16_prove_batch*: kernels are tuned for throughput of many proofs in flight, not latency
   std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)
   zkp::DevBuf ntt_io, poly_tmp, poly_consts, spmv_list;
   // MSM scratch

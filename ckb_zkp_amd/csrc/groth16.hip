@@ -705,6 +705,11 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
     ctx->cur = &ctx->lanes[l];
     ctx->cur_idx = l;
   };
+  struct BatchMode {                             // several proofs in flight: throughput tuning (msm.hip: segmented-sum chunk)
+    zkp_ctx* c;
+    ~BatchMode() { c->batch_mode = false; }
+  } batch_mode{ctx};
+  ctx->batch_mode = n > 1 && !prof;
   try {
     for (size_t i = 0; i < n; i++) {
       const int l = prof ? 0 : (int)(i % nl);

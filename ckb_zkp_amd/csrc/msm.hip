@@ -721,6 +721,8 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     const int L = c - 1;                           // levels with odd entries: 0..L-1 ; root = level L
     SegPlan plan{};
     plan.L = L;
+    const uint32_t chunk = ctx->batch_mode ? SEG_CHUNK_BATCH : SEG_CHUNK;
+    plan.chunk = chunk;
     uint32_t lvl_off = 0, cnt = nb, blocks = 0;
     for (int l = 0; l < L; l++) {
       uint32_t next_off = lvl_off + cnt;
@@ -729,7 +731,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       plan.off[l] = lvl_off + 1;
       plan.stride[l] = 2;
       plan.count[l] = cnt / 2;
-      blocks += (cnt / 2 + SEG_CHUNK - 1) / SEG_CHUNK;
+      blocks += (cnt / 2 + chunk - 1) / chunk;
       lvl_off = next_off;
       cnt /= 2;
     }
@@ -741,12 +743,13 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       vt->segsum(st, buckets, &plan, partial, blocks);
       SegPlan p2{};
       p2.L = L;
+      p2.chunk = chunk;
       for (int l = 0; l < L; l++) {
         p2.first_block[l] = l;
         p2.off[l] = plan.first_block[l];
         p2.stride[l] = 1;
         p2.count[l] = plan.first_block[l + 1] - plan.first_block[l];
-        ZKP_REQUIRE(p2.count[l] <= (uint32_t)SEG_CHUNK, ZKP_ERR_BAD_ARG);
+        ZKP_REQUIRE(p2.count[l] <= chunk, ZKP_ERR_BAD_ARG);
       }
       p2.first_block[L] = L;
       vt->segsum(st, partial, &p2, Obuf, L);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void pair_kernel(const char* __restrict__ in, 
 }
 
 
-// block -> (segment l, chunk): sums <= SEG_CHUNK entries into partial[block]
+// block -> (segment l, chunk): sums <= plan.chunk entries into partial[block]
 template <class F>
 __global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ base, SegPlan plan,
                                                      char* __restrict__ partial) {
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ ba
   int l = 0;
   while (l + 1 < plan.L && blockIdx.x >= plan.first_block[l + 1]) l++;
   uint32_t chunk = blockIdx.x - plan.first_block[l];
-  uint32_t lo = chunk * SEG_CHUNK;
-  uint32_t hi = min(plan.count[l], lo + SEG_CHUNK);
+  uint32_t lo = chunk * plan.chunk;
+  uint32_t hi = min(plan.count[l], lo + plan.chunk);
   BkPoint<F> acc = BkPoint<F>::inf();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
     acc.add(BkPoint<F>::load(base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * BkPoint<F>::BYTES));

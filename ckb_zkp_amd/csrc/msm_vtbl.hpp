@@ -8,10 +8,15 @@
 
 namespace zkp {
 
-constexpr int SEG_CHUNK = 4096;   // entries per block of the segmented sums: 15 serial additions per thread + an 8-level LDS tree (1024: 122.3, 2048: 122.7, 4096: 124.0, 8192: 123.5 proofs/s; single-proof latency 10.3 / 10.35 / 10.5 / 10.7 ms)
+// Entries per block of the segmented sums (chunk / 256 - 1 serial additions per thread, then an 8-level LDS tree: the tree runs
+// at < 50 % lane utilisation, the serial part at 100 %).  Pipelined batches take the large chunk (1024: 122.3, 2048: 122.7,
+// 4096: 124.0, 8192: 123.5 proofs/s), single proofs / single MSMs the small one (latency 10.3 vs 10.5 ms per proof).
+constexpr int SEG_CHUNK = 1024;
+constexpr int SEG_CHUNK_BATCH = 4096;
 constexpr uint32_t MSM_TASK_CAP = 64;      // max entries one lane accumulates before the bucket is split
 struct SegPlan {
   int L;                       // number of segments
+  uint32_t chunk;              // entries per block
   uint32_t first_block[26];    // blocks of segment l: first_block[l] .. first_block[l+1]
   uint32_t off[25];            // element offset of segment l's first entry
   uint32_t stride[25];         // element stride
