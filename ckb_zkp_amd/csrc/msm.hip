@@ -726,7 +726,9 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     uint32_t lvl_off = 0, cnt = nb, blocks = 0;
     for (int l = 0; l < L; l++) {
       uint32_t next_off = lvl_off + cnt;
-      vt->pair(st, buckets + (size_t)lvl_off * XB, buckets + (size_t)next_off * XB, cnt / 2);
+      static const bool top_fused = !(getenv("ZKP_PAIR_TOP") && atoi(getenv("ZKP_PAIR_TOP")) == 0);
+      if (!top_fused || cnt > PAIR_TOP_MAX) vt->pair(st, buckets + (size_t)lvl_off * XB, buckets + (size_t)next_off * XB, cnt / 2);
+      else if (cnt == PAIR_TOP_MAX || l == 0) vt->pair_top(st, buckets + (size_t)lvl_off * XB, cnt);   // this level and all above it
       plan.first_block[l] = blocks;
       plan.off[l] = lvl_off + 1;
       plan.stride[l] = 2;

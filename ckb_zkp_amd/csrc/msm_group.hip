@@ -66,6 +66,27 @@ __global__ __launch_bounds__(256) void pair_kernel(const char* __restrict__ in, 
   a.store(out + (size_t)k * BkPoint<F>::BYTES);
 }
 
+// The top of the pyramid in ONE launch: the level with `cnt` <= 2 * PAIR_TOP_THREADS entries at `base`, every further level
+// directly behind its predecessor (the layout msm.hip uses), down to the root.  One workgroup, a barrier per level: the ~10
+// levels that hold fewer points than the machine has SIMDs cost one dependent addition each either way, but as one packet in
+// the hardware queue instead of ten (streams that share the queue wait behind every packet).
+constexpr int PAIR_TOP_THREADS = PAIR_TOP_MAX / 2;
+template <class F>
+__global__ __launch_bounds__(PAIR_TOP_THREADS) void pair_top_kernel(char* __restrict__ base, uint32_t cnt) {
+  __builtin_amdgcn_s_setprio(3);
+  char* in = base;
+  for (; cnt > 1; cnt >>= 1) {
+    char* out = in + (size_t)cnt * BkPoint<F>::BYTES;
+    if (threadIdx.x < cnt / 2) {
+      BkPoint<F> a = BkPoint<F>::load(in + (size_t)(2 * threadIdx.x) * BkPoint<F>::BYTES);
+      a.add(BkPoint<F>::load(in + (size_t)(2 * threadIdx.x + 1) * BkPoint<F>::BYTES));
+      a.store(out + (size_t)threadIdx.x * BkPoint<F>::BYTES);
+    }
+    __threadfence_block();
+    __syncthreads();
+    in = out;
+  }
+}
 
 // block -> (segment l, chunk): sums <= plan.chunk entries into partial[block]
 template <class F>
@@ -443,6 +464,9 @@ void l_combine(hipStream_t s, const uint32_t* long_list, const uint32_t* n_long_
 void l_pair(hipStream_t s, const char* in, char* out, uint32_t count) {
   hipLaunchKernelGGL(pair_kernel<F>, dim3((count + 255) / 256), dim3(256), 0, s, in, out, count);
 }
+void l_pair_top(hipStream_t s, char* base, uint32_t count) {
+  hipLaunchKernelGGL(pair_top_kernel<F>, dim3(1), dim3(PAIR_TOP_THREADS), 0, s, base, count);
+}
 void l_segsum(hipStream_t s, const char* base, const SegPlan* plan, char* partial, uint32_t blocks) {
   hipLaunchKernelGGL(segsum_kernel<F>, dim3(blocks), dim3(256), 256 * BB, s, base, *plan, partial);
 }
@@ -501,6 +525,7 @@ const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
 #else
       nullptr, nullptr, l_assemble_g2,
 #endif
+      l_pair_top,
   };
   return &v;
 }
