@@ -55,7 +55,8 @@ struct BasesEntry {
   int curve = 0, group = 1;
   const MsmVtbl* vt = nullptr;
   size_t n = 0;
-  int c = 0, W = 0;
+  int c = 0, W = 0;            // bucket bits (= width of the wide windows), number of windows
+  int wide = 0;                // the first `wide` windows are c bits wide, the remaining W - wide are c - 1 (balanced windows)
   char* table = nullptr;       // W * n affine points: T[w][i] = 2^(c*w) * P_i
   uint8_t* inf = nullptr;      // n identity flags (device) or nullptr
   // Variable-base mode (zkp_msm_g*_var): no window tables — `table` holds the n points as uploaded, the digit scan emits
@@ -96,8 +97,18 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, co
   e->group = group;
   e->vt = msm_vtbl(curve, group);
   e->n = n;
-  e->c = pick_window_bits(n, group);
-  e->W = (e->vt->scalar_bits + 1 + e->c - 1) / e->c;
+  // Balanced windows: T = scalar_bits + 1 (one spare bit absorbs the last signed-digit carry) is spread over W = ceil(T / c)
+  // windows of ceil(T / W) and floor(T / W) bits instead of W - 1 full windows and a thin top one.  With c = 20 on a 254-bit
+  // field the top window was 14 bits wide: its n digits fell on 1/64 of the buckets (6x the average load: 16 of the 1024
+  // level-1 sort bins oversized, three tasks per hot bucket and a combine step); now 8 windows are 20 and 5 are 19 bits wide.
+  // ZKP_MSM_BALANCED=0 restores equal widths.
+  {
+    static const bool balanced = !(getenv("ZKP_MSM_BALANCED") && atoi(getenv("ZKP_MSM_BALANCED")) == 0);
+    const int T = e->vt->scalar_bits + 1, c0 = pick_window_bits(n, group);
+    e->W = (T + c0 - 1) / c0;
+    e->c = balanced ? (T + e->W - 1) / e->W : c0;
+    e->wide = balanced ? T - e->W * (e->c - 1) : e->W;
+  }
   ZKP_REQUIRE((double)n * e->W < 2147483000.0, ZKP_ERR_BAD_ARG);
   const size_t ab = e->vt->aff_bytes;
   size_t bytes = std::max<size_t>(1, n) * e->W * ab;
@@ -109,7 +120,7 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, co
       ZKP_HIP(hipMemcpyAsync(e->inf, inf, n, hipMemcpyHostToDevice, ctx->cur->stream));
       e->vt->ingest(ctx->cur->stream, e->table, e->inf, n);
     }
-    e->vt->precompute(ctx->cur->stream, e->table, n, e->c, e->W);
+    e->vt->precompute(ctx->cur->stream, e->table, n, e->c, e->W, e->wide);
     ZKP_HIP(hipGetLastError());
     ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   }
@@ -149,7 +160,7 @@ void bases_set_sort_flags(zkp_ctx* ctx, uint64_t handle, const uint8_t* flags_ho
 }
 bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2) {
   auto a = get_bases(ctx, h1), b = get_bases(ctx, h2);
-  return a->curve == b->curve && a->n == b->n && a->c == b->c && a->W == b->W;
+  return a->curve == b->curve && a->n == b->n && a->c == b->c && a->W == b->W && a->wide == b->wide;
 }
 
 // ------------------------------------------------------------------------------------------- K5 digit scan
@@ -159,19 +170,21 @@ bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2) {
 struct DigitIter {
   uint32_t v[8];
   uint32_t carry;
-  __device__ __forceinline__ void next(int w, int c, uint32_t nb, uint32_t& key, uint32_t& neg) {
-    const int bit = w * c;
+  // window w: the first `wide` windows are c bits wide, the others c - 1 (BasesEntry::wide); nb = 2^(c-1)
+  __device__ __forceinline__ void next(int w, int c, int wide, uint32_t nb, uint32_t& key, uint32_t& neg) {
+    const int cw = w < wide ? c : c - 1;
+    const int bit = w < wide ? w * c : wide * c + (w - wide) * (c - 1);
     const int limb = bit >> 5, sh = bit & 31;
     uint32_t d = 0;
     if (limb < 8) {
       uint64_t two = v[limb];
       if (limb + 1 < 8) two |= (uint64_t)v[limb + 1] << 32;
-      d = (uint32_t)(two >> sh) & ((1u << c) - 1);
+      d = (uint32_t)(two >> sh) & ((1u << cw) - 1);
     }
     d += carry;
     neg = 0;
-    if (d > nb) {
-      d = (1u << c) - d;
+    if (d > (1u << (cw - 1))) {
+      d = (1u << cw) - d;
       neg = 1;
       carry = 1;
     } else {
@@ -285,7 +298,7 @@ constexpr int SORT_SCALARS = 2048;    // default; larger MSMs use larger tiles (
 constexpr int SORT_SCALARS_UNUSED_ = 0;     // scalars per workgroup in the level-1 passes (8 per lane): larger tiles = smaller (bin x tile) count matrix and longer contiguous runs per bin in the scatter (512 -> 2048: +2 % proofs/s)
 template <class FrP>
 __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restrict__ scalars, size_t n, size_t offset,
-                                                        const uint8_t* __restrict__ inf, int montgomery, int c, int W,
+                                                        const uint8_t* __restrict__ inf, int montgomery, int c, int W, int wide,
                                                         uint32_t nb, int L, uint32_t nbins1,
                                                         uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t tile,
                                                         int var) {
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restri
       DigitIter it = load_scalar<FrP>(scalars, i, montgomery);
       for (int w = 0; w < W; w++) {
         uint32_t key, neg;
-        it.next(w, c, nb, key, neg);
+        it.next(w, c, wide, nb, key, neg);
         if (key < nb) atomicAdd(&cnt[(var ? ((uint32_t)w << (c - 1)) | key : key) >> L], 1u);
       }
     }
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restri
 template <class FrP>
 __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __restrict__ scalars, size_t n,
                                                            size_t offset, const uint8_t* __restrict__ inf,
-                                                           int montgomery, size_t ntab, int c, int W, uint32_t nb,
+                                                           int montgomery, size_t ntab, int c, int W, int wide, uint32_t nb,
                                                            int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
                                                            uint32_t nblocks, uint32_t tile,
                                                            uint64_t* __restrict__ kv, int var) {   // (low key << 32) | val
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
       DigitIter it = load_scalar<FrP>(scalars, i, montgomery);
       for (int w = 0; w < W; w++) {
         uint32_t key, neg;
-        it.next(w, c, nb, key, neg);
+        it.next(w, c, wide, nb, key, neg);
         if (key < nb) {                                // zero digits are dropped here
           const uint32_t fk = var ? ((uint32_t)w << (c - 1)) | key : key;     // variable-base: one bucket set per window
           uint32_t pos = atomicAdd(&cur[fk >> L], 1u);
@@ -372,7 +385,8 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
     }
     pre[t] = acc;
     __syncthreads();
-    for (uint32_t d = 1; d < T; d <<= 1) {
+    const uint32_t live = (nk + per - 1) / per;          // threads with a non-zero partial: distances >= live add nothing
+    for (uint32_t d = 1; d < live; d <<= 1) {
       uint32_t add = t >= d ? pre[t - d] : 0;
       __syncthreads();
       pre[t] += add;
@@ -569,7 +583,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
   if (n == 0) {
     vt->write_identity(st, (char*)out_dev_xyzz, out_jac);
   } else {
-    const int c = be->c, W = be->W;
+    const int c = be->c, W = be->W, wide = be->wide;
     const int var = be->var ? 1 : 0;
     int lgW = 0;
     while ((1 << lgW) < W) lgW++;
@@ -610,16 +624,16 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     if (reuse) {
     } else if (be->curve == ZKP_BN254) {
       hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
-                         nb_w, LB, nbins1, hist, nblocks, tile, var);
+                         wide, nb_w, LB, nbins1, hist, nblocks, tile, var);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
       hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
-                         be->n, c, W, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
+                         be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
     } else {
       hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
-                         nb_w, LB, nbins1, hist, nblocks, tile, var);
+                         wide, nb_w, LB, nbins1, hist, nblocks, tile, var);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
       hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
-                         be->n, c, W, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
+                         be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
     }
     if (timed_scan) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
@@ -850,6 +864,7 @@ void msm_var_run(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, co
     if (c == 4 || c == 8 || c == 16) e.c = c;
   }
   e.W = 256 / e.c;
+  e.wide = e.W;                // equal widths: the variable-base reduction weighs window w by 2^(c*w)
   ZKP_REQUIRE((double)n * e.W < 2147483000.0, ZKP_ERR_BAD_ARG);
   hipStream_t st = ctx->cur->stream;
   const size_t ab = e.vt->aff_bytes;

@@ -41,13 +41,14 @@ __global__ void ingest_kernel(char* table, const uint8_t* inf, size_t n) {
 }
 
 template <class F>
-__global__ __launch_bounds__(128) void precompute_kernel(char* table, size_t n, int c, int W) {
+__global__ __launch_bounds__(128) void precompute_kernel(char* table, size_t n, int c, int W, int wide) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<F> p = Affine<F>::load(table + i * Affine<F>::BYTES);
   XYZZ<F> acc = XYZZ<F>::from_affine(p);
   for (int w = 1; w < W; w++) {
-    for (int k = 0; k < c; k++) acc = acc.dbl();
+    const int cw = w - 1 < wide ? c : c - 1;               // width of window w - 1 (balanced windows, msm.hip)
+    for (int k = 0; k < cw; k++) acc = acc.dbl();
     Affine<F> a = acc.to_affine();
     a.store(table + ((size_t)w * n + i) * Affine<F>::BYTES);
     acc = XYZZ<F>::from_affine(a);
@@ -453,8 +454,8 @@ constexpr size_t BB = BkPoint<F>::BYTES;     // bucket / pyramid points (unsatur
 void l_ingest(hipStream_t s, char* table, const uint8_t* inf, size_t n) {
   hipLaunchKernelGGL(ingest_kernel<F>, dim3((n + 255) / 256), dim3(256), 0, s, table, inf, n);
 }
-void l_precompute(hipStream_t s, char* table, size_t n, int c, int W) {
-  hipLaunchKernelGGL(precompute_kernel<F>, dim3((n + 127) / 128), dim3(128), 0, s, table, n, c, W);
+void l_precompute(hipStream_t s, char* table, size_t n, int c, int W, int wide) {
+  hipLaunchKernelGGL(precompute_kernel<F>, dim3((n + 127) / 128), dim3(128), 0, s, table, n, c, W, wide);
 }
 void l_combine(hipStream_t s, const uint32_t* long_list, const uint32_t* n_long_dev, const uint32_t* toff,
                const char* partial, char* buckets) {

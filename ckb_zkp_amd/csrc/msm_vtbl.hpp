@@ -34,7 +34,7 @@ struct MsmVtbl {
   size_t bucket_bytes;         // one bucket / partial / pyramid point (unsaturated XYZZ layout, bucket_dev.hpp)
   int scalar_bits;
   void (*ingest)(hipStream_t, char* table, const uint8_t* inf, size_t n);
-  void (*precompute)(hipStream_t, char* table, size_t n, int c, int W);
+  void (*precompute)(hipStream_t, char* table, size_t n, int c, int W, int wide);
   // one lane per TASK (<= MSM_TASK_CAP consecutive entries of one bucket, tasks ordered by length);
   // dst < 0x80000000: bucket index (single-task bucket), else partial slot (dst & 0x7fffffff)
   void (*accumulate)(hipStream_t, const char* table, const uint32_t* vals, const uint32_t* order,
