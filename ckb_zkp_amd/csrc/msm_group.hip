@@ -119,9 +119,11 @@ __global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ ba
   if (threadIdx.x == 0) acc.store(partial + (size_t)blockIdx.x * BkPoint<F>::BYTES);
 }
 
-// Buckets split into a handful of tasks (the common case: the thinly populated top window gives ~77 entries = 2
-// tasks per bucket) are folded by ONE lane each; only genuinely long buckets (skewed scalars) get a whole wave.
-constexpr uint32_t COMBINE_SMALL = 8;
+// Buckets split into up to COMBINE_SMALL tasks are folded by ONE lane each (64 buckets per wave-addition); only genuinely long
+// buckets (skewed scalars, or MSMs far beyond 2^24 points) get a whole wave, whose LDS tree spends ~4 wave-additions on the
+// ten additions of an 11-task bucket.  At 2^24 with balanced windows half of the 2^19 buckets hold 11 tasks: with the
+// threshold at 8 they all took the wave path and the G1 MSMs lost 7-9 ms each.
+constexpr uint32_t COMBINE_SMALL = 32;
 template <class F>
 __global__ __launch_bounds__(256) void combine_small_kernel(const uint32_t* __restrict__ long_list,
                                                             const uint32_t* __restrict__ n_long_dev,

@@ -342,7 +342,8 @@ def test_msm_reduction_pyramid_exceptional_cases(ctx, curve, group):
 
 
 @pytest.mark.parametrize("curve,group,log_n,distinct", [("bn254", 2, 18, 256), ("bn254", 1, 18, 256), ("bn254", 2, 19, 8192),
-                                                         ("bls12_381", 2, 16, 64), ("bn254", 2, 20, 2048), ("bn254", 2, 22, 4096), ("bn254", 1, 22, 4096)])
+                                                         ("bls12_381", 2, 16, 64), ("bn254", 2, 20, 2048), ("bn254", 2, 22, 4096), ("bn254", 1, 22, 4096),
+                                                         ("bn254", 2, 23, 2500), ("bn254", 1, 23, 2500)])   # > 32 tasks per bucket, > 2048 such buckets: every wave of combine_kernel walks two
 def test_msm_many_long_buckets(ctx, curve, group, log_n, distinct):
     """Hundreds / thousands of buckets that are each split into many tasks (what the lowest buckets of a 2^24-point MSM look
     like: the short top window piles ~1500 entries onto each of them): scalars drawn from `distinct` small values, so
