@@ -95,6 +95,7 @@ struct MsmWorkspace {
   bool own_stream = false;
   hipEvent_t done = nullptr;
   hipEvent_t sorted = nullptr;     // recorded when the bucket sort + task schedule of the current MSM are complete
+  hipEvent_t l1_done = nullptr;    // recorded when the level-1 pass (entries scattered into bins) of the current MSM is complete
   DevBuf keys, vals, keys2, vals2, sort_tmp, offsets, buckets, tmp, out, sched, scan_tmp, scan_tmp2, partial, redo;
 };
 struct Groth16Timing {

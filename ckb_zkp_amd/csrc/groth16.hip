@@ -50,6 +50,7 @@ struct zkp_groth16_pk {
   uint64_t hA = 0, hB1 = 0, hB2 = 0, hH = 0, hL = 0;
   bool share_b_sort = false;     // b_g1_query / b_g2_query: same length, window configuration and identity pattern
   bool share_al_sort = false;    // L (stored index-aligned with z) reuses A's bucket sort: same scalars, same identity pattern
+  bool share_l1 = false;         // A, B2 (+B1) and L share ONE level-1 sort pass over z (each filters its identities at level 2)
   // Base-sharded key (BASELINE configs[4]): this rank holds elements [q_lo, q_lo + q_n) of every
   // (extended) query; world == 0 means the whole key.  Index order: A, B1, B2, H, L.
   int shard_rank = 0, shard_world = 0;
@@ -270,9 +271,34 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
       }
       pk->share_al_sort = on && same && differ <= fA.size() / 16 && bases_same_shape(ctx, pk->hL, pk->hA) && pk->q_n[0] > 0;
       if (pk->share_al_sort && differ) bases_set_sort_flags(ctx, pk->hA, both.data(), both.size());
+      // One level-1 pass over z for A, B2 (whose sort B1 reuses) and L: the digit scan, the (bin, tile) counts and the scatter
+      // into bins are done once, by A, over the bases that are NOT the identity in all three queries; every query then
+      // runs its own level-2 sort and drops its own identities there (bit mask over the table index, bases_set_filter), so
+      // each accumulate kernel still sees exactly its own entries.  Two of the four digit scans of a proof disappear
+      // (ZKP_SHARE_L1=0 disables it).
+      static const bool on_l1 = !(getenv("ZKP_SHARE_L1") && atoi(getenv("ZKP_SHARE_L1")) == 0);
+      const bool aligned = fA.size() == fL.size() && fA.size() == fB2.size() && pk->q_lo[0] == pk->q_lo[4] &&
+                           pk->q_lo[0] == pk->q_lo[2] && pk->q_n[0] > 0;
+      if (on_l1 && aligned && !pk->share_al_sort && pk->share_b_sort && bases_same_shape(ctx, pk->hL, pk->hA) &&
+          bases_same_shape(ctx, pk->hB1, pk->hA)) {
+        // (hB2 is a G2 table: same n, window configuration checked through hB1 / share_b_sort)
+        std::vector<uint8_t> all(fA.size());
+        bool dA = false, dB = false, dL = false;
+        for (size_t k = 0; k < fA.size(); k++) {
+          all[k] = fA[k] & fB2[k] & fL[k];
+          dA |= fA[k] != all[k];
+          dB |= fB2[k] != all[k];
+          dL |= fL[k] != all[k];
+        }
+        bases_set_sort_flags(ctx, pk->hA, all.data(), all.size());
+        if (dA) bases_set_filter(ctx, pk->hA, fA.data(), fA.size());
+        if (dB) bases_set_filter(ctx, pk->hB2, fB2.data(), fB2.size());
+        if (dL) bases_set_filter(ctx, pk->hL, fL.data(), fL.size());
+        pk->share_l1 = true;
+      }
       if (getenv("ZKP_DEBUG_MSM"))
-        fprintf(stderr, "[groth16] A/L sort sharing: %d (flags differ at %zu of %zu bases), B1/B2: %d\n", (int)pk->share_al_sort,
-                differ, fA.size(), (int)pk->share_b_sort);
+        fprintf(stderr, "[groth16] A/L sort sharing: %d (flags differ at %zu of %zu bases), B1/B2: %d, shared level 1: %d\n",
+                (int)pk->share_al_sort, differ, fA.size(), (int)pk->share_b_sort, (int)pk->share_l1);
     }
   }
   uint32_t* consts = pk->consts.as<uint32_t>(64);
@@ -417,12 +443,12 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   // ZKP_SINGLE_STREAM=1: one stream per proof (no fan-out inside a proof); concurrency then comes from the lanes only
   static const bool single_stream = getenv("ZKP_SINGLE_STREAM") && atoi(getenv("ZKP_SINGLE_STREAM")) != 0;
   const bool fan = !prof && !single_stream;
-  auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n, int w, int sort_src = -1) {
+  auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n, int w, int sort_src = -1, int l1_src = -1) {
     float ms = 0.f, ms_sc = 0.f;
     uint64_t e = 0;
     tic();
     msm_run(ctx, handle, 0, sc, n, true, nullptr, res + idx * slot, prof ? &ms : nullptr, &e, fan ? w : 0,
-            fan ? sort_src : -1, prof ? &ms_sc : nullptr);
+            fan ? sort_src : -1, prof ? &ms_sc : nullptr, fan ? l1_src : -1);
     toc(&tm.ms_msm[idx]);
     acc_ms += ms;
     ent += e;
@@ -446,11 +472,14 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
       // Stream plan (round 2; default for single proofs AND the pipelined batch — measured 113.6 vs 111.2 proofs/s and 11.0 vs
       // 11.9 ms single-proof latency against the round-1 plan below, which ZKP_LATENCY_PLAN=0 restores):
       //   ws2: B2 | ws1: A -> L | ws3: B1 (B2's sort), then s*g_a + r*g1_b as soon as A exists | main: witness_map -> H
-      run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2);
+      // (A is enqueued first: with a shared level-1 pass B2's stream waits on an event that A's stream must have recorded)
+      const int l1 = pk->share_l1 ? 1 : -1;
+      if (!pk->share_l1) run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2);
       run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1);
       ZKP_HIP(hipEventRecord(ctx->cur->ev_a, ctx->cur->ws[1].stream));
+      if (pk->share_l1) run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2, -1, l1);
       run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 3, pk->share_b_sort ? 2 : -1);
-      run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 1, pk->share_al_sort ? 1 : -1);   // A's sort, still in this workspace
+      run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 1, pk->share_al_sort ? 1 : -1, l1);   // A's sort / level-1 pass, still in this workspace
       if (!partial_out) {
         ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_a, 0));
         v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, proof_dev, flags_dev);

@@ -35,7 +35,7 @@ int bases_group(zkp_ctx* ctx, uint64_t handle);
 // runs on workspace `ws` (its stream + scratch); does not synchronise unless out_xyz_host != nullptr
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
              uint64_t* out_xyz_host, void* out_dev_xyzz = nullptr, float* ms_accumulate = nullptr,
-             uint64_t* n_entries = nullptr, int ws = 0, int sort_src = -1, float* ms_scan = nullptr);
+             uint64_t* n_entries = nullptr, int ws = 0, int sort_src = -1, float* ms_scan = nullptr, int l1_src = -1);
 // bench_kern.hip: sustained rate (1e9 products/s) of the library's Montgomery multipliers; field 0 = Fr, 1 = Fq
 double bench_mulmod(zkp_ctx* ctx, int curve, int field, bool unsaturated);
 // sort_src >= 0: reuse the bucket sort + task schedule that workspace `sort_src` of the same lane computed for the SAME
@@ -44,6 +44,10 @@ bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2);
 // flags (n bytes, host) the digit scan of `handle` uses instead of the entry's own identity flags when it sorts for a group
 // of MSMs over the same scalars (a point is dropped only if it is the identity in every member)
 void bases_set_sort_flags(zkp_ctx* ctx, uint64_t handle, const uint8_t* flags_host, size_t n);
+// l1_src (msm_run): workspace of the same lane whose LEVEL-1 sort output (entries of a group of queries over the same scalars,
+// scattered into bins) this MSM shares; it then runs its own level 2 and drops its own identities there:
+// drop_host[i] != 0 = base i is the identity in this query although the group's scan keeps it
+void bases_set_filter(zkp_ctx* ctx, uint64_t handle, const uint8_t* drop_host, size_t n);
 void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* offsets, const uint64_t* const* scalars_dev,
                    const size_t* ns, bool montgomery, uint64_t* out_xyz_host);
 void msm_run_multi(zkp_ctx* ctx, size_t count, const uint64_t* handles, const size_t* offsets,

@@ -67,10 +67,14 @@ struct BasesEntry {
   // and L share one sort of z): a point is skipped by the scan only if it is the identity in EVERY sharing query; each
   // MSM's own identities are (0, 0) in its table and are skipped by its accumulate kernel.
   uint8_t* sort_inf = nullptr;
+  // Optional bit mask over the table index space (bit w * n + i set = base i is the identity in THIS query): applied by the
+  // level-2 sort when the level-1 pass was shared with queries that keep base i (bases_set_filter)
+  uint32_t* filter = nullptr;
   ~BasesEntry() {
     if (owns && table) (void)hipFree(table);
     if (owns && inf) (void)hipFree(inf);
     if (sort_inf) (void)hipFree(sort_inf);
+    if (filter) (void)hipFree(filter);
   }
 };
 
@@ -156,6 +160,24 @@ void bases_set_sort_flags(zkp_ctx* ctx, uint64_t handle, const uint8_t* flags_ho
   if (!flags_host || n == 0) return;
   if (hipMalloc(&e->sort_inf, n) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
   ZKP_HIP(hipMemcpyAsync(e->sort_inf, flags_host, n, hipMemcpyHostToDevice, ctx->cur->stream));
+  ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
+}
+void bases_set_filter(zkp_ctx* ctx, uint64_t handle, const uint8_t* drop_host, size_t n) {
+  auto e = get_bases(ctx, handle);
+  ZKP_REQUIRE(n == e->n, ZKP_ERR_BAD_ARG);
+  if (e->filter) (void)hipFree(e->filter);
+  e->filter = nullptr;
+  if (!drop_host || n == 0) return;
+  const size_t bits = (size_t)e->W * n, words = (bits + 31) / 32;
+  std::vector<uint32_t> m(words, 0);
+  for (int w = 0; w < e->W; w++)
+    for (size_t i = 0; i < n; i++)
+      if (drop_host[i]) {
+        const size_t b = (size_t)w * n + i;
+        m[b >> 5] |= 1u << (b & 31);
+      }
+  if (hipMalloc(&e->filter, words * 4) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+  ZKP_HIP(hipMemcpyAsync(e->filter, m.data(), words * 4, hipMemcpyHostToDevice, ctx->cur->stream));
   ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
 }
 bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2) {
@@ -362,7 +384,8 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
                                                                     uint32_t nblocks, int L,
                                                                     uint32_t* __restrict__ vout,
                                                                     uint32_t* __restrict__ start,
-                                                                    uint32_t* __restrict__ end) {
+                                                                    uint32_t* __restrict__ end,
+                                                                    const uint32_t* __restrict__ filter) {
   extern __shared__ uint32_t sm[];                     // [nk] counters / cursors, then [SORT_BIN_STAGE] staged values
   __shared__ uint32_t pre[SORT_BIN_THREADS];
   const uint32_t nk = 1u << L;
@@ -373,7 +396,15 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
   const bool staged = hi - lo <= SORT_BIN_STAGE;       // block-uniform
   for (uint32_t i = t; i < nk; i += T) cnt[i] = 0;
   __syncthreads();
-  for (uint32_t i = lo + t; i < hi; i += T) atomicAdd(&cnt[(uint32_t)(kv[i] >> 32)], 1u);
+  // filter (optional): drop the entries whose base is the identity in this query (level 1 was shared, BasesEntry::filter)
+  auto dropped = [&](uint64_t x) {
+    const uint32_t v = (uint32_t)x & 0x7fffffffu;
+    return filter && ((filter[v >> 5] >> (v & 31)) & 1u);
+  };
+  for (uint32_t i = lo + t; i < hi; i += T) {
+    const uint64_t x = kv[i];
+    if (!dropped(x)) atomicAdd(&cnt[(uint32_t)(x >> 32)], 1u);
+  }
   __syncthreads();
   // exclusive scan of the nk counters: `per` consecutive counters per thread + Hillis-Steele over the partials
   {
@@ -407,6 +438,7 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
   __syncthreads();
   for (uint32_t i = lo + t; i < hi; i += T) {
     const uint64_t x = kv[i];
+    if (dropped(x)) continue;
     uint32_t pos = atomicAdd(&cnt[(uint32_t)(x >> 32)], 1u);
     if (staged) stage[pos] = (uint32_t)x;
     else vout[lo + pos] = (uint32_t)x;                  // oversized bin (skewed scalars): direct scatter
@@ -513,13 +545,13 @@ __global__ void sched_check_kernel(const uint32_t* toff, const uint32_t* long_li
 
 static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, const uint64_t* scalars_dev, size_t n,
                           bool montgomery, uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate,
-                          uint64_t* n_entries, int ws_idx, int sort_src, float* ms_scan);
+                          uint64_t* n_entries, int ws_idx, int sort_src, float* ms_scan, int l1_src = -1);
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
              uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries, int ws_idx,
-             int sort_src, float* ms_scan) {
+             int sort_src, float* ms_scan, int l1_src) {
   auto be = get_bases(ctx, handle);
   msm_run_entry(ctx, be.get(), offset, scalars_dev, n, montgomery, out_xyz_host, out_dev_xyzz, ms_accumulate, n_entries,
-                ws_idx, sort_src, ms_scan);
+                ws_idx, sort_src, ms_scan, l1_src);
 }
 
 // Reduction plan of the variable-base mode (per (c, W), cached in the context): block descriptors for the two
@@ -566,7 +598,7 @@ static VarPlan& var_plan(zkp_ctx* ctx, int c, int W, hipStream_t st) {
 
 static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, const uint64_t* scalars_dev, size_t n,
                           bool montgomery, uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate,
-                          uint64_t* n_entries, int ws_idx, int sort_src, float* ms_scan) {
+                          uint64_t* n_entries, int ws_idx, int sort_src, float* ms_scan, int l1_src) {
   const MsmVtbl* vt = be->vt;
   MsmWorkspace& ws = ctx->cur->ws[ws_idx];
   // sort_src: workspace whose sorted entries + task schedule this MSM reuses (same scalars, window configuration and identity
@@ -593,8 +625,14 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     const uint32_t nb = 1u << kbits;                                   // all buckets
     const size_t E = n * (size_t)W;
     ZKP_REQUIRE(E < 2147483000ull, ZKP_ERR_BAD_ARG);
+    // l1_src >= 0 (and no full reuse): the level-1 pass over these scalars — digit scan, (bin, tile) counts, scatter into bins —
+    // was run by workspace l1_src of this lane for a GROUP of queries (it dropped only the bases that are the identity in all of
+    // them); this MSM runs its own level 2 on that list and filters its own identities there (BasesEntry::filter).
+    // l1_src == ws_idx: by the MSM that ran on this workspace just before.
+    const bool l1_reuse = !reuse && l1_src >= 0;
+    MsmWorkspace& lw = l1_reuse ? ctx->cur->ws[l1_src] : sw;           // owner of the level-1 output
     uint32_t* vals = sw.vals.as<uint32_t>(E);                        // values grouped by bucket (level-2 output)
-    uint64_t* kv = sw.keys2.as<uint64_t>(E);                         // level-1 output: (low key, val) pairs
+    uint64_t* kv = lw.keys2.as<uint64_t>(E);                         // level-1 output: (low key, val) pairs
     const uint32_t* sc = reinterpret_cast<const uint32_t*>(scalars_dev);
     const int mont = montgomery ? 1 : 0;
     // K6: group entries by bucket (two-level counting sort); sorted values land back in `vals`
@@ -612,16 +650,22 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     while ((n + tile - 1) / tile > 1536) tile += 256;
     const uint32_t nblocks = (uint32_t)((n + tile - 1) / tile);
     const size_t hist_n = (size_t)nbins1 * nblocks + 1;                // + total (== number of non-zero digits)
-    uint32_t* hist = sw.sort_tmp.as<uint32_t>(2 * hist_n);
+    uint32_t* hist = lw.sort_tmp.as<uint32_t>(2 * hist_n);
     uint32_t* offs = hist + hist_n;
     uint32_t* start = sw.offsets.as<uint32_t>(2 * (size_t)nb);
     uint32_t* end = start + nb;
-    const uint8_t* scan_inf = be->sort_inf ? be->sort_inf : be->inf;     // see BasesEntry::sort_inf
-    if (reuse && sort_src != ws_idx) ZKP_HIP(hipStreamWaitEvent(st, sw.sorted, 0));
-    else ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
-    const bool timed_scan = ms_scan && ctx->profiling && !reuse;      // K5 "scalar scan": histogram pass + count scan + scatter pass
-    if (timed_scan) ZKP_HIP(hipEventRecord(ctx->ev2, st));
+    // see BasesEntry::sort_inf; a profiled (stand-alone, timed) MSM scans with its own flags so that its entry count is exact
+    const uint8_t* scan_inf = be->sort_inf && !ctx->profiling ? be->sort_inf : be->inf;
     if (reuse) {
+      if (sort_src != ws_idx) ZKP_HIP(hipStreamWaitEvent(st, sw.sorted, 0));
+    } else if (l1_reuse) {
+      if (l1_src != ws_idx) ZKP_HIP(hipStreamWaitEvent(st, lw.l1_done, 0));
+    } else {
+      ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
+    }
+    const bool timed_scan = ms_scan && ctx->profiling && !reuse && !l1_reuse;      // K5 "scalar scan": histogram pass + count scan + scatter pass
+    if (timed_scan) ZKP_HIP(hipEventRecord(ctx->ev2, st));
+    if (reuse || l1_reuse) {
     } else if (be->curve == ZKP_BN254) {
       hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
                          wide, nb_w, LB, nbins1, hist, nblocks, tile, var);
@@ -640,9 +684,10 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       ZKP_HIP(hipEventSynchronize(ctx->ev3));
       ZKP_HIP(hipEventElapsedTime(ms_scan, ctx->ev2, ctx->ev3));
     }
+    if (!reuse && !l1_reuse) ZKP_HIP(hipEventRecord(ws.l1_done, st));
     if (!reuse)
       hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(SORT_BIN_THREADS), ((size_t)4 << LB) + 4 * (size_t)SORT_BIN_STAGE, st,
-                         kv, offs, nblocks, LB, vals, start, end);
+                         kv, offs, nblocks, LB, vals, start, end, be->filter);
     uint32_t* const sorted_vals = vals;
     // K7 scheduling: buckets -> tasks (<= CAP entries), ordered by length
     const uint32_t max_tasks = nb + (uint32_t)(E / MSM_TASK_CAP) + 1;
