@@ -273,7 +273,7 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
       if (pk->share_al_sort && differ) bases_set_sort_flags(ctx, pk->hA, both.data(), both.size());
       // One level-1 pass over z for A, B2 (whose sort B1 reuses) and L: the digit scan, the (bin, tile) counts and the scatter
       // into bins are done once, by A, over the bases that are NOT the identity in all three queries; every query then
-      // runs its own level-2 sort and drops its own identities there (bit mask over the table index, bases_set_filter), so
+      // runs its own level-2 sort and drops its own identities there (three flag bits in the top of every entry, bases_set_group), so
       // each accumulate kernel still sees exactly its own entries.  Two of the four digit scans of a proof disappear
       // (ZKP_SHARE_L1=0 disables it).
       static const bool on_l1 = !(getenv("ZKP_SHARE_L1") && atoi(getenv("ZKP_SHARE_L1")) == 0);
@@ -282,18 +282,16 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
       if (on_l1 && aligned && !pk->share_al_sort && pk->share_b_sort && bases_same_shape(ctx, pk->hL, pk->hA) &&
           bases_same_shape(ctx, pk->hB1, pk->hA)) {
         // (hB2 is a G2 table: same n, window configuration checked through hB1 / share_b_sort)
-        std::vector<uint8_t> all(fA.size());
-        bool dA = false, dB = false, dL = false;
+        std::vector<uint8_t> all(fA.size()), member(fA.size());
         for (size_t k = 0; k < fA.size(); k++) {
           all[k] = fA[k] & fB2[k] & fL[k];
-          dA |= fA[k] != all[k];
-          dB |= fB2[k] != all[k];
-          dL |= fL[k] != all[k];
+          member[k] = all[k] ? 0 : (uint8_t)((fA[k] ? 1 : 0) | (fB2[k] ? 2 : 0) | (fL[k] ? 4 : 0));
         }
         bases_set_sort_flags(ctx, pk->hA, all.data(), all.size());
-        if (dA) bases_set_filter(ctx, pk->hA, fA.data(), fA.size());
-        if (dB) bases_set_filter(ctx, pk->hB2, fB2.data(), fB2.size());
-        if (dL) bases_set_filter(ctx, pk->hL, fL.data(), fL.size());
+        bases_set_group(ctx, pk->hA, member.data(), member.size());
+        bases_set_filter_bit(ctx, pk->hA, 0);
+        bases_set_filter_bit(ctx, pk->hB2, 1);
+        bases_set_filter_bit(ctx, pk->hL, 2);
         pk->share_l1 = true;
       }
       if (getenv("ZKP_DEBUG_MSM"))

@@ -45,9 +45,11 @@ bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2);
 // of MSMs over the same scalars (a point is dropped only if it is the identity in every member)
 void bases_set_sort_flags(zkp_ctx* ctx, uint64_t handle, const uint8_t* flags_host, size_t n);
 // l1_src (msm_run): workspace of the same lane whose LEVEL-1 sort output (entries of a group of queries over the same scalars,
-// scattered into bins) this MSM shares; it then runs its own level 2 and drops its own identities there:
-// drop_host[i] != 0 = base i is the identity in this query although the group's scan keeps it
-void bases_set_filter(zkp_ctx* ctx, uint64_t handle, const uint8_t* drop_host, size_t n);
+// scattered into bins) this MSM shares; it then runs its own level 2 and drops its own identities there.
+// bases_set_group: on the query that runs the shared pass; member_flags_host[i] bit k = base i is the identity in member k
+// (k < 3) although the group's scan (bases_set_sort_flags) keeps it.  bases_set_filter_bit: a member's k (-1 = none).
+void bases_set_group(zkp_ctx* ctx, uint64_t owner, const uint8_t* member_flags_host, size_t n);
+void bases_set_filter_bit(zkp_ctx* ctx, uint64_t handle, int bit);
 void msm_run_batch(zkp_ctx* ctx, uint64_t handle, size_t count, const size_t* offsets, const uint64_t* const* scalars_dev,
                    const size_t* ns, bool montgomery, uint64_t* out_xyz_host);
 void msm_run_multi(zkp_ctx* ctx, size_t count, const uint64_t* handles, const size_t* offsets,

@@ -67,14 +67,16 @@ struct BasesEntry {
   // and L share one sort of z): a point is skipped by the scan only if it is the identity in EVERY sharing query; each
   // MSM's own identities are (0, 0) in its table and are skipped by its accumulate kernel.
   uint8_t* sort_inf = nullptr;
-  // Optional bit mask over the table index space (bit w * n + i set = base i is the identity in THIS query): applied by the
-  // level-2 sort when the level-1 pass was shared with queries that keep base i (bases_set_filter)
-  uint32_t* filter = nullptr;
+  // Shared level-1 pass (bases_set_group): on the OWNER of the pass, group_flags[i] bit k = base i is the identity in member k
+  // of the group although the group's scan keeps it; the scatter stores the three bits in the top of each 8-byte entry.  On
+  // every member, filter_bit = its k: its level-2 sort drops the entries whose bit k is set.
+  uint8_t* group_flags = nullptr;
+  int filter_bit = -1;
   ~BasesEntry() {
     if (owns && table) (void)hipFree(table);
     if (owns && inf) (void)hipFree(inf);
     if (sort_inf) (void)hipFree(sort_inf);
-    if (filter) (void)hipFree(filter);
+    if (group_flags) (void)hipFree(group_flags);
   }
 };
 
@@ -162,23 +164,19 @@ void bases_set_sort_flags(zkp_ctx* ctx, uint64_t handle, const uint8_t* flags_ho
   ZKP_HIP(hipMemcpyAsync(e->sort_inf, flags_host, n, hipMemcpyHostToDevice, ctx->cur->stream));
   ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
 }
-void bases_set_filter(zkp_ctx* ctx, uint64_t handle, const uint8_t* drop_host, size_t n) {
-  auto e = get_bases(ctx, handle);
+void bases_set_group(zkp_ctx* ctx, uint64_t owner, const uint8_t* member_flags_host, size_t n) {
+  auto e = get_bases(ctx, owner);
   ZKP_REQUIRE(n == e->n, ZKP_ERR_BAD_ARG);
-  if (e->filter) (void)hipFree(e->filter);
-  e->filter = nullptr;
-  if (!drop_host || n == 0) return;
-  const size_t bits = (size_t)e->W * n, words = (bits + 31) / 32;
-  std::vector<uint32_t> m(words, 0);
-  for (int w = 0; w < e->W; w++)
-    for (size_t i = 0; i < n; i++)
-      if (drop_host[i]) {
-        const size_t b = (size_t)w * n + i;
-        m[b >> 5] |= 1u << (b & 31);
-      }
-  if (hipMalloc(&e->filter, words * 4) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
-  ZKP_HIP(hipMemcpyAsync(e->filter, m.data(), words * 4, hipMemcpyHostToDevice, ctx->cur->stream));
+  if (e->group_flags) (void)hipFree(e->group_flags);
+  e->group_flags = nullptr;
+  if (!member_flags_host || n == 0) return;
+  if (hipMalloc(&e->group_flags, n) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+  ZKP_HIP(hipMemcpyAsync(e->group_flags, member_flags_host, n, hipMemcpyHostToDevice, ctx->cur->stream));
   ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
+}
+void bases_set_filter_bit(zkp_ctx* ctx, uint64_t handle, int bit) {
+  ZKP_REQUIRE(bit >= -1 && bit < 3, ZKP_ERR_BAD_ARG);
+  get_bases(ctx, handle)->filter_bit = bit;
 }
 bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2) {
   auto a = get_bases(ctx, h1), b = get_bases(ctx, h2);
@@ -347,7 +345,8 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
                                                            int montgomery, size_t ntab, int c, int W, int wide, uint32_t nb,
                                                            int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
                                                            uint32_t nblocks, uint32_t tile,
-                                                           uint64_t* __restrict__ kv, int var) {   // (low key << 32) | val
+                                                           uint64_t* __restrict__ kv, int var,
+                                                           const uint8_t* __restrict__ group_flags) {   // (low key << 32) | val
   __shared__ uint32_t cur[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i < nbins1; i += 256) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
   __syncthreads();
@@ -356,6 +355,8 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
     size_t i = (size_t)blockIdx.x * tile + rep * 256 + threadIdx.x;
     if (i < n && !(inf && inf[offset + i])) {
       DigitIter it = load_scalar<FrP>(scalars, i, montgomery);
+      // shared level-1 pass: bit 61 + k of every entry of this base = "identity in member k of the group" (sort_bin_kernel)
+      const uint64_t gbits = group_flags ? (uint64_t)(group_flags[offset + i] & 7u) << 61 : 0;
       for (int w = 0; w < W; w++) {
         uint32_t key, neg;
         it.next(w, c, wide, nb, key, neg);
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
           const uint32_t fk = var ? ((uint32_t)w << (c - 1)) | key : key;     // variable-base: one bucket set per window
           uint32_t pos = atomicAdd(&cur[fk >> L], 1u);
           uint32_t val = (uint32_t)((var ? (size_t)0 : (size_t)w * ntab) + offset + i) | (neg << 31);
-          kv[pos] = ((uint64_t)(fk & lmask) << 32) | val;   // one 8-B store per entry
+          kv[pos] = gbits | ((uint64_t)(fk & lmask) << 32) | val;   // one 8-B store per entry
         }
       }
     }
@@ -384,8 +385,7 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
                                                                     uint32_t nblocks, int L,
                                                                     uint32_t* __restrict__ vout,
                                                                     uint32_t* __restrict__ start,
-                                                                    uint32_t* __restrict__ end,
-                                                                    const uint32_t* __restrict__ filter) {
+                                                                    uint32_t* __restrict__ end, int drop_bit) {
   extern __shared__ uint32_t sm[];                     // [nk] counters / cursors, then [SORT_BIN_STAGE] staged values
   __shared__ uint32_t pre[SORT_BIN_THREADS];
   const uint32_t nk = 1u << L;
@@ -396,14 +396,13 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
   const bool staged = hi - lo <= SORT_BIN_STAGE;       // block-uniform
   for (uint32_t i = t; i < nk; i += T) cnt[i] = 0;
   __syncthreads();
-  // filter (optional): drop the entries whose base is the identity in this query (level 1 was shared, BasesEntry::filter)
-  auto dropped = [&](uint64_t x) {
-    const uint32_t v = (uint32_t)x & 0x7fffffffu;
-    return filter && ((filter[v >> 5] >> (v & 31)) & 1u);
-  };
+  // drop_bit >= 0: the level-1 pass was shared by a group of queries; entries whose base is the identity in THIS query carry
+  // bit 61 + drop_bit (sort_scatter_kernel) and are dropped here.  The low key sits in bits 32 .. 32 + L - 1.
+  const uint64_t dmask = drop_bit >= 0 ? (uint64_t)1 << (61 + drop_bit) : 0;
+  const uint32_t kmask = nk - 1;
   for (uint32_t i = lo + t; i < hi; i += T) {
     const uint64_t x = kv[i];
-    if (!dropped(x)) atomicAdd(&cnt[(uint32_t)(x >> 32)], 1u);
+    if (!(x & dmask)) atomicAdd(&cnt[(uint32_t)(x >> 32) & kmask], 1u);
   }
   __syncthreads();
   // exclusive scan of the nk counters: `per` consecutive counters per thread + Hillis-Steele over the partials
@@ -438,8 +437,8 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
   __syncthreads();
   for (uint32_t i = lo + t; i < hi; i += T) {
     const uint64_t x = kv[i];
-    if (dropped(x)) continue;
-    uint32_t pos = atomicAdd(&cnt[(uint32_t)(x >> 32)], 1u);
+    if (x & dmask) continue;
+    uint32_t pos = atomicAdd(&cnt[(uint32_t)(x >> 32) & kmask], 1u);
     if (staged) stage[pos] = (uint32_t)x;
     else vout[lo + pos] = (uint32_t)x;                  // oversized bin (skewed scalars): direct scatter
   }
@@ -627,7 +626,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     ZKP_REQUIRE(E < 2147483000ull, ZKP_ERR_BAD_ARG);
     // l1_src >= 0 (and no full reuse): the level-1 pass over these scalars — digit scan, (bin, tile) counts, scatter into bins —
     // was run by workspace l1_src of this lane for a GROUP of queries (it dropped only the bases that are the identity in all of
-    // them); this MSM runs its own level 2 on that list and filters its own identities there (BasesEntry::filter).
+    // them); this MSM runs its own level 2 on that list and drops its own identities there (BasesEntry::filter_bit).
     // l1_src == ws_idx: by the MSM that ran on this workspace just before.
     const bool l1_reuse = !reuse && l1_src >= 0;
     MsmWorkspace& lw = l1_reuse ? ctx->cur->ws[l1_src] : sw;           // owner of the level-1 output
@@ -663,6 +662,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     } else {
       ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
     }
+    const uint8_t* grp = scan_inf == be->sort_inf ? be->group_flags : nullptr;   // group bits only with the group's scan flags
     const bool timed_scan = ms_scan && ctx->profiling && !reuse && !l1_reuse;      // K5 "scalar scan": histogram pass + count scan + scatter pass
     if (timed_scan) ZKP_HIP(hipEventRecord(ctx->ev2, st));
     if (reuse || l1_reuse) {
@@ -671,13 +671,13 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
                          wide, nb_w, LB, nbins1, hist, nblocks, tile, var);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
       hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
-                         be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
+                         be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp);
     } else {
       hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
                          wide, nb_w, LB, nbins1, hist, nblocks, tile, var);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
       hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
-                         be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var);
+                         be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp);
     }
     if (timed_scan) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
@@ -687,7 +687,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     if (!reuse && !l1_reuse) ZKP_HIP(hipEventRecord(ws.l1_done, st));
     if (!reuse)
       hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(SORT_BIN_THREADS), ((size_t)4 << LB) + 4 * (size_t)SORT_BIN_STAGE, st,
-                         kv, offs, nblocks, LB, vals, start, end, be->filter);
+                         kv, offs, nblocks, LB, vals, start, end, (l1_reuse || grp) ? be->filter_bit : -1);
     uint32_t* const sorted_vals = vals;
     // K7 scheduling: buckets -> tasks (<= CAP entries), ordered by length
     const uint32_t max_tasks = nb + (uint32_t)(E / MSM_TASK_CAP) + 1;
