@@ -433,7 +433,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   const size_t slot = v2->xyzz_bytes;                  // uniform slot size
   char* res = reinterpret_cast<char*>(PL.results.get(6 * slot));
   const uint64_t* Sd = reinterpret_cast<const uint64_t*>(S);
-  bool l_done_in_fan = false;
+  bool l_done_in_fan = false, g2_done_in_fan = false;
   float acc_ms = 0.f, scan_ms = 0.f;
   uint64_t ent = 0, scan_bytes = 0, scan_runs = 0;
   // Schedule.  profiling: everything on the main stream, one MSM at a time, with per-phase events.
@@ -476,6 +476,12 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
       run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1);
       ZKP_HIP(hipEventRecord(ctx->cur->ev_a, ctx->cur->ws[1].stream));
       if (pk->share_l1) run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2, -1, l1);
+      // proof.b needs B2 only: its into_affine runs on B2's stream as soon as the MSM is done instead of in the tail of the proof
+      static const bool g2_early = !(getenv("ZKP_G2_EARLY") && atoi(getenv("ZKP_G2_EARLY")) == 0);
+      if (!partial_out && g2_early) {
+        v2->assemble_g2(ctx->cur->ws[2].stream, res, slot, proof_dev, flags_dev, 2 * v1->fN);
+        g2_done_in_fan = true;
+      }
       run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 3, pk->share_b_sort ? 2 : -1);
       run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 1, pk->share_al_sort ? 1 : -1, l1);   // A's sort / level-1 pass, still in this workspace
       if (!partial_out) {
@@ -536,7 +542,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   // proof layout (32-bit words): A = 2*fN1 | B = 2*fN2 | C = 2*fN1
   if (!fan) v1->assemble_g1_part1(st, res, slot, rs, proof_dev, flags_dev);
   v1->assemble_g1_part2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN + 2 * v2->fN);
-  v2->assemble_g2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN);
+  if (!g2_done_in_fan) v2->assemble_g2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN);
   ZKP_HIP(hipGetLastError());
   toc(&tm.ms_assemble);
   const size_t proof_words = 4 * (size_t)v1->fN + 2 * (size_t)v2->fN;
