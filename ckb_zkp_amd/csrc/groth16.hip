@@ -441,6 +441,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   // ZKP_SINGLE_STREAM=1: one stream per proof (no fan-out inside a proof); concurrency then comes from the lanes only
   static const bool single_stream = getenv("ZKP_SINGLE_STREAM") && atoi(getenv("ZKP_SINGLE_STREAM")) != 0;
   const bool fan = !prof && !single_stream;
+  uint32_t* h = nullptr;
   auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n, int w, int sort_src = -1, int l1_src = -1) {
     float ms = 0.f, ms_sc = 0.f;
     uint64_t e = 0;
@@ -462,6 +463,12 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   if (fan) {
     ZKP_HIP(hipEventRecord(ctx->cur->ev_fork, st));                       // S is complete
     for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[w].stream, ctx->cur->ev_fork, 0));
+    // The witness map heads the longest chain of a proof (witness map -> H MSM -> assembly): its launches go out FIRST, before
+    // the ~150 launches of the four other MSMs (0.5 ms of host time): single-proof latency 10.1 -> 9.65 ms (ZKP_WM_FIRST=0: after
+    // them, as in round 1).  Making the other MSMs' accumulate kernels wait for it — a kernel timeline shows machine-filling
+    // accumulates from three streams leaving its kernels few wave slots for milliseconds — was measured too: 10.3 ms, not kept.
+    static const bool wm_first = !(getenv("ZKP_WM_FIRST") && atoi(getenv("ZKP_WM_FIRST")) == 0);
+    if (wm_first) h = witness_map_dev<FrP>(ctx, pk, S);
     static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
     static const int lat_env = [] { const char* e = getenv("ZKP_LATENCY_PLAN"); return e ? atoi(e) : -1; }();
     (void)latency_plan;
@@ -506,7 +513,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     l_done_in_fan = lat || l_own;
   }
   tic();
-  uint32_t* h = witness_map_dev<FrP>(ctx, pk, S);
+  if (!h) h = witness_map_dev<FrP>(ctx, pk, S);
   toc(&tm.ms_witness_map);
   if (!fan) {
     run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 0);
