@@ -786,8 +786,9 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     for (int l = 0; l < L; l++) {
       uint32_t next_off = lvl_off + cnt;
       static const bool top_fused = !(getenv("ZKP_PAIR_TOP") && atoi(getenv("ZKP_PAIR_TOP")) == 0);
-      if (!top_fused || cnt > PAIR_TOP_MAX) vt->pair(st, buckets + (size_t)lvl_off * XB, buckets + (size_t)next_off * XB, cnt / 2);
-      else if (cnt == PAIR_TOP_MAX || l == 0) vt->pair_top(st, buckets + (size_t)lvl_off * XB, cnt);   // this level and all above it
+      static const uint32_t top_max = [] { const char* e = getenv("ZKP_PAIR_TOP_MAX"); uint32_t v = e ? (uint32_t)atoi(e) : PAIR_TOP_MAX; return v < 2 ? PAIR_TOP_MAX : v; }();
+      if (!top_fused || cnt > top_max) vt->pair(st, buckets + (size_t)lvl_off * XB, buckets + (size_t)next_off * XB, cnt / 2);
+      else if (cnt == top_max || l == 0) vt->pair_top(st, buckets + (size_t)lvl_off * XB, cnt);   // this level and all above it
       plan.first_block[l] = blocks;
       plan.off[l] = lvl_off + 1;
       plan.stride[l] = 2;

@@ -67,21 +67,21 @@ __global__ __launch_bounds__(256) void pair_kernel(const char* __restrict__ in, 
   a.store(out + (size_t)k * BkPoint<F>::BYTES);
 }
 
-// The top of the pyramid in ONE launch: the level with `cnt` <= 2 * PAIR_TOP_THREADS entries at `base`, every further level
+// The top of the pyramid in ONE launch: the level with `cnt` <= PAIR_TOP_MAX entries at `base`, every further level
 // directly behind its predecessor (the layout msm.hip uses), down to the root.  One workgroup, a barrier per level: the ~10
 // levels that hold fewer points than the machine has SIMDs cost one dependent addition each either way, but as one packet in
 // the hardware queue instead of ten (streams that share the queue wait behind every packet).
-constexpr int PAIR_TOP_THREADS = PAIR_TOP_MAX / 2;
+constexpr int PAIR_TOP_THREADS = 512;
 template <class F>
 __global__ __launch_bounds__(PAIR_TOP_THREADS) void pair_top_kernel(char* __restrict__ base, uint32_t cnt) {
   __builtin_amdgcn_s_setprio(3);
   char* in = base;
   for (; cnt > 1; cnt >>= 1) {
     char* out = in + (size_t)cnt * BkPoint<F>::BYTES;
-    if (threadIdx.x < cnt / 2) {
-      BkPoint<F> a = BkPoint<F>::load(in + (size_t)(2 * threadIdx.x) * BkPoint<F>::BYTES);
-      a.add(BkPoint<F>::load(in + (size_t)(2 * threadIdx.x + 1) * BkPoint<F>::BYTES));
-      a.store(out + (size_t)threadIdx.x * BkPoint<F>::BYTES);
+    for (uint32_t k = threadIdx.x; k < cnt / 2; k += PAIR_TOP_THREADS) {
+      BkPoint<F> a = BkPoint<F>::load(in + (size_t)(2 * k) * BkPoint<F>::BYTES);
+      a.add(BkPoint<F>::load(in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES));
+      a.store(out + (size_t)k * BkPoint<F>::BYTES);
     }
     __threadfence_block();
     __syncthreads();
