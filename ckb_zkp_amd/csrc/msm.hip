@@ -453,8 +453,8 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
 // CAP+1 bins) so that the 64 lanes of a wave walk runs of (almost) equal length: with Poisson-distributed
 // bucket sizes this turns ~65 % lane utilisation into > 95 %, and it bounds the serial chain of any lane by CAP
 // even for adversarial inputs (all scalars equal) or the thinly populated top window.
-// tmeta layout (uint32): [0] n_long  [1..CAP+1] histogram by length  [128..128+CAP] cursors
-constexpr int TM_NLONG = 0, TM_HIST = 1, TM_CUR = 128, TM_WORDS = 256;
+// tmeta layout (uint32): [0] n_long  [1..CAP+1] histogram by length  [256..256+CAP] cursors
+constexpr int TM_NLONG = 0, TM_HIST = 1, TM_CUR = 256, TM_WORDS = 512;
 
 __global__ void task_count_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nb,
                                   uint32_t* __restrict__ tcount) {
