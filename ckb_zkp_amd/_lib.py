@@ -73,6 +73,13 @@ SIGNATURES = {
     "zkp_version": (C.c_char_p, []),
     "zkp_ctx_create": (C.c_int32, [C.POINTER(vp), C.c_int]),
     "zkp_ctx_destroy": (C.c_int32, [vp]),
+    "zkp_ctx_create_multi": (C.c_int32, [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]),
+    "zkp_ctx_num_devices": (C.c_int32, [vp, C.POINTER(C.c_int32)]),
+    "zkp_ctx_device": (C.c_int32, [vp, C.c_int32, C.POINTER(vp)]),
+    "zkp_groth16_pk_upload_multi": (C.c_int32, [vp, C.POINTER(Groth16PkDesc), C.c_int32, C.POINTER(vp)]),
+    "zkp_groth16_pk_multi_free": (C.c_int32, [vp, vp]),
+    "zkp_groth16_prove_multi": (C.c_int32, [vp, vp, vp, C.c_int32, vp, vp, vp, vp]),
+    "zkp_groth16_prove_batch_multi": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_int32, vp, vp, vp, vp]),
     "zkp_ctx_set_stream": (C.c_int32, [vp, vp]),
     "zkp_ctx_sync": (C.c_int32, [vp]),
     "zkp_dev_alloc": (C.c_int32, [vp, C.c_size_t, C.POINTER(vp)]),

@@ -35,7 +35,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.zkp_ctx_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.zkp_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -331,3 +332,32 @@ def msm_mont_multi_dev(self, jobs) -> list:
     offs = (C.c_size_t * k)(*[j[3] for j in jobs])
     _lib.check(self.lib.zkp_msm_mont_multi_dev(self.h, k, handles, offs, ptrs, ns, _ptr(out), slot), "zkp_msm_mont_multi_dev")
     return [out[i, :3 * b.curve.fq_limbs * (1 if b.group == 1 else 2)].copy() for i, (b, *_) in enumerate(jobs)]
+
+
+class MultiContext(Context):
+    """zkp_ctx_create_multi: ONE process, one context per listed device (ids may repeat on a one-GPU box), the exchange
+    step of the base-sharded prover owned by the library.  The object itself is rank 0's context (usable like any
+    Context); member(k) borrows rank k's."""
+
+    def __init__(self, device_ids):
+        self.lib = _lib.load()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        _lib.check(self.lib.zkp_ctx_create_multi(C.byref(h), ids, len(device_ids)), "zkp_ctx_create_multi")
+        self.h = h
+        self.device = device_ids[0]
+        self.device_ids = list(device_ids)
+        n = C.c_int32()
+        _lib.check(self.lib.zkp_ctx_num_devices(self.h, C.byref(n)), "zkp_ctx_num_devices")
+        assert n.value == len(device_ids)
+
+    @property
+    def num_devices(self) -> int:
+        return len(self.device_ids)
+
+    def member(self, rank: int) -> Context:
+        m = C.c_void_p()
+        _lib.check(self.lib.zkp_ctx_device(self.h, rank, C.byref(m)), "zkp_ctx_device")
+        c = Context.__new__(Context)
+        c.lib, c.h, c.device, c._borrowed = self.lib, m, self.device_ids[rank], True
+        return c

@@ -96,8 +96,58 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
   return ZKP_OK;
 }
 
+int32_t zkp_ctx_create_multi(zkp_ctx** out, const int* device_ids, int n_devices) {
+  if (!out || !device_ids || n_devices < 1 || n_devices > 64) return ZKP_ERR_BAD_ARG;
+  *out = nullptr;
+  zkp_ctx* root = nullptr;
+  int32_t st = zkp_ctx_create(&root, device_ids[0]);
+  if (st != ZKP_OK) return st;
+  root->devs.push_back(root);
+  for (int k = 1; k < n_devices; k++) {
+    zkp_ctx* m = nullptr;
+    st = zkp_ctx_create(&m, device_ids[k]);
+    if (st != ZKP_OK) {
+      (void)zkp_ctx_destroy(root);
+      return st;
+    }
+    root->devs.push_back(m);
+  }
+  // xGMI peer access between distinct devices (hipMemcpyPeerAsync then goes device to device instead of through the host)
+  for (int a = 0; a < n_devices; a++)
+    for (int b = 0; b < n_devices; b++) {
+      if (device_ids[a] == device_ids[b]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, device_ids[a], device_ids[b]) == hipSuccess && can) {
+        (void)hipSetDevice(device_ids[a]);
+        hipError_t e = hipDeviceEnablePeerAccess(device_ids[b], 0);
+        if (e != hipSuccess) (void)hipGetLastError();        // already enabled
+      }
+    }
+  (void)hipSetDevice(device_ids[0]);
+  *out = root;
+  return ZKP_OK;
+}
+int32_t zkp_ctx_num_devices(zkp_ctx* ctx, int32_t* n) {
+  if (!ctx || !n) return ZKP_ERR_BAD_ARG;
+  *n = ctx->devs.empty() ? 1 : (int32_t)ctx->devs.size();
+  return ZKP_OK;
+}
+int32_t zkp_ctx_device(zkp_ctx* ctx, int32_t rank, zkp_ctx** member) {
+  if (!ctx || !member) return ZKP_ERR_BAD_ARG;
+  if (ctx->devs.empty()) {
+    if (rank != 0) return ZKP_ERR_BAD_ARG;
+    *member = ctx;
+    return ZKP_OK;
+  }
+  if (rank < 0 || rank >= (int32_t)ctx->devs.size()) return ZKP_ERR_BAD_ARG;
+  *member = ctx->devs[rank];
+  return ZKP_OK;
+}
+
 int32_t zkp_ctx_destroy(zkp_ctx* ctx) {
   if (!ctx) return ZKP_ERR_BAD_ARG;
+  for (size_t k = 1; k < ctx->devs.size(); k++) (void)zkp_ctx_destroy(ctx->devs[k]);      // members of a multi-device root
+  ctx->devs.clear();
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   ntt_free_tables(ctx);
@@ -397,6 +447,28 @@ int32_t zkp_groth16_fold_assemble_dev(zkp_ctx* ctx, zkp_curve_t curve, const voi
                                       const uint64_t* r, const uint64_t* s, uint64_t* proof, uint8_t* inf) {
   if (!gathered_dev || world < 1 || !r || !s || !proof || !inf) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { groth16_fold_assemble(ctx, curve, gathered_dev, world, r, s, proof, inf); });
+}
+int32_t zkp_groth16_pk_upload_multi(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, int32_t mode, zkp_groth16_pk_multi** out) {
+  if (!ctx || !desc || !out || ctx->devs.empty() || (mode != ZKP_MULTI_SHARD && mode != ZKP_MULTI_REPLICATE)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { *out = groth16_pk_upload_multi(ctx, desc, mode); });
+}
+int32_t zkp_groth16_pk_multi_free(zkp_ctx* ctx, zkp_groth16_pk_multi* pk) {
+  if (!ctx || !pk || ctx->devs.empty()) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_pk_multi_free(ctx, pk); });
+}
+int32_t zkp_groth16_prove_multi(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, const uint64_t* const* z, int32_t z_on_device,
+                                const uint64_t* r, const uint64_t* s, uint64_t* proof, uint8_t* inf) {
+  if (!ctx || !pk || !z || !z[0] || !r || !s || !proof || !inf || ctx->devs.empty()) return ZKP_ERR_BAD_ARG;
+  if (z_on_device)
+    for (size_t k = 0; k < ctx->devs.size(); k++)
+      if (!z[k]) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_prove_multi(ctx, pk, z, z_on_device != 0, r, s, proof, inf); });
+}
+int32_t zkp_groth16_prove_batch_multi(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, size_t count, const uint64_t* const* z,
+                                      int32_t z_on_device, const uint64_t* r, const uint64_t* s, uint64_t* proofs,
+                                      uint8_t* inf) {
+  if (!ctx || !pk || ctx->devs.empty() || (count && (!z || !r || !s || !proofs || !inf))) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_prove_batch_multi(ctx, pk, count, z, z_on_device != 0, r, s, proofs, inf); });
 }
 int32_t zkp_groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk) {
   if (!pk) return ZKP_ERR_BAD_ARG;

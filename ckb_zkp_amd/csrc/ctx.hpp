@@ -140,4 +140,9 @@ struct zkp_ctx {
   uint64_t next_handle = 1;
   zkp_groth16_timing last_timing{};
   std::string last_error;
+  // Single-process multi-GPU (zkp_ctx_create_multi): the ROOT context lists one context per requested device in rank order
+  // (devs[0] == this; device ids may repeat: several ranks on one GPU).  Empty on an ordinary context and on the members.
+  std::vector<zkp_ctx*> devs;
+  // variable-base reduction plans (msm.hip var_plan), owned by the context and released with it
+  std::map<std::pair<int, int>, std::shared_ptr<void>> var_plans;
 };

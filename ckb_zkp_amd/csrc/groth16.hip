@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <string>
 #include <vector>
 
 #include "field_dev.hpp"
@@ -501,7 +503,8 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2);                          // prover.rs:182-184
     run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1);                           // prover.rs:164-167
     run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 1, pk->share_b_sort ? 2 : -1);   // prover.rs:170-177 (B2's bucket sort reused)
-    if (l_own) run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 3, pk->share_al_sort ? 1 : -1);   // prover.rs:189-190 (A's sort reused)
+    // (A's sort is reused only when B1 does not re-sort on the same workspace in the meantime, i.e. when B1 takes B2's sort)
+    if (l_own) run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 3, pk->share_al_sort && pk->share_b_sort ? 1 : -1);   // prover.rs:189-190
     ZKP_HIP(hipEventRecord(ctx->cur->ev_b1, ctx->cur->ws[1].stream));
     // the two dynamic scalar multiplications (s*g_a, r*g1_b) are a ~2 ms single-lane chain each: start them as soon as
     // A and B1 exist so they hide under the remaining MSMs
@@ -770,6 +773,358 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
     throw;
   }
   select(0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-process multi-GPU (BASELINE configs[4]): the caller of `create_proof` (prover.rs:124) is ONE
+// process, so the library owns one context per device (zkp_ctx_create_multi) and the exchange step itself.
+//   shard      every (extended) query is split by index over the devices (rank k keeps 1/n of the window tables); one proof
+//              uses all devices: partial MSMs per device -> partial sums gathered on device 0 over xGMI (peer copies of
+//              n x 1.25 KiB; optionally an RCCL all-gather) -> fold + assembly on device 0.  With >= 3 devices the witness map
+//              is task-split: the three independent chains of r1cs_to_qap.rs:144-162 (A z / B z / C z -> ifft -> coset_fft) run
+//              on devices 0 / 1 / 2, the b and c coset evaluations are gathered on device 0 (pointwise step + coset_ifft), and
+//              every device receives its slice of h for its share of the H MSM.
+//   replicate  full key on every device, independent proofs dealt round-robin, one host thread per device driving that
+//              device's pipelined lanes (zkp_groth16_prove_batch semantics).
+// Everything is enqueued from the calling thread with streams and cross-device events; device ids may repeat (several ranks
+// on ONE GPU: the tests on a one-GPU box), peer copies then degenerate to device-to-device copies.
+}  // namespace zkp
+#include <dlfcn.h>
+
+#include <thread>
+struct zkp_groth16_pk_multi {
+  int mode = 0, curve = 0;
+  std::vector<zkp_groth16_pk*> pk;          // one per device of the root context, rank order
+  std::vector<hipEvent_t> ev_chain, ev_done, ev_h_read;
+  hipEvent_t ev_h = nullptr;
+  void* gathered = nullptr;                 // device 0: n x partials bytes
+  std::vector<void*> gathered_all;          // RCCL exchange: a receive buffer on every device
+  std::vector<void*> partial;               // per device: 5 XYZZ slots
+};
+namespace zkp {
+
+namespace {
+// RCCL all-gather of the partial sums, resolved at run time (no link-time dependency: the host may already have loaded its
+// own librccl).  Opt-in: ZKP_MULTI_EXCHANGE=rccl; needs distinct devices.  Falls back to peer copies when unavailable.
+struct RcclApi {
+  void* lib = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  std::vector<void*> comms;
+  std::vector<int> devices;
+  bool ready(const std::vector<zkp_ctx*>& devs) {
+    std::vector<int> ids;
+    for (zkp_ctx* d : devs) ids.push_back(d->device);
+    if (!comms.empty() && ids == devices) return true;
+    for (size_t i = 0; i < ids.size(); i++)
+      for (size_t j = i + 1; j < ids.size(); j++)
+        if (ids[i] == ids[j]) return false;                         // RCCL refuses duplicate devices
+    if (!lib) {
+      for (const char* name : {"librccl.so", "librccl.so.1"})
+        if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+      if (!lib) return false;
+      CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+      CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+      GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+      GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+      AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+    }
+    if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !AllGather) return false;
+    for (void* c : comms) (void)CommDestroy(c);
+    comms.assign(ids.size(), nullptr);
+    if (CommInitAll(comms.data(), (int)ids.size(), ids.data()) != 0) {
+      comms.clear();
+      return false;
+    }
+    devices = ids;
+    return true;
+  }
+};
+RcclApi& rccl() {
+  static RcclApi* api = new RcclApi();      // never destructed: communicators must not be torn down after the HIP runtime
+  return *api;
+}
+
+void copy_between(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t st) {
+  if (!bytes) return;
+  if (dst_dev == src_dev) ZKP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+  else ZKP_HIP(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st));
+}
+
+// one of the three chains of the witness map (k = 0 / 1 / 2: a / b / c), on ctx's current stream; result in region k of abc
+template <class P>
+void witness_chain(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint32_t* z_dev, int k) {
+  const uint32_t N = (uint32_t)pk->N;
+  uint32_t* abc = pk->lane[ctx->cur_idx].abc.as<uint32_t>(3 * pk->N * 8);
+  uint32_t* buf = abc + (size_t)k * pk->N * 8;
+  hipLaunchKernelGGL(csr_eval_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, ctx->cur->stream, pk->m[k].row_ptr, pk->m[k].col,
+                     pk->m[k].coeff, z_dev, pk->num_constraints, N, pk->num_inputs, k == 0 ? 1 : 0, buf);
+  if (!ntt_ifft_coset_fft(ctx, pk->curve, buf, pk->log_n)) {
+    ntt_run(ctx, pk->curve, buf, pk->log_n, ZKP_NTT_IFFT);
+    ntt_run(ctx, pk->curve, buf, pk->log_n, ZKP_NTT_COSET_FFT);
+  }
+  ZKP_HIP(hipGetLastError());
+}
+// second half of the witness map (pointwise step + coset_ifft) over the three regions of abc; returns h
+template <class P>
+uint32_t* witness_tail(zkp_ctx* ctx, zkp_groth16_pk* pk) {
+  const uint32_t N = (uint32_t)pk->N;
+  uint32_t* a = pk->lane[ctx->cur_idx].abc.as<uint32_t>(3 * pk->N * 8);
+  uint32_t* b = a + pk->N * 8;
+  uint32_t* c = b + pk->N * 8;
+  if (uint32_t* hq = ntt_qap_coset_ifft(ctx, pk->curve, a, b, c, pk->consts.as<uint32_t>(64), pk->log_n)) return hq;
+  hipLaunchKernelGGL(qap_pointwise_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, ctx->cur->stream, a, b, c,
+                     pk->consts.as<uint32_t>(64), N);
+  ntt_run(ctx, pk->curve, a, pk->log_n, ZKP_NTT_COSET_IFFT);
+  ZKP_HIP(hipGetLastError());
+  return a;
+}
+
+template <class FrP>
+void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const* z, bool z_on_device, const uint64_t* r,
+                   const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out) {
+  const int n = (int)root->devs.size();
+  const MsmVtbl* v2 = msm_vtbl(M->curve, 2);
+  const size_t slot = v2->xyzz_bytes, pb = 5 * slot;
+  static const bool split_env = !(getenv("ZKP_MULTI_WM_SPLIT") && atoi(getenv("ZKP_MULTI_WM_SPLIT")) == 0);
+  const bool split = split_env && n >= 3;
+  static const bool want_rccl = getenv("ZKP_MULTI_EXCHANGE") && std::string(getenv("ZKP_MULTI_EXCHANGE")) == "rccl";
+  const bool use_rccl = want_rccl && n > 1 && rccl().ready(root->devs);
+  std::vector<uint32_t*> S(n), h(n, nullptr);
+  std::vector<char*> res(n);
+  // phase 1 — every device: inputs, the four z-MSMs over its slices on the MSM streams, its part of the witness map
+  for (int k = 0; k < n; k++) {
+    zkp_ctx* ctx = root->devs[k];
+    zkp_groth16_pk* pk = M->pk[k];
+    ZKP_HIP(hipSetDevice(ctx->device));
+    ctx->cur = &ctx->lanes[0];
+    ctx->cur_idx = 0;
+    hipStream_t st = ctx->cur->stream;
+    zkp_groth16_pk::PerLane& PL = pk->lane[0];
+    S[k] = PL.S.as<uint32_t>((pk->nz + 4) * 8);
+    uint32_t* rs = PL.proof.as<uint32_t>(1024);
+    res[k] = reinterpret_cast<char*>(PL.results.get(6 * slot));
+    const uint64_t* zk = z_on_device ? z[k] : z[0];
+    ZKP_HIP(hipMemcpyAsync(S[k], zk, pk->nz * 32, z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    ZKP_HIP(hipMemcpyAsync(rs, r, 32, hipMemcpyHostToDevice, st));
+    ZKP_HIP(hipMemcpyAsync(rs + 8, s, 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(scalar_tail_kernel<FrP>, dim3(1), dim3(64), 0, st, S[k] + pk->nz * 8, rs);
+    ZKP_HIP(hipEventRecord(ctx->cur->ev_fork, st));
+    for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[w].stream, ctx->cur->ev_fork, 0));
+    if (!split) h[k] = witness_map_dev<FrP>(ctx, pk, S[k]);
+    else if (k < 3) {
+      witness_chain<FrP>(ctx, pk, S[k], k);
+      ZKP_HIP(hipEventRecord(M->ev_chain[k], st));
+    }
+    const uint64_t* Sd = reinterpret_cast<const uint64_t*>(S[k]);
+    auto run = [&](int idx, uint64_t handle, int w, int sort_src, int l1_src) {
+      msm_run(ctx, handle, 0, Sd + 4 * pk->q_lo[idx], pk->q_n[idx], true, nullptr, res[k] + idx * slot, nullptr, nullptr, w,
+              sort_src, nullptr, l1_src);
+    };
+    const int l1 = pk->share_l1 ? 1 : -1;
+    if (!pk->share_l1) run(2, pk->hB2, 2, -1, -1);
+    run(0, pk->hA, 1, -1, -1);
+    if (pk->share_l1) run(2, pk->hB2, 2, -1, l1);
+    run(1, pk->hB1, 3, pk->share_b_sort ? 2 : -1, -1);
+    run(4, pk->hL, 1, pk->share_al_sort ? 1 : -1, l1);
+  }
+  // phase 2 (task-split witness map) — device 0 gathers b and c, finishes h, every device fetches its slice of h
+  if (split) {
+    zkp_ctx* c0 = root->devs[0];
+    zkp_groth16_pk* p0 = M->pk[0];
+    ZKP_HIP(hipSetDevice(c0->device));
+    hipStream_t st0 = c0->cur->stream;
+    uint32_t* abc0 = p0->lane[0].abc.as<uint32_t>(3 * p0->N * 8);
+    for (int k = 1; k < 3; k++) {
+      zkp_groth16_pk* pk = M->pk[k];
+      const uint32_t* src = pk->lane[0].abc.as<uint32_t>(3 * pk->N * 8) + (size_t)k * pk->N * 8;
+      ZKP_HIP(hipStreamWaitEvent(st0, M->ev_chain[k], 0));
+      copy_between(abc0 + (size_t)k * p0->N * 8, c0->device, src, root->devs[k]->device, p0->N * 32, st0);
+    }
+    h[0] = witness_tail<FrP>(c0, p0);
+    ZKP_HIP(hipEventRecord(M->ev_h, st0));
+    for (int k = 1; k < n; k++) {
+      zkp_ctx* ctx = root->devs[k];
+      zkp_groth16_pk* pk = M->pk[k];
+      ZKP_HIP(hipSetDevice(ctx->device));
+      hipStream_t st = ctx->cur->stream;
+      h[k] = pk->lane[0].abc.as<uint32_t>(3 * pk->N * 8);        // region a of this device (its own chain, if any, is consumed)
+      ZKP_HIP(hipStreamWaitEvent(st, M->ev_h, 0));
+      if (k < 3) ZKP_HIP(hipStreamWaitEvent(st, M->ev_chain[k], 0));
+      copy_between(h[k] + pk->q_lo[3] * 8, ctx->device, h[0] + pk->q_lo[3] * 8, c0->device, pk->q_n[3] * 32, st);
+      ZKP_HIP(hipEventRecord(M->ev_h_read[k], st));
+    }
+  }
+  // phase 3 — every device: H MSM over its slice of h, join, partial sums
+  for (int k = 0; k < n; k++) {
+    zkp_ctx* ctx = root->devs[k];
+    zkp_groth16_pk* pk = M->pk[k];
+    ZKP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->cur->stream;
+    msm_run(ctx, pk->hH, 0, reinterpret_cast<const uint64_t*>(h[k]) + 4 * pk->q_lo[3], pk->q_n[3], true, nullptr,
+            res[k] + 3 * slot, nullptr, nullptr, 0);
+    for (int w = 1; w < zkp_ctx::N_WS; w++) {
+      ZKP_HIP(hipEventRecord(ctx->cur->ws[w].done, ctx->cur->ws[w].stream));
+      ZKP_HIP(hipStreamWaitEvent(st, ctx->cur->ws[w].done, 0));
+    }
+    ZKP_HIP(hipMemcpyAsync(M->partial[k], res[k], pb, hipMemcpyDeviceToDevice, st));
+    ZKP_HIP(hipEventRecord(M->ev_done[k], st));
+  }
+  // phase 4 — exchange (n x 1.25 KiB for BN254: latency-bound on any topology) + fold + assembly on device 0
+  zkp_ctx* c0 = root->devs[0];
+  const void* gathered = M->gathered;
+  if (use_rccl) {
+    RcclApi& R = rccl();
+    ZKP_REQUIRE(R.GroupStart() == 0, ZKP_ERR_DEVICE);
+    for (int k = 0; k < n; k++) {
+      ZKP_HIP(hipSetDevice(root->devs[k]->device));
+      ZKP_REQUIRE(R.AllGather(M->partial[k], M->gathered_all[k], pb, /*ncclUint8*/ 1, R.comms[k], root->devs[k]->cur->stream) == 0,
+                  ZKP_ERR_DEVICE);
+    }
+    ZKP_REQUIRE(R.GroupEnd() == 0, ZKP_ERR_DEVICE);
+    gathered = M->gathered_all[0];
+    ZKP_HIP(hipSetDevice(c0->device));
+  } else {
+    ZKP_HIP(hipSetDevice(c0->device));
+    hipStream_t st0 = c0->cur->stream;
+    for (int k = 0; k < n; k++) {
+      if (k) ZKP_HIP(hipStreamWaitEvent(st0, M->ev_done[k], 0));
+      copy_between((char*)M->gathered + (size_t)k * pb, c0->device, M->partial[k], root->devs[k]->device, pb, st0);
+    }
+  }
+  if (split)                                     // h on device 0 must outlive the slice reads of the other devices
+    for (int k = 1; k < n; k++) ZKP_HIP(hipStreamWaitEvent(c0->cur->stream, M->ev_h_read[k], 0));
+  groth16_fold_assemble(c0, M->curve, gathered, n, r, s, proof_out, inf_out);        // synchronises device 0's stream
+  for (int k = 1; k < n; k++) {                  // the next call reuses every device's buffers
+    ZKP_HIP(hipSetDevice(root->devs[k]->device));
+    ZKP_HIP(hipStreamSynchronize(root->devs[k]->cur->stream));
+  }
+  ZKP_HIP(hipSetDevice(c0->device));
+}
+}  // namespace
+
+zkp_groth16_pk_multi* groth16_pk_upload_multi(zkp_ctx* root, const zkp_groth16_pk_desc* d, int mode) {
+  ZKP_REQUIRE(!root->devs.empty() && (mode == 0 || mode == 1), ZKP_ERR_BAD_ARG);
+  const int n = (int)root->devs.size();
+  std::unique_ptr<zkp_groth16_pk_multi> M(new zkp_groth16_pk_multi());
+  M->mode = mode;
+  M->curve = d->curve;
+  try {
+    for (int k = 0; k < n; k++) {
+      zkp_ctx* ctx = root->devs[k];
+      ZKP_HIP(hipSetDevice(ctx->device));
+      M->pk.push_back(mode == 0 ? groth16_pk_upload(ctx, d, k, n) : groth16_pk_upload(ctx, d, 0, 0));
+      hipEvent_t e;
+      ZKP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      M->ev_chain.push_back(e);
+      ZKP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      M->ev_done.push_back(e);
+      ZKP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      M->ev_h_read.push_back(e);
+      void* p = nullptr;
+      if (hipMalloc(&p, groth16_partials_bytes(d->curve)) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+      M->partial.push_back(p);
+      p = nullptr;
+      if (hipMalloc(&p, (size_t)n * groth16_partials_bytes(d->curve)) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+      M->gathered_all.push_back(p);
+    }
+    ZKP_HIP(hipSetDevice(root->device));
+    ZKP_HIP(hipEventCreateWithFlags(&M->ev_h, hipEventDisableTiming));
+    M->gathered = M->gathered_all[0];
+  } catch (...) {
+    groth16_pk_multi_free(root, M.release());
+    throw;
+  }
+  return M.release();
+}
+
+void groth16_pk_multi_free(zkp_ctx* root, zkp_groth16_pk_multi* M) {
+  for (size_t k = 0; k < M->pk.size(); k++) {
+    (void)hipSetDevice(root->devs[k]->device);
+    if (M->pk[k]) groth16_pk_free(root->devs[k], M->pk[k]);
+  }
+  for (size_t k = 0; k < M->partial.size(); k++) {
+    (void)hipSetDevice(root->devs[k]->device);
+    if (M->partial[k]) (void)hipFree(M->partial[k]);
+  }
+  for (size_t k = 0; k < M->gathered_all.size(); k++) {
+    (void)hipSetDevice(root->devs[k]->device);
+    if (M->gathered_all[k]) (void)hipFree(M->gathered_all[k]);
+  }
+  for (auto& v : {M->ev_chain, M->ev_done, M->ev_h_read})
+    for (hipEvent_t e : v)
+      if (e) (void)hipEventDestroy(e);
+  if (M->ev_h) (void)hipEventDestroy(M->ev_h);
+  (void)hipSetDevice(root->device);
+  delete M;
+}
+
+void groth16_prove_multi(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const* z, bool z_on_device,
+                         const uint64_t* r, const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out) {
+  ZKP_REQUIRE(M->mode == 0 && M->pk.size() == root->devs.size() && !root->devs.empty(), ZKP_ERR_BAD_ARG);
+  try {
+    if (M->curve == ZKP_BN254) prove_multi_t<Bn254Fr>(root, M, z, z_on_device, r, s, proof_out, inf_out);
+    else prove_multi_t<Bls381Fr>(root, M, z, z_on_device, r, s, proof_out, inf_out);
+  } catch (...) {
+    for (zkp_ctx* c : root->devs) {
+      (void)hipSetDevice(c->device);
+      (void)hipDeviceSynchronize();
+    }
+    (void)hipSetDevice(root->device);
+    throw;
+  }
+}
+
+// Throughput mode on every device of the root context: proof i runs on device i % n (its witness pointer, when
+// z_on_device, lives there); one host thread per device drives that device's lanes exactly as zkp_groth16_prove_batch does.
+void groth16_prove_batch_multi(zkp_ctx* root, zkp_groth16_pk_multi* M, size_t count, const uint64_t* const* z,
+                               bool z_on_device, const uint64_t* r, const uint64_t* s, uint64_t* proofs_out,
+                               uint8_t* inf_out) {
+  ZKP_REQUIRE(M->mode == 1 && M->pk.size() == root->devs.size() && !root->devs.empty(), ZKP_ERR_BAD_ARG);
+  const int n = (int)root->devs.size();
+  const MsmVtbl* v1 = msm_vtbl(M->curve, 1);
+  const MsmVtbl* v2 = msm_vtbl(M->curve, 2);
+  const size_t pw64 = (4 * (size_t)v1->fN + 2 * (size_t)v2->fN) / 2;
+  std::vector<int32_t> status(n, ZKP_OK);
+  std::vector<std::thread> th;
+  for (int k = 0; k < n; k++) {
+    th.emplace_back([&, k] {
+      try {
+        zkp_ctx* ctx = root->devs[k];
+        ZKP_HIP(hipSetDevice(ctx->device));
+        std::vector<const uint64_t*> zk;
+        std::vector<uint64_t> rk, sk;
+        for (size_t i = (size_t)k; i < count; i += (size_t)n) {
+          zk.push_back(z[i]);
+          rk.insert(rk.end(), r + 4 * i, r + 4 * i + 4);
+          sk.insert(sk.end(), s + 4 * i, s + 4 * i + 4);
+        }
+        if (zk.empty()) return;
+        std::vector<uint64_t> po(zk.size() * pw64);
+        std::vector<uint8_t> io(zk.size() * 3);
+        groth16_prove_batch(ctx, M->pk[k], zk.size(), zk.data(), rk.data(), sk.data(), po.data(), io.data(), z_on_device);
+        size_t j = 0;
+        for (size_t i = (size_t)k; i < count; i += (size_t)n, j++) {
+          memcpy(proofs_out + i * pw64, po.data() + j * pw64, pw64 * 8);
+          memcpy(inf_out + i * 3, io.data() + j * 3, 3);
+        }
+      } catch (const StatusError& e) {
+        status[k] = e.status;
+      } catch (const HipError& e) {
+        fprintf(stderr, "[zkp_accel] HIP error %s at line %d: %s (device rank %d)\n", hipGetErrorString(e.e), e.line, e.what, k);
+        status[k] = e.e == hipErrorOutOfMemory ? ZKP_ERR_OOM : ZKP_ERR_DEVICE;
+      } catch (...) {
+        status[k] = ZKP_ERR_DEVICE;
+      }
+    });
+  }
+  for (auto& t : th) t.join();
+  (void)hipSetDevice(root->device);
+  for (int32_t st : status)
+    if (st != ZKP_OK) throw StatusError{st};
 }
 
 }  // namespace zkp

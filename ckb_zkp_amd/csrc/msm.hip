@@ -146,7 +146,10 @@ void bases_free(zkp_ctx* ctx, uint64_t handle) {
 }
 size_t bases_len(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->n; }
 int bases_group(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->group; }
-void msm_free_all(zkp_ctx* ctx) { ctx->bases.clear(); }
+void msm_free_all(zkp_ctx* ctx) {
+  ctx->bases.clear();
+  ctx->var_plans.clear();
+}
 uint64_t bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t handle) {
   auto e = get_bases(src, handle);
   ZKP_REQUIRE(dst->device == src->device, ZKP_ERR_BAD_ARG);
@@ -561,13 +564,11 @@ struct VarPlan {
   uint32_t n1 = 0, n2 = 0;
 };
 static VarPlan& var_plan(zkp_ctx* ctx, int c, int W, hipStream_t st) {
-  // per DEVICE (not per context): the descriptors are immutable and live until process exit
-  static std::map<std::pair<int, std::pair<int, int>>, std::unique_ptr<VarPlan>> plans;
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  auto key = std::make_pair(ctx->device, std::make_pair(c, W));
-  auto it = plans.find(key);
-  if (it != plans.end()) return *it->second;
+  // owned by the context (released by msm_free_all / zkp_ctx_destroy, before the HIP runtime goes away): the descriptors
+  // are immutable, one plan per (c, W)
+  auto key = std::make_pair(c, W);
+  auto it = ctx->var_plans.find(key);
+  if (it != ctx->var_plans.end()) return *static_cast<VarPlan*>(it->second.get());
   const uint32_t nb_w = 1u << (c - 1);
   std::vector<SegDesc> s1, s2(256);
   uint32_t lvl_off = 0, cnt = (uint32_t)W * nb_w;
@@ -586,13 +587,14 @@ static VarPlan& var_plan(zkp_ctx* ctx, int c, int W, hipStream_t st) {
     cnt >>= 1;
   }
   for (int t = 0; t < 256; t++) s2[t].out = (uint32_t)t;
-  auto vp = std::make_unique<VarPlan>();
+  auto vp = std::make_shared<VarPlan>();
   vp->n1 = (uint32_t)s1.size();
   vp->n2 = 256;
   ZKP_HIP(hipMemcpyAsync(vp->d1.as<SegDesc>(s1.size()), s1.data(), s1.size() * sizeof(SegDesc), hipMemcpyHostToDevice, st));
   ZKP_HIP(hipMemcpyAsync(vp->d2.as<SegDesc>(256), s2.data(), 256 * sizeof(SegDesc), hipMemcpyHostToDevice, st));
   ZKP_HIP(hipStreamSynchronize(st));                             // the host vectors die with this call
-  return *(plans[key] = std::move(vp));
+  ctx->var_plans[key] = vp;
+  return *vp;
 }
 
 static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, const uint64_t* scalars_dev, size_t n,
@@ -786,7 +788,14 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     for (int l = 0; l < L; l++) {
       uint32_t next_off = lvl_off + cnt;
       static const bool top_fused = !(getenv("ZKP_PAIR_TOP") && atoi(getenv("ZKP_PAIR_TOP")) == 0);
-      static const uint32_t top_max = [] { const char* e = getenv("ZKP_PAIR_TOP_MAX"); uint32_t v = e ? (uint32_t)atoi(e) : PAIR_TOP_MAX; return v < 2 ? PAIR_TOP_MAX : v; }();
+      // (rounded down to a power of two: the fused top starts at the level whose size EQUALS top_max)
+      static const uint32_t top_max = [] {
+        const char* e = getenv("ZKP_PAIR_TOP_MAX");
+        uint32_t v = e ? (uint32_t)atoi(e) : PAIR_TOP_MAX;
+        if (v < 2) v = PAIR_TOP_MAX;
+        while (v & (v - 1)) v &= v - 1;
+        return v;
+      }();
       if (!top_fused || cnt > top_max) vt->pair(st, buckets + (size_t)lvl_off * XB, buckets + (size_t)next_off * XB, cnt / 2);
       else if (cnt == top_max || l == 0) vt->pair_top(st, buckets + (size_t)lvl_off * XB, cnt);   // this level and all above it
       plan.first_block[l] = blocks;

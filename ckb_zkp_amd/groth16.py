@@ -307,6 +307,89 @@ class ProvingKey:
                     ms_msm_acc=list(t.ms_msm_acc), msm_entries=list(t.msm_entries))
 
 
+def _fill_desc(params: Parameters, inst: R1csInstance, matrices_only: bool = False):
+    """zkp_groth16_pk_desc over host arrays (kept alive by the returned list)."""
+    d = _lib.Groth16PkDesc()
+    d.curve, d.num_inputs, d.num_aux, d.num_constraints = params.curve.cid, inst.num_inputs, inst.num_aux, \
+        inst.num_constraints()
+    keep = []
+
+    def P(a):
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        return a.ctypes.data
+
+    for name, which in (("at", "a"), ("bt", "b"), ("ct", "c")):
+        rp, col, cf = inst.csr(which)
+        m = getattr(d, name)
+        m.row_ptr, m.col, m.coeff = P(rp.astype(np.uint32)), P(col.astype(np.uint32)), P(cf.astype(np.uint64))
+    for name in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2"):
+        setattr(d, name, P(getattr(params, name).astype(np.uint64)))
+    for name, fld in (() if matrices_only else (("a", "a_query"), ("b_g1", "b_g1_query"), ("b_g2", "b_g2_query"),
+                                                ("h", "h_query"), ("l", "l_query"))):
+        xy, inf = getattr(params, fld)
+        setattr(d, f"{name}_query", P(xy.astype(np.uint64)))
+        setattr(d, f"{name}_inf", P(inf.astype(np.uint8)) if len(inf) else None)
+        setattr(d, f"{name}_len", len(inf))
+    return d, keep
+
+
+MULTI_SHARD, MULTI_REPLICATE = 0, 1
+
+
+class MultiProvingKey:
+    """zkp_groth16_pk_upload_multi on a MultiContext: mode MULTI_SHARD (every query split by index over the devices; one
+    proof uses all of them: prove) or MULTI_REPLICATE (whole key per device; independent proofs round-robin: prove_batch)."""
+
+    def __init__(self, mctx, params: Parameters, circuit, mode: int):
+        self.ctx, self.params, self.curve, self.mode = mctx, params, params.curve, mode
+        inst = _as_instance(self.curve, circuit, assign=False)
+        d, keep = _fill_desc(params, inst)
+        h = C.c_void_p()
+        _lib.check(mctx.lib.zkp_groth16_pk_upload_multi(mctx.h, C.byref(d), mode, C.byref(h)), "zkp_groth16_pk_upload_multi")
+        self.h = h
+        self.nz = inst.num_inputs + inst.num_aux
+
+    def free(self):
+        if self.h:
+            _lib.check(self.ctx.lib.zkp_groth16_pk_multi_free(self.ctx.h, self.h), "zkp_groth16_pk_multi_free")
+            self.h = None
+
+    def prove_raw(self, z, r_mont, s_mont, z_on_device: bool = False):
+        """SHARD key.  z: (nz, 4) host array, or — z_on_device — a list of one device pointer per rank."""
+        c = self.curve
+        out = np.zeros(8 * c.fq_limbs, dtype=np.uint64)
+        inf = np.zeros(3, dtype=np.uint8)
+        r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64)
+        s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
+        if z_on_device:
+            zp = (C.c_void_p * len(z))(*[C.c_void_p(p) for p in z])
+        else:
+            z = np.ascontiguousarray(z, dtype=np.uint64)
+            assert z.shape == (self.nz, 4)
+            zp = (C.c_void_p * 1)(C.c_void_p(z.ctypes.data))
+        _lib.check(self.ctx.lib.zkp_groth16_prove_multi(self.ctx.h, self.h, C.cast(zp, C.c_void_p), 1 if z_on_device else 0,
+                                                        _ptr(r_mont), _ptr(s_mont), _ptr(out), _ptr(inf)),
+                   "zkp_groth16_prove_multi")
+        return out, inf
+
+    def prove_batch_raw(self, zs, r_mont, s_mont, z_on_device: bool = False):
+        """REPLICATE key.  zs[i]: host address (int) / host array of proof i's assignment, or — z_on_device — a device
+        pointer on the device of rank i % n."""
+        n = len(zs)
+        out = np.zeros((n, 8 * self.curve.fq_limbs), dtype=np.uint64)
+        inf = np.zeros((n, 3), dtype=np.uint8)
+        keep = [np.ascontiguousarray(z, dtype=np.uint64) if not isinstance(z, int) else None for z in zs]
+        ptrs = [z if isinstance(z, int) else k.ctypes.data for z, k in zip(zs, keep)]
+        zp = (C.c_void_p * n)(*[C.c_void_p(p) for p in ptrs])
+        r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64).reshape(n, 4)
+        s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64).reshape(n, 4)
+        _lib.check(self.ctx.lib.zkp_groth16_prove_batch_multi(self.ctx.h, self.h, n, C.cast(zp, C.c_void_p),
+                                                              1 if z_on_device else 0, _ptr(r_mont), _ptr(s_mont),
+                                                              _ptr(out), _ptr(inf)), "zkp_groth16_prove_batch_multi")
+        return out, inf
+
+
 def create_proof(pk: ProvingKey, circuit, r: int, s: int) -> Proof:
     """prover.rs:124-211: synthesise on the host, prove on the device."""
     inst = _as_instance(pk.curve, circuit, assign=True)

@@ -259,6 +259,41 @@ int32_t zkp_groth16_prove_partials_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const u
 int32_t zkp_groth16_fold_assemble_dev(zkp_ctx* ctx, zkp_curve_t curve, const void* gathered_dev, int32_t world,
                                       const uint64_t* r, const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 
+/* ---- Single-process multi-GPU: `create_proof` (groth16/src/prover.rs:124) is ONE call in ONE process, so the library owns
+ * one context per device and the exchange step (zkp_ctx_create(ctx**, device_ids, n_devices)).
+ *   zkp_ctx_create_multi   root context = rank 0 (device_ids[0]) + one member context per further id, rank order = argument
+ *                          order.  Ids may repeat (several ranks on one GPU: one-GPU test boxes).  Peer access between
+ *                          distinct devices is enabled when the topology offers it (xGMI).  The root is an ordinary
+ *                          zkp_ctx for every other call; zkp_ctx_destroy(root) destroys the members.
+ *   zkp_ctx_device         borrow member `rank` (rank 0 = the root itself) for zkp_dev_alloc / zkp_h2d / ... on that device.
+ *   zkp_groth16_pk_upload_multi
+ *       ZKP_MULTI_SHARD      every (extended) query of prover.rs:164-190 split by index, rank k keeps 1/n of the window
+ *                            tables (BASELINE configs[4]: keys that do not fit one GPU; lower single-proof latency);
+ *       ZKP_MULTI_REPLICATE  the whole key on every device (throughput: independent proofs on independent GPUs).
+ *   zkp_groth16_prove_multi        (SHARD key) ONE proof over all devices: partial MSMs per device, the five partial sums
+ *                          gathered on rank 0 over xGMI (hipMemcpyPeerAsync of n x zkp_groth16_partials_bytes; an RCCL
+ *                          ncclAllGather instead with ZKP_MULTI_EXCHANGE=rccl), slot-wise fold + assembly on rank 0.  With
+ *                          n >= 3 the witness map is task-split: the a / b / c chains of r1cs_to_qap.rs:144-162 run on ranks
+ *                          0 / 1 / 2, rank 0 finishes h and every rank fetches its slice of h for its share of the H MSM
+ *                          (ZKP_MULTI_WM_SPLIT=0: replicated witness map).  z_on_device == 0: z[0] is the host assignment;
+ *                          != 0: z[k] is a device pointer on rank k's device, k < n.
+ *   zkp_groth16_prove_batch_multi  (REPLICATE key) `count` independent proofs, proof i on rank i % n (z[i] host, or a device
+ *                          pointer on that rank's device), one host thread per device driving its lanes as
+ *                          zkp_groth16_prove_batch does; outputs in input order. */
+typedef struct zkp_groth16_pk_multi zkp_groth16_pk_multi;
+typedef enum { ZKP_MULTI_SHARD = 0, ZKP_MULTI_REPLICATE = 1 } zkp_multi_mode;
+int32_t zkp_ctx_create_multi(zkp_ctx** out, const int* device_ids, int n_devices);
+int32_t zkp_ctx_num_devices(zkp_ctx* ctx, int32_t* n);
+int32_t zkp_ctx_device(zkp_ctx* ctx, int32_t rank, zkp_ctx** member);
+int32_t zkp_groth16_pk_upload_multi(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, int32_t mode,
+                                    zkp_groth16_pk_multi** out);
+int32_t zkp_groth16_pk_multi_free(zkp_ctx* ctx, zkp_groth16_pk_multi* pk);
+int32_t zkp_groth16_prove_multi(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, const uint64_t* const* z, int32_t z_on_device,
+                                const uint64_t* r, const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
+int32_t zkp_groth16_prove_batch_multi(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, size_t count, const uint64_t* const* z,
+                                      int32_t z_on_device, const uint64_t* r, const uint64_t* s, uint64_t* proofs_out,
+                                      uint8_t* inf_out);
+
 /* ---- Marlin Fiat–Shamir RNG (host code): replaces marlin/src/fs_rng.rs:11-70 `FiatShamirRng` ----------------------------
  * merlin 2.0 transcript "MARLINSEED" -> 32-byte seed -> ChaCha20 RNG (rand_chacha 0.2).  The byte strings absorbed are
  * the caller's `to_bytes![...]` (marlin/src/lib.rs:105-158); samples come back in the ABI's field layout.

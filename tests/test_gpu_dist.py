@@ -122,9 +122,18 @@ def test_config5_2p24_single_gpu_and_8way_sharded(ctx):
         pk = groth16.ProvingKey(ctx, params, inst)
         try:
             assert pk.domain_size == 1 << k
-            h = codec.fr_from_mont(pk.witness_map(z), c)
+            from oracle import cpu_oracle
+            thr = cpu_oracle.hardware_threads()
+            h_dev = pk.witness_map(z)
+            # full-size pin at 2^24: h and the whole proof equal the C++ restatement of the reference (all host threads)
+            assert np.array_equal(h_dev, cpu_oracle.witness_map(params, inst, z, threads=thr))
+            h = codec.fr_from_mont(h_dev, c)
+            del h_dev
             assert h[-1] == 0
-            out1, inf1 = pk.prove_raw(zd, codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0], z_on_device=True)
+            rm, sm = codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0]
+            out1, inf1 = pk.prove_raw(zd, rm, sm, z_on_device=True)
+            o_out, o_inf, _ = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=thr)
+            assert np.array_equal(out1, o_out) and np.array_equal(inf1, o_inf)
             proof = pk.decode_proof(out1, inf1)
         finally:
             pk.free()

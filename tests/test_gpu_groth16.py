@@ -156,11 +156,21 @@ def test_full_size_proof_trapdoor_and_pipeline(ctx, curve, k):
         assert pk.domain_size == 1 << k
         c = params.curve
         z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
-        h = codec.fr_from_mont(pk.witness_map(z), c)
+        import numpy as np
+        from oracle import cpu_oracle
+        thr = cpu_oracle.hardware_threads()
+        h_dev = pk.witness_map(z)
+        # FULL-SIZE pin of h: the device's witness map equals the C++ restatement of
+        # R1CStoQAP::witness_map (r1cs_to_qap.rs:113-172) limb for limb, not just "h[-1] == 0"
+        assert np.array_equal(h_dev, cpu_oracle.witness_map(params, inst, z, threads=thr))
+        h = codec.fr_from_mont(h_dev, c)
         assert h[-1] == 0
         r_, s_ = 0x1F2E3D4C5B6A7988, 0x8899AABBCCDDEEFF
         rm, sm = codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0]
         out, inf = pk.prove_raw(z, rm, sm)
+        # ... and of the whole proof: device proof == the C++ restatement of create_proof (prover.rs:124-211) on all host threads
+        o_out, o_inf, _ = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=thr)
+        assert np.array_equal(out, o_out) and np.array_equal(inf, o_inf)
         proof = pk.decode_proof(out, inf)
         t, r, ni = params.toxic, c.r, inst.num_inputs
         A = (t["alpha"] + sum(zi * ai for zi, ai in zip(inst.z, t["a"])) + r_ * t["delta"]) % r

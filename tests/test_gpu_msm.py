@@ -70,8 +70,14 @@ def test_msm_known_dlog(ctx, curve, group, log_n):
     rng = np.random.default_rng(log_n * 10 + group)
     d = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     d[:, 3] >>= np.uint64(4)            # < 2^251 < r
-    k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
-    k[:, 3] >>= np.uint64(4)
+    # FULL-RANGE scalars: uniform in [0, r) (256 random bits reduced mod r), so the top window's high digits and the last
+    # signed-digit carry are exercised at every size; every 13th scalar sits within 2^20 of r - 1
+    kraw = np.frombuffer(rng.bytes(32 * n), dtype=np.uint64).reshape(n, 4)
+    kint = [x % c.r for x in codec.limbs_to_ints(kraw)]
+    for i in range(0, n, 13):
+        kint[i] = c.r - 1 - (kint[i] & 0xFFFFF)
+    k = codec.fr_canonical(kint, c).reshape(n, 4).copy()
+    assert max(kint).bit_length() == c.r.bit_length()
     k[::7] = 0                          # zero scalars (ark skips them)
     k[1::11, 1:] = 0
     k[1::11, 0] = 1                     # ones (ark fast path)

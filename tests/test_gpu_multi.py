@@ -1,0 +1,163 @@
+"""GPU: the single-process multi-GPU boundary (zkp_ctx_create_multi / zkp_groth16_prove_multi /
+zkp_groth16_prove_batch_multi) with every rank on cuda:0 (device ids may repeat), and the PRODUCT's
+multi-process sharded prover (distributed.DeviceShardedGroth16Prover, what `bench.py --mode shard` runs) as two real
+processes on cuda:0 with the collective over gloo.  Replaces one `create_proof` call (groth16/src/prover.rs:124-211)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from ckb_zkp_amd import codec, groth16
+from ckb_zkp_amd.api import MultiContext
+from ckb_zkp_amd.circuits import mimc_chain_instance, samples_for_domain
+from ckb_zkp_amd.params import get_curve
+
+pytestmark = pytest.mark.gpu
+TOXIC = dict(alpha=0x1234567890ABCDEF1, beta=0xFEDCBA09876543211, gamma=0x1111111111111111111,
+             delta=0x2222222222222222223, tau=0x3333333333333333335)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("curve,k,world", [("bn254", 12, 2), ("bn254", 11, 3), ("bn254", 10, 8), ("bn254", 4, 5),
+                                           ("bls12_381", 9, 3)])
+def test_prove_multi_sharded_equals_single_gpu(ctx, curve, k, world):
+    """ONE proof base-sharded over `world` ranks inside one process (world >= 3: task-split witness map, a / b / c chains
+    on ranks 0 / 1 / 2, h slices fetched by every rank) == the single-GPU proof, host witness and device witnesses."""
+    c = get_curve(curve)
+    inst = mimc_chain_instance(curve, samples_for_domain(k))
+    params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    pk = groth16.ProvingKey(ctx, params, inst)
+    z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+    m = MultiContext([0] * world)
+    try:
+        mpk = groth16.MultiProvingKey(m, params, inst, groth16.MULTI_SHARD)
+        try:
+            zds = [m.member(r).to_device(z) for r in range(world)]
+            for r_, s_ in ((0xABCDEF0123456789ABCDEF, 0x13579BDF02468ACE), (0, 0)):
+                rm, sm = codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0]
+                out1, inf1 = pk.prove_raw(z, rm, sm)
+                for rep in range(2):                                # the second call reuses every buffer
+                    out2, inf2 = mpk.prove_raw(z, rm, sm)
+                    assert np.array_equal(out1, out2) and np.array_equal(inf1, inf2), (r_, s_, rep)
+                out3, inf3 = mpk.prove_raw(zds, rm, sm, z_on_device=True)
+                assert np.array_equal(out1, out3) and np.array_equal(inf1, inf3)
+            for r, d in enumerate(zds):
+                m.member(r).dev_free(d)
+            # a sharded multi key refuses the batch entry point
+            from ckb_zkp_amd._lib import ZkpError
+            with pytest.raises(ZkpError):
+                mpk.prove_batch_raw([z], np.stack([rm]), np.stack([sm]))
+        finally:
+            mpk.free()
+    finally:
+        m.close()
+        pk.free()
+
+
+def test_prove_multi_replicated_witness_map(ctx, monkeypatch):
+    """ZKP_MULTI_WM_SPLIT=0 is read once per process, so the replicated-witness-map variant of the 3-rank step runs in a
+    child process and must print the same proof as the task-split one."""
+    code = r'''
+import numpy as np
+from ckb_zkp_amd import codec, groth16
+from ckb_zkp_amd.api import MultiContext
+from ckb_zkp_amd.circuits import mimc_chain_instance, samples_for_domain
+TOXIC = dict(alpha=11, beta=13, gamma=17, delta=19, tau=23)
+m = MultiContext([0, 0, 0])
+inst = mimc_chain_instance("bn254", samples_for_domain(10))
+params = groth16.generate_parameters(m, "bn254", inst, **TOXIC)
+mpk = groth16.MultiProvingKey(m, params, inst, groth16.MULTI_SHARD)
+c = params.curve
+z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+out, inf = mpk.prove_raw(z, codec.fr_to_mont([5], c)[0], codec.fr_to_mont([7], c)[0])
+print("PROOF", out.tobytes().hex(), inf.tobytes().hex())
+'''
+    res = {}
+    for split in ("0", "1"):
+        env = dict(os.environ, ZKP_MULTI_WM_SPLIT=split, PYTHONPATH=ROOT)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[split] = [l for l in out.stdout.splitlines() if l.startswith("PROOF")][0]
+    assert res["0"] == res["1"]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_prove_batch_multi_replicated_equals_sequential(ctx, world):
+    """Throughput mode through the C boundary: n independent proofs dealt round-robin over `world` ranks (one host thread
+    per rank driving its lanes) == n blocking single-GPU proofs, host and device witnesses, n not a multiple of world."""
+    import random
+    curve = "bn254"
+    c = get_curve(curve)
+    inst = mimc_chain_instance(curve, samples_for_domain(11), seed=0xC0FFEE)
+    params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    pk = groth16.ProvingKey(ctx, params, inst)
+    z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+    rnd = random.Random(world)
+    m = MultiContext([0] * world)
+    try:
+        mpk = groth16.MultiProvingKey(m, params, inst, groth16.MULTI_REPLICATE)
+        try:
+            for n in (1, 7, 20):
+                rm = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(n)], c)
+                sm = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(n)], c)
+                outs, infs = mpk.prove_batch_raw([z] * n, rm, sm)
+                zds = [m.member(r).to_device(z) for r in range(world)]
+                outs_d, infs_d = mpk.prove_batch_raw([zds[i % world] for i in range(n)], rm, sm, z_on_device=True)
+                for r, d in enumerate(zds):
+                    m.member(r).dev_free(d)
+                for i in range(n):
+                    o1, i1 = pk.prove_raw(z, rm[i], sm[i])
+                    assert np.array_equal(outs[i], o1) and np.array_equal(infs[i], i1), (n, i)
+                    assert np.array_equal(outs_d[i], o1) and np.array_equal(infs_d[i], i1), (n, i)
+            from ckb_zkp_amd._lib import ZkpError
+            with pytest.raises(ZkpError):                       # a replicated key refuses the sharded entry point
+                mpk.prove_raw(z, rm[0], sm[0])
+        finally:
+            mpk.free()
+    finally:
+        m.close()
+        pk.free()
+
+
+def test_multi_context_argument_checks(ctx):
+    from ckb_zkp_amd._lib import ZkpError
+    with pytest.raises(ZkpError):
+        MultiContext([0, 9999])                                  # no such device: hard error, members already made are released
+    m = MultiContext([0, 0])
+    try:
+        assert m.num_devices == 2
+        with pytest.raises(ZkpError):
+            m.member(2)
+        # an ordinary context is not a multi root
+        inst = mimc_chain_instance("bn254", 3)
+        params = groth16.generate_parameters(ctx, "bn254", inst, **TOXIC)
+        with pytest.raises(ZkpError):
+            groth16.MultiProvingKey(ctx, params, inst, groth16.MULTI_SHARD)
+    finally:
+        m.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_sharded_prover_multiprocess_gloo_on_one_gpu(world):
+    """The product's sharded prover as REAL processes: `world` ranks launched by torch.distributed.run, every rank on
+    cuda:0, DeviceShardedGroth16Prover.prove with its collective branch (all-gather of the device-resident partial sums,
+    here staged over gloo) == the single-GPU proof computed by rank 0 with the whole key."""
+    env = dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="16")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    oks = [l for l in out.stdout.splitlines() if l.startswith("SHARDED_OK")]
+    assert len(oks) == world, out.stdout[-2000:]
