@@ -1,4 +1,4 @@
-"""Device-resident Marlin prover: the same algorithm as `marlin.create_proof` (reference: marlin/src/lib.rs:97-181,
+"""Device-resident Marlin prover: the algorithm of the host-list cross-check prover `tests/marlin_hostlist.create_proof` (reference: marlin/src/lib.rs:97-181,
 ahp/prover.rs:86-427, pc/mod.rs:34-160) but every vector stays in HBM from the witness to the opening proofs — NTTs,
 element-wise arithmetic, batch inversions, sparse products (z_a = A z, the transposed product behind `t`), gathers,
 vanishing-polynomial folds, evaluations, witness division and the KZG10 MSMs are all C-ABI calls on device pointers;
@@ -15,8 +15,67 @@ import numpy as np
 
 from . import _lib, api, codec, kzg10
 from .api import Context
-from .marlin import INDEX_LABELS, LABELS_1, LABELS_2, LABELS_3, ZK_BOUND, MarlinCS, _next_pow2, reindex_by_subdomain
 from .params import get_curve
+from .r1cs import INPUT, ConstraintSystem
+
+# ---- shared with the host-list cross-check prover under tests/ (tests/marlin_hostlist.py)
+ZK_BOUND = 1
+LABELS_1, LABELS_2, LABELS_3 = ["w", "z_a", "z_b", "mask"], ["t", "g_1", "h_1"], ["g_2", "h_2"]
+INDEX_LABELS = [f"{m}_{k}" for m in "abc" for k in ("row", "col", "val", "row_col")]
+
+
+def _next_pow2(n):
+    s = 1
+    while s < n:
+        s <<= 1
+    return s
+
+
+def reindex_by_subdomain(h_size, x_size, j):
+    period = h_size // x_size
+    if j < x_size:
+        return j * period
+    i = j - x_size
+    return i + i // (period - 1) + 1
+
+
+class MarlinCS(ConstraintSystem):
+    """IndexerConstraintSystem / ProverConstraintSystem (ahp/constraint_systems.rs)."""
+
+    def make_matrices_square(self):
+        nv, nc = self.num_inputs + self.num_aux, self.num_constraints()
+        if nv < nc:
+            for _ in range(nc - nv):
+                self.alloc(lambda: 1)
+        else:
+            for _ in range(nv - nc):
+                self.enforce(lambda lc: lc, lambda lc: lc, lambda lc: lc)
+
+
+def index_matrices(curve, circuit):
+    """Host half of AHP::index (indexer.rs:70-96): synthesis, make_matrices_square, balance_matrices, per-row column
+    sort.  -> (constraint system, [a, b, c]) with rows as lists of (coeff, column)."""
+    c = get_curve(curve)
+    cs = MarlinCS(c, assign=False)
+    circuit.generate_constraints(cs)
+    cs.make_matrices_square()
+    mats = [[[(cf, j if kind == INPUT else cs.num_inputs + j) for cf, (kind, j) in row] for row in m]
+            for m in (cs.at, cs.bt, cs.ct)]
+    a, b, cc = mats
+    da, db_ = sum(map(len, a)), sum(map(len, b))          # balance_matrices
+    denser = da > db_
+    for i in range(len(a)):
+        if denser:
+            la, lb = len(a[i]), len(b[i])
+            a[i], b[i] = b[i], a[i]
+            da += lb - la
+            db_ += la - lb
+            denser = da > db_
+    for m in mats:
+        for row in m:
+            row.sort(key=lambda t: t[1])
+    return cs, mats
+
 
 
 class DVec:

@@ -26,6 +26,7 @@ use ark_ff::{BigInteger256, BigInteger384, Fp256, Fp256Parameters, Fp384, Fp384P
 
 pub mod ffi;
 pub mod groth16;
+pub mod marlin;
 
 /// Errors of the device library (zkp_status) — see `Error::into_synthesis_error` for the mapping the reference expects.
 #[derive(Debug, Clone, PartialEq, Eq)]
@@ -91,6 +92,22 @@ impl Ctx {
 impl Drop for Ctx {
     fn drop(&mut self) {
         unsafe { ffi::zkp_ctx_destroy(self.0) };
+    }
+}
+
+/// `zkp_ctx_create_multi`: ONE process, one context per listed device; the root is an ordinary context (rank 0).
+/// `create_proof` (groth16/src/prover.rs:124) is one call in one process — this is how it reaches 8 GPUs without `torchrun`:
+/// see `groth16::MultiDeviceProvingKey`.
+pub struct MultiCtx {
+    pub root: Ctx,
+    pub num_devices: usize,
+}
+impl MultiCtx {
+    pub fn new(device_ids: &[i32]) -> Result<Self, Error> {
+        let ids: Vec<c_int> = device_ids.iter().map(|&d| d as c_int).collect();
+        let mut p: *mut ffi::zkp_ctx = ptr::null_mut();
+        check(unsafe { ffi::zkp_ctx_create_multi(&mut p, ids.as_ptr(), ids.len() as c_int) })?;
+        Ok(MultiCtx { root: Ctx(p), num_devices: ids.len() })
     }
 }
 
@@ -184,11 +201,29 @@ where
     GroupAffine::new(<P::BaseField as AbiField>::read_limbs(&xy[..l]), <P::BaseField as AbiField>::read_limbs(&xy[l..2 * l]), false)
 }
 
-/// Scalars: `BigInteger256` is `[u64; 4]` (canonical after `into_repr()`), `Fp256` stores its Montgomery limbs in the same
-/// shape; a slice of either is contiguous `4 * n` u64 — passed by pointer, no copy.
-pub fn scalars_ptr<T>(s: &[T]) -> *const u64 {
-    debug_assert_eq!(std::mem::size_of::<T>(), 32);
+/// Scalar element types whose in-memory form is exactly 4 little-endian u64 limbs (32 bytes): the only types the ABI's
+/// scalar / NTT arguments accept.  SEALED: implemented here for `BigInteger256` (canonical, after `into_repr()`) and
+/// `Fp256<P>` (Montgomery limbs) and nowhere else, so safe generic callers cannot hand the C library a slice of any other
+/// element size (which would make it read or write `32 * n` bytes past the slice).
+pub trait AbiScalar: sealed::Sealed + Copy {}
+mod sealed {
+    pub trait Sealed {}
+}
+impl sealed::Sealed for BigInteger256 {}
+impl AbiScalar for BigInteger256 {}
+impl<P: Fp256Parameters> sealed::Sealed for Fp256<P> {}
+impl<P: Fp256Parameters> AbiScalar for Fp256<P> {}
+
+/// A slice of scalars as the ABI's `const uint64_t*` (4 limbs per element, no copy).  The size check is a hard assertion
+/// (also in release builds) on top of the sealed trait: a layout change in arkworks must fail loudly, not corrupt memory.
+pub fn scalars_ptr<T: AbiScalar>(s: &[T]) -> *const u64 {
+    assert_eq!(std::mem::size_of::<T>(), 32, "ABI scalars are 4 x u64");
+    assert_eq!(std::mem::align_of::<T>() % std::mem::align_of::<u64>(), 0);
     s.as_ptr() as *const u64
+}
+fn scalars_mut_ptr<T: AbiScalar>(s: &mut [T]) -> *mut u64 {
+    assert_eq!(std::mem::size_of::<T>(), 32, "ABI scalars are 4 x u64");
+    s.as_mut_ptr() as *mut u64
 }
 
 // ------------------------------------------------------------------------------------------------ curves
@@ -273,7 +308,7 @@ where
 
     /// `Curve::vartime_multiscalar_mul` with resident points: `Fr` elements as they sit in memory (Montgomery);
     /// `into_repr()` is fused into the device's digit scan.
-    pub fn vartime_multiscalar_mul<F>(&self, scalars: &[F]) -> Result<GroupProjective<P>, Error> {
+    pub fn vartime_multiscalar_mul<F: AbiScalar>(&self, scalars: &[F]) -> Result<GroupProjective<P>, Error> {
         let l = <P::BaseField as AbiField>::LIMBS;
         let mut out = vec![0u64; 3 * l];
         let st = unsafe {
@@ -285,6 +320,47 @@ where
         };
         check(st)?;
         Ok(unmarshal_projective::<P>(&out))
+    }
+}
+impl<'c, P: AccelGroup> ResidentBases<'c, P>
+where
+    P::BaseField: AbiField,
+{
+    /// `KZG10::commit` / `open` on a coefficient vector that already lives in HBM (marlin/src/pc/kzg10.rs:108-109,137-140):
+    /// Montgomery `Fr` coefficients at `coeffs_dev` against `powers[offset ..]`, `offset` = the leading zeros skipped by
+    /// `skip_leading_zeros_and_convert_to_bigints` (`into_repr()` is fused into the device's digit scan).
+    ///
+    /// # Safety
+    /// `coeffs_dev` must be a device pointer to `n` `Fr` elements on this context's device.
+    pub unsafe fn msm_mont_dev(&self, offset: usize, coeffs_dev: *const u64, n: usize) -> Result<GroupProjective<P>, Error> {
+        let l = <P::BaseField as AbiField>::LIMBS;
+        let mut out = vec![0u64; 3 * l];
+        let st = if P::GROUP == 1 {
+            ffi::zkp_msm_g1_mont_dev(self.ctx.0, self.handle, offset, coeffs_dev, n, out.as_mut_ptr())
+        } else {
+            ffi::zkp_msm_g2_mont_dev(self.ctx.0, self.handle, offset, coeffs_dev, n, out.as_mut_ptr())
+        };
+        check(st)?;
+        Ok(unmarshal_projective::<P>(&out))
+    }
+    /// The same for host-resident Montgomery coefficients: uploads them and runs `msm_mont_dev` (what the KZG10 seam in
+    /// rust/patches/marlin-accel.diff calls: no `into_repr()` pass over the polynomial on the CPU).
+    pub fn msm_mont<F: AbiScalar>(&self, offset: usize, coeffs: &[F]) -> Result<GroupProjective<P>, Error> {
+        if coeffs.is_empty() {
+            return Ok(GroupProjective::<P>::zero());
+        }
+        let bytes = coeffs.len() * 32;
+        let mut d: *mut std::os::raw::c_void = ptr::null_mut();
+        check(unsafe { ffi::zkp_dev_alloc(self.ctx.0, bytes, &mut d) })?;
+        let r = (|| {
+            check(unsafe { ffi::zkp_h2d(self.ctx.0, d, coeffs.as_ptr() as *const std::os::raw::c_void, bytes) })?;
+            unsafe { self.msm_mont_dev(offset, d as *const u64, coeffs.len()) }
+        })();
+        unsafe { ffi::zkp_dev_free(self.ctx.0, d) };
+        r
+    }
+    pub fn handle(&self) -> u64 {
+        self.handle
     }
 }
 impl<'c, P: AccelGroup> Drop for ResidentBases<'c, P>
@@ -299,7 +375,7 @@ where
 /// True variable-base MSM (`zkp_msm_g*_var`): fresh bases every call, nothing stays resident — the semantics of
 /// `Curve::vartime_multiscalar_mul(scalars, points)` for callers such as bulletproofs / spartan whose generators change.
 /// `montgomery = true`: `scalars` are `Fr` elements; `false`: canonical `BigInteger256`.
-pub fn msm_var<P: AccelGroup, S>(ctx: &Ctx, points: &[GroupAffine<P>], scalars: &[S], montgomery: bool) -> Result<GroupProjective<P>, Error>
+pub fn msm_var<P: AccelGroup, S: AbiScalar>(ctx: &Ctx, points: &[GroupAffine<P>], scalars: &[S], montgomery: bool) -> Result<GroupProjective<P>, Error>
 where
     P::BaseField: AbiField,
 {
@@ -329,9 +405,8 @@ pub enum NttOp {
 
 /// drop-in for `domain.{fft,ifft,coset_fft,coset_ifft}_in_place(&mut v)`: `v.len()` must be the domain size (a power of
 /// two; arkworks pads with zeros before calling — do the same), elements are `Fr` in memory layout.
-pub fn ntt_in_place<F>(ctx: &Ctx, curve: c_int, v: &mut [F], op: NttOp) -> Result<(), Error> {
-    debug_assert_eq!(std::mem::size_of::<F>(), 32);
+pub fn ntt_in_place<F: AbiScalar>(ctx: &Ctx, curve: c_int, v: &mut [F], op: NttOp) -> Result<(), Error> {
     assert!(v.len().is_power_of_two());
     let log_n = v.len().trailing_zeros();
-    check(unsafe { ffi::zkp_ntt(ctx.0, curve, v.as_mut_ptr() as *mut u64, log_n, op as i32) })
+    check(unsafe { ffi::zkp_ntt(ctx.0, curve, scalars_mut_ptr(v), log_n, op as i32) })
 }

@@ -1,4 +1,7 @@
-"""Host-side mirror of the reference's Marlin prover on the MI355X backend (BASELINE.json configs[3]).
+"""TEST INFRASTRUCTURE (moved out of the product package in round 3): a second, host-list implementation of the Marlin prover
+over the C ABI, kept only to cross-check the device-resident product prover (ckb_zkp_amd/marlin_dev.py, csrc/marlin.hip).
+
+Host-side mirror of the reference's Marlin prover on the MI355X backend (BASELINE.json configs[3]).
 
 Mirrors /root/reference/marlin/src/lib.rs:97-181 (`create_random_proof`), ahp/indexer.rs:70-117 (`AHP::index`),
 ahp/prover.rs:86-427 (`prover_init`, `prover_{first,second,third}_round`) and pc/mod.rs:34-160 (`PC::commit`,
@@ -13,21 +16,11 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import api, codec, kzg10
-from .api import Context
-from .params import get_curve
-from .r1cs import INPUT, ConstraintSystem
-
-ZK_BOUND = 1
-LABELS_1, LABELS_2, LABELS_3 = ["w", "z_a", "z_b", "mask"], ["t", "g_1", "h_1"], ["g_2", "h_2"]
-INDEX_LABELS = [f"{m}_{k}" for m in "abc" for k in ("row", "col", "val", "row_col")]
-
-
-def _next_pow2(n):
-    s = 1
-    while s < n:
-        s <<= 1
-    return s
+from ckb_zkp_amd import api, codec, kzg10
+from ckb_zkp_amd.api import Context
+from ckb_zkp_amd.marlin_dev import (INDEX_LABELS, LABELS_1, LABELS_2, LABELS_3, ZK_BOUND, MarlinCS, _next_pow2,  # noqa: F401
+                                    index_matrices, reindex_by_subdomain)
+from ckb_zkp_amd.params import get_curve
 
 
 def _trim(p):
@@ -126,14 +119,6 @@ def mul_by_vanishing(p, n, r):
     return out
 
 
-def reindex_by_subdomain(h_size, x_size, j):
-    period = h_size // x_size
-    if j < x_size:
-        return j * period
-    i = j - x_size
-    return i + i // (period - 1) + 1
-
-
 def _domain(c, n):
     size = _next_pow2(n)
     lg = size.bit_length() - 1
@@ -143,44 +128,6 @@ def _domain(c, n):
         els.append(p)
         p = p * w % c.r
     return size, els
-
-
-class MarlinCS(ConstraintSystem):
-    """IndexerConstraintSystem / ProverConstraintSystem (ahp/constraint_systems.rs)."""
-
-    def make_matrices_square(self):
-        nv, nc = self.num_inputs + self.num_aux, self.num_constraints()
-        if nv < nc:
-            for _ in range(nc - nv):
-                self.alloc(lambda: 1)
-        else:
-            for _ in range(nv - nc):
-                self.enforce(lambda lc: lc, lambda lc: lc, lambda lc: lc)
-
-
-def index_matrices(curve, circuit):
-    """Host half of AHP::index (indexer.rs:70-96): synthesis, make_matrices_square, balance_matrices, per-row column
-    sort.  -> (constraint system, [a, b, c]) with rows as lists of (coeff, column)."""
-    c = get_curve(curve)
-    cs = MarlinCS(c, assign=False)
-    circuit.generate_constraints(cs)
-    cs.make_matrices_square()
-    mats = [[[(cf, j if kind == INPUT else cs.num_inputs + j) for cf, (kind, j) in row] for row in m]
-            for m in (cs.at, cs.bt, cs.ct)]
-    a, b, cc = mats
-    da, db_ = sum(map(len, a)), sum(map(len, b))          # balance_matrices
-    denser = da > db_
-    for i in range(len(a)):
-        if denser:
-            la, lb = len(a[i]), len(b[i])
-            a[i], b[i] = b[i], a[i]
-            da += lb - la
-            db_ += la - lb
-            denser = da > db_
-    for m in mats:
-        for row in m:
-            row.sort(key=lambda t: t[1])
-    return cs, mats
 
 
 def index(ctx: Context, curve, circuit):

@@ -5,7 +5,8 @@ import random
 
 import pytest
 
-from ckb_zkp_amd import kzg10, marlin
+from ckb_zkp_amd import kzg10
+from tests import marlin_hostlist as marlin
 from ckb_zkp_amd.circuits import Mini, MimcChain
 from ckb_zkp_amd.params import get_curve
 from oracle.pyref import groth16 as og

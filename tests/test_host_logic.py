@@ -87,7 +87,8 @@ def test_marlin_array_indexer_matches_constraint_by_constraint_synthesis():
     """marlin_dev.prepare_matrices (make_matrices_square + balance_matrices + column sort on CSR index arrays) yields the
     matrices marlin.index_matrices builds row by row (ahp/constraint_systems.rs:9-31,100-114), incl. the case where A is
     denser and rows are swapped, and the case with more constraints than variables (padding variables)."""
-    from ckb_zkp_amd import codec, marlin, marlin_dev
+    from ckb_zkp_amd import codec, marlin_dev
+    from ckb_zkp_amd import marlin_dev as marlin
     from ckb_zkp_amd.circuits import MimcChain, mimc_chain_instance
     from ckb_zkp_amd.params import get_curve
     from ckb_zkp_amd.r1cs import R1csInstance
