@@ -96,6 +96,74 @@ def bench_sharded(args, ctx, c, inst, params, z, rank, world, local):
         dist.destroy_process_group()
 
 
+def bench_single_process_multi(args):
+    """`python bench.py --gpus N` WITHOUT torchrun: one process drives N GPUs through the library's own multi-GPU entry points
+    (include/zkp_accel.h: zkp_ctx_create_multi + zkp_groth16_prove_batch_multi / zkp_groth16_prove_multi) — what a Rust caller
+    of create_proof gets.  throughput: independent proofs round-robin over replicated keys (weak scaling); shard: ONE proof per
+    step, every query base-sharded, partial sums gathered over xGMI inside the library (BASELINE configs[4])."""
+    from ckb_zkp_amd import codec, groth16
+    from ckb_zkp_amd.api import MultiContext
+    from ckb_zkp_amd.circuits import mimc_chain_instance, samples_for_domain
+    from ckb_zkp_amd.params import get_curve
+    ids = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    n = len(ids)
+    c = get_curve(args.curve)
+    m = MultiContext(ids)
+    inst = mimc_chain_instance(c, samples_for_domain(args.log_n))
+    t0 = time.time()
+    params = groth16.generate_parameters(m, c, inst, **TOXIC)
+    log(f"instance + synthetic key: {time.time()-t0:.1f}s; devices {ids}")
+    shard = args.mode == "shard"
+    t0 = time.time()
+    mpk = groth16.MultiProvingKey(m, params, inst, groth16.MULTI_SHARD if shard else groth16.MULTI_REPLICATE)
+    log(f"key upload on {n} device(s) ({'sharded' if shard else 'replicated'}): {time.time()-t0:.1f}s")
+    z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+    zds = [m.member(k).to_device(z) for k in range(n)]          # witness resident in HBM on every device before the timed region
+    rng = np.random.default_rng(1234)
+
+    def rand_fr(k):
+        return np.stack([codec.fr_to_mont([int.from_bytes(rng.bytes(32), "little") % c.r], c)[0] for _ in range(k)])
+
+    def steps(k):
+        if k <= 0:
+            return
+        if shard:
+            for _ in range(k):
+                mpk.prove_raw(zds, rand_fr(1)[0], rand_fr(1)[0], z_on_device=True)
+        else:
+            # `k` steps = k proofs PER GPU, like one rank per GPU in the torchrun mode
+            mpk.prove_batch_raw([zds[i % n] for i in range(k * n)], rand_fr(k * n), rand_fr(k * n), z_on_device=True)
+
+    def sync_all():
+        for k in range(n):
+            m.member(k).sync()
+
+    steps(args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    steps(args.steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    proofs = args.steps if shard else args.steps * n
+    print(json.dumps({
+        "metric": "Groth16 proofs/sec (2^20 constraints, BN256)" if (args.log_n == 20 and c.name == "bn254" and not shard)
+        else f"Groth16 proofs/sec (2^{args.log_n} domain, {c.name})" + (", ONE proof base-sharded over the GPUs" if shard else ""),
+        "value": round(proofs / dt, 4), "unit": "proofs/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if shard else "weak",
+        "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery integers)",
+        "data": "synthetic (MiMC-chain R1CS, PRF witness, proving key generated from a fixed trapdoor)",
+        "config": {"workload": f"Groth16 prove, MiMC-chain R1CS, {inst.num_constraints()} constraints (domain 2^{args.log_n}), {c.name}",
+                   "curve": c.name, "log_domain": args.log_n, "devices": ids,
+                   "parallelism": (f"base-sharded x{n}, in-library exchange (zkp_groth16_prove_multi)" if shard
+                                   else f"independent proofs x{n}, one process, one host thread per GPU (zkp_groth16_prove_batch_multi)"),
+                   "launch": "single process (no torchrun): the C-ABI multi-GPU path"},
+        "roofline": None, "cpu_baseline": None}), flush=True)
+    for k, d in enumerate(zds):
+        m.member(k).dev_free(d)
+    mpk.free()
+    m.close()
+
+
 def bench_marlin(ctx, curve="bn254", samples=87381, reps=3, verify=True):
     """BASELINE configs[3]: Marlin create_random_proof (|H| = 2^20, |K| = 2^21, |B| = 2^23, SRS degree 6.29 M) on one GPU:
     device-side indexer + device-resident prover, verifier messages derived from the Fiat-Shamir transcript round by
@@ -174,6 +242,9 @@ def main():
                     help="groth16 (default, the BASELINE metric; its line also carries a short Marlin config-4 measurement "
                          "unless --no-marlin) or marlin: BASELINE configs[3] only")
     ap.add_argument("--no-marlin", action="store_true")
+    ap.add_argument("--devices", default="",
+                    help="single-process multi-GPU only: comma-separated device ids for zkp_ctx_create_multi (default 0..gpus-1; "
+                         "ids may repeat, e.g. 0,0,0 exercises the 3-rank path on a one-GPU box — not a multi-GPU measurement)")
     ap.add_argument("--single-device-test", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 and the collectives run over gloo (exercises the N>1 code path "
                          "on a one-GPU box; the number it prints is not a multi-GPU measurement)")
@@ -183,6 +254,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.devices):
+        # launched as ONE process for N GPUs: the in-library multi-GPU path behind the C boundary (zkp_ctx_create_multi)
+        return bench_single_process_multi(args)
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if args.single_device_test:
         local = 0
@@ -426,6 +500,7 @@ def main():
 
     # ---- CPU baseline (rank 0, N=1 only): oracle/cpu port of the reference algorithm on a bounded sample
     cpu_baseline = None
+    parity_check = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_oracle
         import statistics
@@ -464,6 +539,23 @@ def main():
             scale_all = scale_s
             sample_all = (f"2^{k}-domain MiMC chain ({inst_s.num_constraints()} constraints), median of 3 runs "
                           f"{[round(x, 2) for x in runs_all]} s on {cores} threads, scaled x{int(scale_s)} linearly")
+        # parity of THIS run: one (r, s), the device proof and the CPU port's proof of the same instance
+        # — the full 2^20 instance when the host is fast enough for it, else the bounded sample — must agree limb for limb
+        r_fix, s_fix = rand_fr(), rand_fr()
+        if scale_all == 1.0:
+            p_pk, p_params, p_inst, p_z, p_what = pk, params, inst, z, f"full 2^{args.log_n} instance"
+        else:
+            p_pk = groth16.ProvingKey(ctx, params_s, inst_s)
+            p_params, p_inst, p_z, p_what = params_s, inst_s, z_s, f"2^{k} sample"
+        d_out, d_inf = p_pk.prove_raw(p_z, r_fix, s_fix)
+        c_out, c_inf, _ = cpu_oracle.groth16_prove(p_params, p_inst, p_z, r_fix, s_fix, threads=cores)
+        h_eq = bool(np.array_equal(p_pk.witness_map(p_z), cpu_oracle.witness_map(p_params, p_inst, p_z, threads=cores)))
+        parity_check = {"device_eq_cpu_port": bool(np.array_equal(d_out, c_out) and np.array_equal(d_inf, c_inf)),
+                        "witness_map_eq_cpu_port": h_eq, "instance": p_what,
+                        "note": "same (r, s): zkp_groth16_prove vs oracle/cpu groth16_prove, proof limbs + identity flags; "
+                                "zkp_groth16_witness_map vs the port's witness_map, all N coefficients"}
+        if p_pk is not pk:
+            p_pk.free()
         # one thread: the bounded sample, 3 runs, median, scaled linearly
         t_one, runs_one, _ = timed(params_s, inst_s, z_s, 1, 3)
         cpu_baseline = {"value": round(1.0 / (t_all * scale_all), 6), "unit": "proofs/s", "cores": cores, "kind": "port",
@@ -500,7 +592,8 @@ def main():
                        "curve": c.name, "log_domain": args.log_n, "parallelism": f"independent proofs x{world}",
                        "pipelining": "none" if args.no_pipeline else f"{os.environ.get('ZKP_LANES', '8 (4 above 2^22)')} proofs in flight per GPU (zkp_groth16_prove_batch_dev), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}"},
             "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_scan": roofline_scan, "valu_roof": valu_roof,
-            "with_h2d": with_h2d, "latency": latency, "cpu_baseline": cpu_baseline, "msm_g1": msm_g1, "marlin_config4": marlin,
+            "with_h2d": with_h2d, "latency": latency, "cpu_baseline": cpu_baseline, "parity_check": parity_check,
+            "msm_g1": msm_g1, "marlin_config4": marlin,
             "phases_ms": phases,
         }
         print(json.dumps(out), flush=True)

@@ -12,8 +12,13 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
-LIBDIR = ROOT / "lib"
-OBJDIR = ROOT / "lib" / "obj"
+# A/B builds: ZKP_BUILD_TAG=<tag> ZKP_BUILD_DEFS="-DFOO -DBAR=1" python -m ckb_zkp_amd.build  ->  variants/<tag>/libzkp_accel.so
+# (own object directory; select it at run time with ZKP_ACCEL_LIB=variants/<tag>/libzkp_accel.so).  The shipped library is
+# the untagged build.
+TAG = os.environ.get("ZKP_BUILD_TAG", "")
+EXTRA_DEFS = os.environ.get("ZKP_BUILD_DEFS", "").split()
+LIBDIR = (ROOT.parent / "variants" / TAG) if TAG else ROOT / "lib"
+OBJDIR = LIBDIR / "obj"
 LIB = LIBDIR / "libzkp_accel.so"
 CONFIGS = [(0, 1), (0, 2), (1, 1), (1, 2)]        # (curve, group): BN254 G1/G2, BLS12-381 G1/G2
 # Full unrolling of the limb loops is part of the design (every index a compile-time constant, no scratch arrays).  The default
@@ -60,7 +65,7 @@ def _newer(target: Path, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    LIBDIR.mkdir(exist_ok=True)
+    LIBDIR.mkdir(parents=True, exist_ok=True)
     OBJDIR.mkdir(exist_ok=True)
     headers = sorted(CSRC.glob("*.hpp")) + sorted(CSRC.glob("*.inc")) + \
         [ROOT.parent / "include" / "zkp_accel.h"]
@@ -73,7 +78,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             return o, 0.0
         import time
         t0 = time.time()
-        cmd = [hipcc, *FLAGS, *extra, "-c", str(s), "-o", str(o)]
+        cmd = [hipcc, *FLAGS, *extra, *EXTRA_DEFS, "-c", str(s), "-o", str(o)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src} {extra}:\n{r.stdout}\n{r.stderr}")

@@ -125,10 +125,10 @@ struct BkPoint<Fp<P>> {
       bk_same_x<F>(*this, rd.f.template is_multiple_of_p<4>());
       return;
     }
-    const auto pp = ub_mul(pd, pd);                        // 16
+    const auto pp = ub_sqr(pd);                            // 16
     const auto ppp = ub_mul(pd, pp);
     const auto q = ub_mul(u1, pp);
-    const auto t = ub_sub(ub_mul(rd, rd), ppp);            // (0, 4p)
+    const auto t = ub_sub(ub_sqr(rd), ppp);                // (0, 4p)
     const UB<P, 8> x3 = ub_sub(t, ub_dbl(q));              // (0, 8p)
     const UB<P, 2> y3 = ub_mul_add(rd, ub_sub(q, x3), s1, ub_neg<2>(ppp));      // 4*10 + 2*2 = 44
     v.zz = ub_mul(ub_mul(v.zz, o.v.zz), pp);
@@ -140,12 +140,12 @@ struct BkPoint<Fp<P>> {
   ZKP_DEV BkPoint dbl() const {
     if (v.inf) return *this;
     const auto u = ub_dbl(v.y);                            // < 8p
-    const auto vv = ub_mul(u, u);                          // 64
+    const auto vv = ub_sqr(u);                             // 64
     const auto w = ub_mul(u, vv);
     const auto s = ub_mul(v.x, vv);
-    const auto x2 = ub_mul(v.x, v.x);                      // 64
+    const auto x2 = ub_sqr(v.x);                           // 64
     const auto m = ub_add3(ub_dbl(x2), x2);                // < 6p
-    const auto x3 = ub_sub(ub_mul(m, m), ub_dbl(s));       // (0, 6p)
+    const auto x3 = ub_sub(ub_sqr(m), ub_dbl(s));          // (0, 6p)
     const UB<P, 2> y3 = ub_mul_add(m, ub_sub(s, x3), w, ub_neg<4>(v.y));         // 6*8 + 2*4 = 56
     BkPoint r;
     r.v.x = {x3.f};
