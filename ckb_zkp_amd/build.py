@@ -78,7 +78,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             return o, 0.0
         import time
         t0 = time.time()
-        cmd = [hipcc, *FLAGS, *extra, *EXTRA_DEFS, "-c", str(s), "-o", str(o)]
+        unit_defs = os.environ.get("ZKP_BUILD_DEFS_" + Path(src).stem, "").split()     # e.g. ZKP_BUILD_DEFS_msm_group="-DFOO"
+        cmd = [hipcc, *FLAGS, *extra, *EXTRA_DEFS, *unit_defs, "-c", str(s), "-o", str(o)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src} {extra}:\n{r.stdout}\n{r.stderr}")

@@ -25,6 +25,10 @@ struct Affine {
     const char* q = reinterpret_cast<const char*>(p);
     return {F::load(q), F::load(q + 4 * F::N)};
   }
+  ZKP_DEV static Affine load_nt(const void* p) {
+    const char* q = reinterpret_cast<const char*>(p);
+    return {F::load_nt(q), F::load_nt(q + 4 * F::N)};
+  }
   ZKP_DEV void store(void* p) const {
     char* q = reinterpret_cast<char*>(p);
     x.store(q);

@@ -155,6 +155,18 @@ struct Fp {
     }
     return r;
   }
+  // the same with the non-temporal hint (streaming gathers that should not displace other kernels' lines in L2)
+  ZKP_DEV static Fp load_nt(const void* p) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    Fp r;
+    const u32x4_t* q = reinterpret_cast<const u32x4_t*>(p);
+#pragma unroll
+    for (int i = 0; i < N / 4; i++) {
+      u32x4_t x = __builtin_nontemporal_load(q + i);
+      r.v[4 * i] = x.x; r.v[4 * i + 1] = x.y; r.v[4 * i + 2] = x.z; r.v[4 * i + 3] = x.w;
+    }
+    return r;
+  }
   ZKP_DEV void store(void* p) const {
     uint4* q = reinterpret_cast<uint4*>(p);
 #pragma unroll
@@ -241,6 +253,10 @@ struct Fp2 {
   ZKP_DEV static Fp2 load(const void* p) {
     const char* q = reinterpret_cast<const char*>(p);
     return {B::load(q), B::load(q + 4 * P::N)};
+  }
+  ZKP_DEV static Fp2 load_nt(const void* p) {
+    const char* q = reinterpret_cast<const char*>(p);
+    return {B::load_nt(q), B::load_nt(q + 4 * P::N)};
   }
   ZKP_DEV void store(void* p) const {
     char* q = reinterpret_cast<char*>(p);

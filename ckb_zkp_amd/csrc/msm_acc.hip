@@ -34,32 +34,58 @@ using CfgF = Fp2<CfgFq>;
 namespace ZKP_CFG_SYM(cfg) {}
 using namespace ZKP_CFG_SYM(cfg);
 
+// -DZKP_ACC_NT_GATHER: window-table gathers carry the non-temporal hint (A/B switch)
+#if defined(ZKP_ACC_NT_GATHER)
+#define ZKP_GATHER load_nt
+#else
+#define ZKP_GATHER load
+#endif
+
 namespace ZKP_CFG_SYM(cfg) {
+// One 16-B load brings four consecutive values of the lane's run (entries are 4 B; a lane walks its own run, so the 64 lanes of
+// a wave touch 64 different lines per step and a 4-B load per entry cost up to one 128-B fabric read each once the window-table
+// gathers had swept the line out of L2: PMC, 1.55 -> 1.30 read requests per entry with four values per load, eight values now).
+struct ValQuads {
+  const uint32_t* vals;
+  uint4 q0, q1;                                     // eight consecutive values: one 32-B-aligned pair of 16-B loads per 8 entries
+  __device__ __forceinline__ void fill(uint32_t e) {
+    const uint4* p = reinterpret_cast<const uint4*>(vals + (e & ~7u));
+    q0 = p[0];
+    q1 = p[1];
+  }
+  __device__ __forceinline__ ValQuads(const uint32_t* v, uint32_t e0) : vals(v) { fill(e0); }
+  __device__ __forceinline__ uint32_t get(uint32_t e, uint32_t e0) {
+    const uint32_t k = e & 7u;
+    if (k == 0 && e != e0) fill(e);
+    const uint4 q = (k & 4u) ? q1 : q0;
+    const uint32_t j = k & 3u;
+    return j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w;
+  }
+};
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __restrict__ table,
                                                          const uint32_t* __restrict__ vals,
-                                                         const uint32_t* __restrict__ order,
-                                                         const uint32_t* __restrict__ task_start,
-                                                         const uint32_t* __restrict__ task_len,
-                                                         const uint32_t* __restrict__ task_dst,
+                                                         const uint4* __restrict__ desc,
                                                          const uint32_t* __restrict__ n_tasks_dev,
                                                          char* __restrict__ buckets, char* __restrict__ partial, uint32_t idx_mask,
                                                          uint32_t* __restrict__ redo) {
   using F = CfgF;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *n_tasks_dev) return;
-  const uint32_t id = order[t];
-  const uint32_t e0 = task_start[id], e1 = e0 + task_len[id];
-  const uint32_t d = task_dst[id];
+  const uint4 td = desc[t];
+  const uint32_t id = t;                       // what the redo list records: the task's position in the schedule
+  const uint32_t e0 = td.x, e1 = e0 + td.y;
+  const uint32_t d = td.z;
   // buckets and partial sums are BkPoint<F> (unsaturated layout): the accumulator is stored as it stands
   char* out = (d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * BkPoint<F>::BYTES : buckets + (size_t)d * BkPoint<F>::BYTES;
+  ValQuads vq(vals, e0);
 #if ZKP_CFG_GROUP == 1 && defined(ZKP_ACC_UNSAT)
   // G1: accumulate on unsaturated limbs (unsat_dev.hpp); the window table and the buckets keep the saturated layout
   XYZZu<CfgFq> acc;
   acc.inf = true;
   for (uint32_t e = e0; e < e1; e++) {
-    uint32_t v = vals[e];
-    Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
+    uint32_t v = vq.get(e, e0);
+    Affine<F> p = Affine<F>::ZKP_GATHER(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
     if (p.is_inf()) continue;
     if (v >> 31) p.y = p.y.neg();
     const Fu<CfgFq> ux = Fu<CfgFq>::from_sat(p.x), uy = Fu<CfgFq>::from_sat(p.y);
@@ -78,8 +104,8 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   XYZZu2<CfgFq> acc;
   acc.inf = true;
   for (uint32_t e = e0; e < e1; e++) {
-    uint32_t v = vals[e];
-    Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
+    uint32_t v = vq.get(e, e0);
+    Affine<F> p = Affine<F>::ZKP_GATHER(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
     if (p.is_inf()) continue;
     if (v >> 31) p.y = p.y.neg();
     using U = Fu<CfgFq>;
@@ -96,8 +122,8 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   // (a software-pipelined gather of entry e+1 was tried twice — G1: +20 VGPRs -> spills; G2 after the redo split:
   //  276 VGPRs -> 1 wave/SIMD, or 256 with launch bounds — no gain either time: the gather latency is covered)
   for (uint32_t e = e0; e < e1; e++) {
-    uint32_t v = vals[e];
-    Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
+    uint32_t v = vq.get(e, e0);
+    Affine<F> p = Affine<F>::ZKP_GATHER(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
     if (v >> 31) p.y = p.y.neg();
     if (!acc.madd_fast(p)) {                     // p = +-acc: the exact redo kernel takes the whole task
       redo[1 + atomicAdd(redo, 1u)] = id;
@@ -109,16 +135,14 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
 }
 // exact (saturated, all exceptional cases) accumulation of the tasks listed in redo[1 .. redo[0]]
 __global__ __launch_bounds__(64) void accumulate_redo_kernel(const char* __restrict__ table, const uint32_t* __restrict__ vals,
-                                                            const uint32_t* __restrict__ task_start,
-                                                            const uint32_t* __restrict__ task_len,
-                                                            const uint32_t* __restrict__ task_dst, char* __restrict__ buckets,
+                                                            const uint4* __restrict__ desc, char* __restrict__ buckets,
                                                             char* __restrict__ partial, uint32_t idx_mask,
                                                             const uint32_t* __restrict__ redo) {
   using F = CfgF;
   const uint32_t count = redo[0];
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
-    const uint32_t id = redo[1 + k];
-    const uint32_t e0 = task_start[id], e1 = e0 + task_len[id];
+    const uint4 td = desc[redo[1 + k]];
+    const uint32_t e0 = td.x, e1 = e0 + td.y;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t e = e0; e < e1; e++) {
       uint32_t v = vals[e];
@@ -126,7 +150,7 @@ __global__ __launch_bounds__(64) void accumulate_redo_kernel(const char* __restr
       if (v >> 31) p.y = p.y.neg();
       acc.madd(p);
     }
-    const uint32_t d = task_dst[id];
+    const uint32_t d = td.z;
     BkPoint<F>::from_sat(acc).store((d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * BkPoint<F>::BYTES
                                               : buckets + (size_t)d * BkPoint<F>::BYTES);
   }
@@ -143,8 +167,7 @@ static uint32_t dbg_mask() {
   return 0x7fffffffu;
 #endif
 }
-void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint32_t* order,
-                                        const uint32_t* task_start, const uint32_t* task_len, const uint32_t* task_dst,
+void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint4* desc,
                                         const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial,
                                         uint32_t* redo) {
   // G2: 1 wave/SIMD (VGPRs + AGPRs as spill space, default) vs 2 waves/SIMD (256 VGPRs + 704 B scratch): the latter makes
@@ -156,31 +179,32 @@ void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const 
   struct Redo {                                  // every launch path below is followed by the exact redo kernel
     hipStream_t s;
     const char* table;
-    const uint32_t *vals, *task_start, *task_len, *task_dst;
+    const uint32_t* vals;
+    const uint4* desc;
     char *buckets, *partial;
     uint32_t* redo;
     ~Redo() {
-      hipLaunchKernelGGL(accumulate_redo_kernel, dim3(64), dim3(64), 0, s, table, vals, task_start, task_len, task_dst,
-                         buckets, partial, dbg_mask(), redo);
+      hipLaunchKernelGGL(accumulate_redo_kernel, dim3(64), dim3(64), 0, s, table, vals, desc, buckets, partial,
+                         dbg_mask(), redo);
     }
-  } redo_after{s, table, vals, task_start, task_len, task_dst, buckets, partial, redo};
+  } redo_after{s, table, vals, desc, buckets, partial, redo};
 #if ZKP_CFG_GROUP == 1 && defined(ZKP_ACC_UNSAT)
-  hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
-                     task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
+  hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
+                     n_tasks_dev, buckets, partial, dbg_mask(), redo);
   return;
 #endif
   if (ZKP_CFG_GROUP == 1 && occ1 == 4)
-    hipLaunchKernelGGL(accumulate_kernel<4>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
-                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
+    hipLaunchKernelGGL(accumulate_kernel<4>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
   else if (ZKP_CFG_GROUP == 2 && occ == 3)
-    hipLaunchKernelGGL(accumulate_kernel<3>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
-                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
+    hipLaunchKernelGGL(accumulate_kernel<3>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
   else if (ZKP_CFG_GROUP == 2 && occ == 2)
-    hipLaunchKernelGGL(accumulate_kernel<2>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
-                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
+    hipLaunchKernelGGL(accumulate_kernel<2>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
   else
-    hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, order,
-                       task_start, task_len, task_dst, n_tasks_dev, buckets, partial, dbg_mask(), redo);
+    hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
 }
 
 }  // namespace zkp

@@ -445,9 +445,8 @@ __global__ __launch_bounds__(64) void assemble_g2_kernel(const char* __restrict_
 }  // namespace ZKP_CFG_SYM(cfg)
 
 // ------------------------------------------------------------------------------------------- launch table
-void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t, const char*, const uint32_t*, const uint32_t*, const uint32_t*,
-                                        const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*,
-                                        char*, uint32_t*);   // msm_acc.hip
+void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t, const char*, const uint32_t*, const uint4*, const uint32_t*, uint32_t,
+                                        char*, char*, uint32_t*);   // msm_acc.hip
 
 namespace {
 using F = CfgF;

@@ -37,8 +37,9 @@ struct MsmVtbl {
   void (*precompute)(hipStream_t, char* table, size_t n, int c, int W, int wide);
   // one lane per TASK (<= MSM_TASK_CAP consecutive entries of one bucket, tasks ordered by length);
   // dst < 0x80000000: bucket index (single-task bucket), else partial slot (dst & 0x7fffffff)
-  void (*accumulate)(hipStream_t, const char* table, const uint32_t* vals, const uint32_t* order,
-                     const uint32_t* task_start, const uint32_t* task_len, const uint32_t* task_dst,
+  // desc[t] = {first entry, length, dst, -} of the t-th task IN SCHEDULE ORDER (task_order_kernel): one coalesced 16-B load per
+  // lane instead of four dependent random ones
+  void (*accumulate)(hipStream_t, const char* table, const uint32_t* vals, const uint4* desc,
                      const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial, uint32_t* redo);
   // redo: max_tasks + 1 words of scratch ([0] = count, zeroed by the launcher): tasks the fast path abandoned because an
   // operand might equal +-accumulator are listed there and redone by an exact second kernel

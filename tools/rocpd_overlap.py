@@ -46,3 +46,24 @@ for t, d in ev:
 print(f"window {wall/1e6:.1f} ms: union coverage {busy/wall:.3f}, mean concurrency {area/wall:.2f}")
 for k, (n, t) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k:36s} launches {n:6d}  busy {t/1e6:9.2f} ms  = {t/wall:.3f} of the window")
+
+
+def coverage(pred):
+    iv = [(s, e) for k, s, e in sel if pred(syms.get(k, ""))]
+    ev2 = sorted([(s, 1) for s, e in iv] + [(e, -1) for s, e in iv])
+    busy2, area2, d2, last2 = 0, 0, 0, a
+    for t, d in ev2:
+        if d2 > 0:
+            busy2 += t - last2
+        area2 += d2 * (t - last2)
+        d2 += d
+        last2 = t
+    return busy2 / wall, area2 / wall
+
+
+# how much of the window has at least one VALU-bound (machine-filling) kernel in flight, and how many at once
+for label, pred in (("accumulate", lambda n: "accumulate_kernel" in n),
+                    ("accumulate|ntt_pass", lambda n: "accumulate_kernel" in n or "ntt_pass" in n),
+                    ("accumulate|ntt|pair|segsum", lambda n: any(x in n for x in ("accumulate_kernel", "ntt_pass", "pair_kernel", "segsum")))):
+    c, m = coverage(pred)
+    print(f"  >= 1 {label:28s} in flight: {c:.3f} of the window, mean concurrency {m:.2f}")
