@@ -128,9 +128,8 @@ struct BkPoint<Fp<P>> {
     const auto pp = ub_sqr(pd);                            // 16
     const auto ppp = ub_mul(pd, pp);
     const auto q = ub_mul(u1, pp);
-    const auto t = ub_sub(ub_sqr(rd), ppp);                // (0, 4p)
-    const UB<P, 8> x3 = ub_sub(t, ub_dbl(q));              // (0, 8p)
-    const UB<P, 2> y3 = ub_mul_add(rd, ub_sub(q, x3), s1, ub_neg<2>(ppp));      // 4*10 + 2*2 = 44
+    const UB<P, 8> x3 = ub_sub_sub2(ub_sqr(rd), ppp, q);   // R^2 - PPP - 2Q + 6p, one carry chain: (0, 8p)
+    const UB<P, 2> y3 = ub_mul_add(rd, ub_sub_lazy(q, x3), s1, ub_neg_lazy(ppp));      // lazy-limb second factors: 4*11 + 2*3 = 50
     v.zz = ub_mul(ub_mul(v.zz, o.v.zz), pp);
     v.zzz = ub_mul(ub_mul(v.zzz, o.v.zzz), ppp);
     v.x = x3;
@@ -146,7 +145,7 @@ struct BkPoint<Fp<P>> {
     const auto x2 = ub_sqr(v.x);                           // 64
     const auto m = ub_add3(ub_dbl(x2), x2);                // < 6p
     const auto x3 = ub_sub(ub_sqr(m), ub_dbl(s));          // (0, 6p)
-    const UB<P, 2> y3 = ub_mul_add(m, ub_sub(s, x3), w, ub_neg<4>(v.y));         // 6*8 + 2*4 = 56
+    const UB<P, 2> y3 = ub_mul_add(m, ub_sub_lazy(s, x3), w, ub_neg_lazy(v.y));         // 6*9 + 2*5 = 64
     BkPoint r;
     r.v.x = {x3.f};
     r.v.y = {y3.f};

@@ -83,13 +83,26 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   // G1: accumulate on unsaturated limbs (unsat_dev.hpp); the window table and the buckets keep the saturated layout
   XYZZu<CfgFq> acc;
   acc.inf = true;
+#if defined(ZKP_ACC_PREFETCH)
+  // software pipeline: the gather of entry e + 1 is in flight while entry e is added (A/B switch; + 16 VGPRs -> 3 waves/SIMD)
+  uint32_t v_next = vq.get(e0, e0);
+  Affine<F> p_next = Affine<F>::ZKP_GATHER(table + (size_t)(v_next & idx_mask) * Affine<F>::BYTES);
+#endif
   for (uint32_t e = e0; e < e1; e++) {
+#if defined(ZKP_ACC_PREFETCH)
+    const uint32_t v = v_next;
+    Affine<F> p = p_next;
+    if (e + 1 < e1) {
+      v_next = vq.get(e + 1, e0);
+      p_next = Affine<F>::ZKP_GATHER(table + (size_t)(v_next & idx_mask) * Affine<F>::BYTES);
+    }
+#else
     uint32_t v = vq.get(e, e0);
     Affine<F> p = Affine<F>::ZKP_GATHER(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
+#endif
     if (p.is_inf()) continue;
-    if (v >> 31) p.y = p.y.neg();
     const Fu<CfgFq> ux = Fu<CfgFq>::from_sat(p.x), uy = Fu<CfgFq>::from_sat(p.y);
-    if (!xyzz_madd_u<CfgFq>(acc, ux, uy)) {
+    if (!xyzz_madd_u<CfgFq>(acc, ux, uy, 0u - (v >> 31))) {   // the digit's sign goes into the formulas (R = +-S2 - Y1)
       // the operand may equal +-accumulator (doubling / cancellation): leave the whole task to
       // the exact kernel below instead of carrying the exceptional formulas through the hot loop's register budget
       redo[1 + atomicAdd(redo, 1u)] = id;
@@ -107,9 +120,9 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
     uint32_t v = vq.get(e, e0);
     Affine<F> p = Affine<F>::ZKP_GATHER(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
     if (p.is_inf()) continue;
-    if (v >> 31) p.y = p.y.neg();
     using U = Fu<CfgFq>;
-    if (!xyzz_madd_u2<CfgFq>(acc, U::from_sat(p.x.c0), U::from_sat(p.x.c1), U::from_sat(p.y.c0), U::from_sat(p.y.c1))) {
+    if (!xyzz_madd_u2<CfgFq>(acc, U::from_sat(p.x.c0), U::from_sat(p.x.c1), U::from_sat(p.y.c0), U::from_sat(p.y.c1),
+                             0u - (v >> 31))) {
       redo[1 + atomicAdd(redo, 1u)] = id;
       return;
     }
