@@ -129,6 +129,7 @@ struct zkp_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // zkp_timer_*
   hipEvent_t ev2 = nullptr, ev3 = nullptr;   // internal per-kernel timing
   bool profiling = false;
+  bool dbg_skip_k8 = false;    // ABLATION ONLY (ZKP_DEBUG_SKIP_K8_MASK): the next MSM skips its bucket reduction — wrong results, timing experiments
   bool batch_mode = false;     // inside zkp_groth16_prove_batch*: kernels are tuned for throughput of many proofs in flight, not latency
   std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)
   zkp::DevBuf ntt_io, poly_tmp, poly_consts, spmv_list;

@@ -57,6 +57,7 @@ struct BasesEntry {
   size_t n = 0;
   int c = 0, W = 0;            // bucket bits (= width of the wide windows), number of windows
   int wide = 0;                // the first `wide` windows are c bits wide, the remaining W - wide are c - 1 (balanced windows)
+  uint32_t cap = MSM_TASK_CAP; // entries per task (<= MSM_TASK_CAP): smaller = more lanes for MSMs with few, long buckets
   char* table = nullptr;       // W * n affine points: T[w][i] = 2^(c*w) * P_i
   uint8_t* inf = nullptr;      // n identity flags (device) or nullptr
   // Variable-base mode (zkp_msm_g*_var): no window tables — `table` holds the n points as uploaded, the digit scan emits
@@ -114,6 +115,11 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, co
     e->W = (T + c0 - 1) / c0;
     e->c = balanced ? (T + e->W - 1) / e->W : c0;
     e->wide = balanced ? T - e->W * (e->c - 1) : e->W;
+  }
+  {
+    const char* env = group == 2 ? getenv("ZKP_TASK_CAP_G2") : nullptr;
+    if (!env) env = getenv("ZKP_TASK_CAP");
+    if (env && atoi(env) >= 4) e->cap = std::min<uint32_t>(MSM_TASK_CAP, (uint32_t)atoi(env));
   }
   ZKP_REQUIRE((double)n * e->W < 2147483000.0, ZKP_ERR_BAD_ARG);
   const size_t ab = e->vt->aff_bytes;
@@ -183,7 +189,7 @@ void bases_set_filter_bit(zkp_ctx* ctx, uint64_t handle, int bit) {
 }
 bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2) {
   auto a = get_bases(ctx, h1), b = get_bases(ctx, h2);
-  return a->curve == b->curve && a->n == b->n && a->c == b->c && a->W == b->W && a->wide == b->wide;
+  return a->curve == b->curve && a->n == b->n && a->c == b->c && a->W == b->W && a->wide == b->wide && a->cap == b->cap;
 }
 
 // ------------------------------------------------------------------------------------------- K5 digit scan
@@ -460,10 +466,22 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
 constexpr int TM_NLONG = 0, TM_HIST = 1, TM_CUR = 256, TM_WORDS = 512;
 
 __global__ void task_count_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nb,
-                                  uint32_t* __restrict__ tcount) {
+                                  uint32_t* __restrict__ tcount, uint32_t cap) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b > nb) return;
-  tcount[b] = b < nb ? (end[b] - start[b] + MSM_TASK_CAP - 1) / MSM_TASK_CAP : 0;
+  tcount[b] = b < nb ? (end[b] - start[b] + cap - 1) / cap : 0;
+}
+
+// Empty buckets get the identity (all-zero bytes: zz == 0) here instead of a memset of the whole bucket array in front of every
+// accumulate launch (75 / 151 MB of writes per 2^20 G1 / G2 MSM, 0.45 GB per proof): every non-empty bucket is written by the
+// accumulate, redo or combine kernels.
+__global__ __launch_bounds__(256) void zero_empty_buckets_kernel(const uint32_t* __restrict__ start,
+                                                                 const uint32_t* __restrict__ end, uint32_t nb,
+                                                                 char* __restrict__ buckets, uint32_t xb) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb || end[b] != start[b]) return;
+  uint4* p = reinterpret_cast<uint4*>(buckets + (size_t)b * xb);
+  for (uint32_t k = 0; k < xb / 16; k++) p[k] = make_uint4(0, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(256) void task_fill_kernel(const uint32_t* __restrict__ start,
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(256) void task_fill_kernel(const uint32_t* __restri
                                                         uint32_t* __restrict__ task_len,
                                                         uint32_t* __restrict__ task_dst,
                                                         uint32_t* __restrict__ long_list,
-                                                        uint32_t* __restrict__ tmeta) {
+                                                        uint32_t* __restrict__ tmeta, uint32_t cap) {
   __shared__ uint32_t hist[MSM_TASK_CAP + 1];
   for (int i = threadIdx.x; i <= (int)MSM_TASK_CAP; i += blockDim.x) hist[i] = 0;
   __syncthreads();
@@ -483,8 +501,8 @@ __global__ __launch_bounds__(256) void task_fill_kernel(const uint32_t* __restri
     const uint32_t t0 = toff[b], nt = toff[b + 1] - t0;
     if (nt > 1) long_list[atomicAdd(&tmeta[TM_NLONG], 1u)] = b;
     for (uint32_t j = 0; j < nt; j++) {
-      uint32_t l = min(MSM_TASK_CAP, len - j * MSM_TASK_CAP);
-      task_start[t0 + j] = s + j * MSM_TASK_CAP;
+      uint32_t l = min(cap, len - j * cap);
+      task_start[t0 + j] = s + j * cap;
       task_len[t0 + j] = l;
       task_dst[t0 + j] = nt == 1 ? b : (0x80000000u | (t0 + j));
       atomicAdd(&hist[l], 1u);
@@ -696,7 +714,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
                          kv, offs, nblocks, LB, vals, start, end, (l1_reuse || grp) ? be->filter_bit : -1);
     uint32_t* const sorted_vals = vals;
     // K7 scheduling: buckets -> tasks (<= CAP entries), ordered by length
-    const uint32_t max_tasks = nb + (uint32_t)(E / MSM_TASK_CAP) + 1;
+    const uint32_t max_tasks = nb + (uint32_t)(E / be->cap) + 1;
     uint32_t* sched = sw.sched.as<uint32_t>((size_t)2 * (nb + 2) + (size_t)8 * max_tasks + TM_WORDS + 8);
     uint32_t* tcount = sched;                       // nb + 1
     uint32_t* toff = tcount + (nb + 2);             // nb + 1  (toff[nb] = number of tasks)
@@ -708,10 +726,10 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     uint4* desc = reinterpret_cast<uint4*>((reinterpret_cast<uintptr_t>(tmeta + TM_WORDS) + 15) & ~(uintptr_t)15);   // max_tasks x 16 B
     if (!reuse) {
       ZKP_HIP(hipMemsetAsync(tmeta, 0, TM_WORDS * 4, st));
-      hipLaunchKernelGGL(task_count_kernel, dim3((nb + 256) / 256), dim3(256), 0, st, start, end, nb, tcount);
+      hipLaunchKernelGGL(task_count_kernel, dim3((nb + 256) / 256), dim3(256), 0, st, start, end, nb, tcount, be->cap);
       exclusive_scan_u32(st, tcount, toff, (size_t)nb + 1, ws.scan_tmp2);
       hipLaunchKernelGGL(task_fill_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, start, end, toff, nb, task_start,
-                         task_len, task_dst, long_list, tmeta);
+                         task_len, task_dst, long_list, tmeta, be->cap);
       hipLaunchKernelGGL(task_cursor_kernel, dim3(1), dim3(64), 0, st, tmeta);
       hipLaunchKernelGGL(task_order_kernel, dim3((max_tasks + 255) / 256), dim3(256), 0, st, task_start, task_len, task_dst,
                          toff + nb, tmeta, desc);
@@ -721,7 +739,9 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     // all-zero bytes are a valid identity (zz == 0), so empty buckets need no kernel
     char* buckets = reinterpret_cast<char*>(ws.buckets.get((size_t)2 * nb * XB + XB));
     char* task_partial = reinterpret_cast<char*>(ws.partial.get((size_t)max_tasks * XB));
-    ZKP_HIP(hipMemsetAsync(buckets, 0, (size_t)nb * XB, st));
+    static const bool zero_all = getenv("ZKP_MEMSET_BUCKETS") && atoi(getenv("ZKP_MEMSET_BUCKETS")) != 0;   // A/B: round-2 behaviour
+    if (zero_all) ZKP_HIP(hipMemsetAsync(buckets, 0, (size_t)nb * XB, st));
+    else hipLaunchKernelGGL(zero_empty_buckets_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, start, end, nb, buckets, (uint32_t)XB);
     const bool timed = ms_accumulate && ctx->profiling;
     if (timed) ZKP_HIP(hipEventRecord(ctx->ev2, st));
     vt->accumulate(st, be->table, sorted_vals, desc, toff + nb, max_tasks, buckets, task_partial,
@@ -782,6 +802,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       }
       return;
     }
+    if (ctx->dbg_skip_k8) return;                  // ablation experiments only (wrong result)
     // K8: pyramid
     const int L = c - 1;                           // levels with odd entries: 0..L-1 ; root = level L
     SegPlan plan{};

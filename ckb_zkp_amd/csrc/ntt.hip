@@ -26,6 +26,7 @@
 
 #include "ctx.hpp"
 #include "field_dev.hpp"
+#include "unsat_dev.hpp"
 
 namespace zkp {
 
@@ -189,18 +190,36 @@ __global__ __launch_bounds__(256) void ntt_full_table_kernel(uint32_t* __restric
   (F::load(hi + (size_t)(e >> h) * 8) * F::load(lo + (size_t)(e & ((1u << h) - 1)) * 8)).store(out + (size_t)i * 8);
 }
 
+// Round 3: the products of a pass run on the UNSATURATED multiplier (unsat_dev.hpp: 9 x 29-bit limbs, one v_mad_u64_u32 per
+// partial product, 205 instead of ~330 VALU instructions) while the data stay saturated (canonical Montgomery words) in LDS and
+// HBM, so additions / subtractions keep their carry-chain forms: x enters by a plain limb repack (value < p), the table factor t
+// (a twiddle / coset factor, canonical t * 2^256) as from_sat(t) = t * R' (< 32p: 1 * 32 <= floor(R' / r), also for the 255-bit
+// BLS12-381 scalar field), the product x t * 2^256 < 2p leaves by a repack and one conditional subtraction.  The butterfly
+// twiddle tile is converted once per workgroup (9 words per twiddle in LDS).
+template <class P>
+ZKP_DEV Fp<P> ntt_mul(const Fp<P>& x, const Fu<P>& t) {
+  Fu<P> r = Fu<P>::mul(Fu<P>::from_words(x.v, 0), t);
+  Fp<P> o;
+  r.to_words(o.v);
+  return Fp<P>::reduce_once(o);
+}
+template <class P>
+ZKP_DEV Fu<P> ntt_factor(const uint32_t* p) { return Fu<P>::from_sat(Fp<P>::load(p)); }
+
 // 129 VGPRs -> 3 workgroups per CU.  Forcing 128 (launch bounds (256, 4): 3 spilled registers, 4 workgroups per CU) was
 // measured slower: 0.181 vs 0.174 ms per 2^20 transform, 110-112 vs 113-115 proofs/s.
 template <class P>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   using F = Fp<P>;
+  using U = Fu<P>;
+  constexpr int UL = U::L;
   const uint32_t* __restrict__ in = a.in[blockIdx.y];
   uint32_t* __restrict__ out = a.out[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int S = a.S, logC = a.logC;
   const int R = 1 << S, C = 1 << logC;
   const int TILE = R << logC;
-  uint32_t* tw_l = lds + 8 * TILE;                 // R/2 twiddles, AoS (broadcast reads)
+  uint32_t* tw_l = lds + 8 * TILE;                 // R/2 twiddles as product factors (from_sat: UL words each), AoS (broadcast reads)
   const uint32_t ncols = 1u << (a.log_n - S);
   const uint32_t c0 = blockIdx.x << logC;
   const int tid = threadIdx.x;
@@ -209,9 +228,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   // sub-FFT twiddle tile -> LDS
   {
     const int shift = a.sub_log - S;               // w_R^k = w_Rsub^(k << shift)
-    for (int k = tid; k < (R >> 1) * 8; k += NTT_THREADS) {
-      int e = k >> 3, l = k & 7;
-      tw_l[k] = a.tw_sub[((size_t)(e << shift)) * 8 + l];
+    for (int e = tid; e < (R >> 1); e += NTT_THREADS) {
+      const U t = ntt_factor<P>(a.tw_sub + ((size_t)(e << shift)) * 8);
+#pragma unroll
+      for (int l = 0; l < UL; l++) tw_l[e * UL + l] = t.v[l];
     }
   }
   // load tile (coalesced runs of C elements), optional coset pre-scale
@@ -219,12 +239,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
     uint32_t j1 = e >> logC, cc = e & (C - 1);
     uint32_t gidx = j1 * ncols + c0 + cc;
     F x = F::load(in + (size_t)gidx * 8);
-    if (a.fuse_b) x = (x * F::load(a.fuse_b + (size_t)gidx * 8) - F::load(a.fuse_c + (size_t)gidx * 8)) * F::load(a.fuse_k);
+    if (a.fuse_b)
+      x = ntt_mul(ntt_mul(x, ntt_factor<P>(a.fuse_b + (size_t)gidx * 8)) - F::load(a.fuse_c + (size_t)gidx * 8), ntt_factor<P>(a.fuse_k));
     if (a.pre_full) {
-      x = x * F::load(a.pre_full + (size_t)gidx * 8);
+      x = ntt_mul(x, ntt_factor<P>(a.pre_full + (size_t)gidx * 8));
     } else if (a.pre_lo) {
-      F s = F::load(a.pre_hi + (size_t)(gidx >> a.h) * 8) * F::load(a.pre_lo + (size_t)(gidx & hmask) * 8);
-      x = x * s;
+      F s = ntt_mul(F::load(a.pre_hi + (size_t)(gidx >> a.h) * 8), ntt_factor<P>(a.pre_lo + (size_t)(gidx & hmask) * 8));
+      x = ntt_mul(x, U::from_sat(s));
     }
 #pragma unroll
     for (int l = 0; l < 8; l++) lds[l * TILE + e] = x.v[l];
@@ -251,21 +272,21 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
         x2.v[l] = lds[l * TILE + p2];
         x3.v[l] = lds[l * TILE + p3];
       }
-      F ta, tb;
+      U ta, tb;
 #pragma unroll
-      for (int l = 0; l < 8; l++) {
-        ta.v[l] = tw_l[((pos << s) << 3) + l];
-        tb.v[l] = tw_l[(((pos + quarter) << s) << 3) + l];
+      for (int l = 0; l < UL; l++) {
+        ta.v[l] = tw_l[(pos << s) * UL + l];
+        tb.v[l] = tw_l[((pos + quarter) << s) * UL + l];
       }
-      F y0 = x0 + x2, y2 = (x0 - x2) * ta;
-      F y1 = x1 + x3, y3 = (x1 - x3) * tb;
+      F y0 = x0 + x2, y2 = ntt_mul(x0 - x2, ta);
+      F y1 = x1 + x3, y3 = ntt_mul(x1 - x3, tb);
       F z0 = y0 + y1, z1 = y0 - y1, z2 = y2 + y3, z3 = y2 - y3;
       if (s + 2 < S) {                                     // the last stage's twiddle is w^0
-        F tc;
+        U tc;
 #pragma unroll
-        for (int l = 0; l < 8; l++) tc.v[l] = tw_l[((pos << (s + 1)) << 3) + l];
-        z1 = z1 * tc;
-        z3 = z3 * tc;
+        for (int l = 0; l < UL; l++) tc.v[l] = tw_l[(pos << (s + 1)) * UL + l];
+        z1 = ntt_mul(z1, tc);
+        z3 = ntt_mul(z3, tc);
       }
 #pragma unroll
       for (int l = 0; l < 8; l++) {
@@ -295,10 +316,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       F y0 = x0 + x1;
       F y1 = x0 - x1;
       if (s + 1 < S) {                                   // the last stage's twiddle is w^0
-        F tw;
+        U tw;
 #pragma unroll
-        for (int l = 0; l < 8; l++) tw.v[l] = tw_l[((pos << s) << 3) + l];
-        y1 = y1 * tw;
+        for (int l = 0; l < UL; l++) tw.v[l] = tw_l[(pos << s) * UL + l];
+        y1 = ntt_mul(y1, tw);
       }
 #pragma unroll
       for (int l = 0; l < 8; l++) {
@@ -327,22 +348,22 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
     for (int l = 0; l < 8; l++) x.v[l] = lds[l * TILE + pos];
     if (!a.last) {
       if (a.tw_full) {
-        x = x * F::load(a.tw_full + (size_t)oidx * 8);
+        x = ntt_mul(x, ntt_factor<P>(a.tw_full + (size_t)oidx * 8));
       } else {
         uint32_t e = bj * k1;                           // < N
         if (e) {
-          F t = F::load(a.tw_hi + (size_t)(e >> a.h) * 8) * F::load(a.tw_lo + (size_t)(e & hmask) * 8);
-          x = x * t;
+          F t = ntt_mul(F::load(a.tw_hi + (size_t)(e >> a.h) * 8), ntt_factor<P>(a.tw_lo + (size_t)(e & hmask) * 8));
+          x = ntt_mul(x, U::from_sat(t));
         }
       }
     }
     if (a.post_full) {
-      x = x * F::load(a.post_full + (size_t)oidx * 8);
+      x = ntt_mul(x, ntt_factor<P>(a.post_full + (size_t)oidx * 8));
     } else if (a.post_lo) {
-      F t = F::load(a.post_hi + (size_t)(oidx >> a.h) * 8) * F::load(a.post_lo + (size_t)(oidx & hmask) * 8);
-      x = x * t;
+      F t = ntt_mul(F::load(a.post_hi + (size_t)(oidx >> a.h) * 8), ntt_factor<P>(a.post_lo + (size_t)(oidx & hmask) * 8));
+      x = ntt_mul(x, U::from_sat(t));
     } else if (a.post_const) {
-      x = x * F::load(a.post_const);
+      x = ntt_mul(x, ntt_factor<P>(a.post_const));
     }
     x.store(out + (size_t)oidx * 8);
   }
@@ -433,7 +454,7 @@ void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* const* data, int count, int lo
       }
     }
     const int tile = 1 << (S[p] + logC);
-    const size_t lds_bytes = (size_t)tile * 32 + ((size_t)1 << S[p]) / 2 * 32 + 32;
+    const size_t lds_bytes = (size_t)tile * 32 + ((size_t)1 << S[p]) / 2 * 4 * Fu<P>::L + 32;
     const uint32_t grid = (uint32_t)(N >> (S[p] + logC));
     hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid, count), dim3(NTT_THREADS), lds_bytes, ctx->cur->stream, a);
     in_scratch = to_scratch;
@@ -464,7 +485,7 @@ static void launch_pass(zkp_ctx* ctx, NttTables& t, int log_n, const int* S, int
   a.tw_hi = inverse ? t.wi_hi : t.w_hi;
   if (!a.last) a.tw_full = full_table<P>(ctx, t, inverse ? &t.full_inv[p] : &t.full_fwd[p], a.tw_lo, a.tw_hi, S[p], logB, 1);
   const int tile = 1 << (S[p] + logC);
-  const size_t lds_bytes = (size_t)tile * 32 + ((size_t)1 << S[p]) / 2 * 32 + 32;
+  const size_t lds_bytes = (size_t)tile * 32 + ((size_t)1 << S[p]) / 2 * 4 * Fu<P>::L + 32;
   const uint32_t grid = (uint32_t)(((size_t)1 << log_n) >> (S[p] + logC));
   hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid, 1), dim3(NTT_THREADS), lds_bytes, ctx->cur->stream, a);
 }

@@ -17,7 +17,7 @@ column i + L), and the last shift + move is one v_alignbit_b32.
 """
 import sys
 
-CFGS = [("Bn254Fq", 9, 29), ("Bls381Fq", 14, 28)]
+CFGS = [("Bn254Fq", 9, 29), ("Bls381Fq", 14, 28), ("Bn254Fr", 9, 29), ("Bls381Fr", 9, 29)]
 
 
 def gen(L, B, nprod, square=False):
