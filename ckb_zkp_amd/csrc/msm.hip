@@ -38,6 +38,13 @@
 
 namespace zkp {
 
+// memory- / latency-bound kernels that gate the next accumulate launch raise their wave priority (A/B: -DZKP_NO_SORT_PRIO)
+#if defined(ZKP_NO_SORT_PRIO)
+#define ZKP_SORT_PRIO() do { } while (0)
+#else
+#define ZKP_SORT_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 const MsmVtbl* msm_vtbl_c01();
 const MsmVtbl* msm_vtbl_c02();
 const MsmVtbl* msm_vtbl_c11();
@@ -239,6 +246,7 @@ __device__ __forceinline__ DigitIter load_scalar(const uint32_t* __restrict__ sc
 constexpr int SCAN_CHUNK = 2048;
 __global__ __launch_bounds__(256) void scan_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
                                                           uint32_t* __restrict__ sums) {
+  ZKP_SORT_PRIO();
   __shared__ uint32_t red[256];
   size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
   uint32_t acc = 0;
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const uint32_t* __rest
   if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
 }
 __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ sums, size_t m) {
+  ZKP_SORT_PRIO();
   __shared__ uint32_t buf[1024];
   uint32_t carry = 0;
   for (size_t t0 = 0; t0 < m; t0 += 1024) {
@@ -277,6 +286,7 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ 
 __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t* __restrict__ in, size_t n,
                                                          const uint32_t* __restrict__ sums,
                                                          uint32_t* __restrict__ out) {
+  ZKP_SORT_PRIO();
   __shared__ uint32_t part[256];
   size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
   constexpr int PER = SCAN_CHUNK / 256;                         // 8 consecutive elements per thread
@@ -331,6 +341,7 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restri
                                                         uint32_t nb, int L, uint32_t nbins1,
                                                         uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t tile,
                                                         int var) {
+  ZKP_SORT_PRIO();
   __shared__ uint32_t cnt[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i <= nbins1; i += 256) cnt[i] = 0;
   __syncthreads();
@@ -356,6 +367,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
                                                            uint32_t nblocks, uint32_t tile,
                                                            uint64_t* __restrict__ kv, int var,
                                                            const uint8_t* __restrict__ group_flags) {   // (low key << 32) | val
+  ZKP_SORT_PRIO();
   __shared__ uint32_t cur[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i < nbins1; i += 256) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
   __syncthreads();
@@ -395,6 +407,7 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
                                                                     uint32_t* __restrict__ vout,
                                                                     uint32_t* __restrict__ start,
                                                                     uint32_t* __restrict__ end, int drop_bit) {
+  ZKP_SORT_PRIO();
   extern __shared__ uint32_t sm[];                     // [nk] counters / cursors, then [SORT_BIN_STAGE] staged values
   __shared__ uint32_t pre[SORT_BIN_THREADS];
   const uint32_t nk = 1u << L;
@@ -467,6 +480,7 @@ constexpr int TM_NLONG = 0, TM_HIST = 1, TM_CUR = 256, TM_WORDS = 512;
 
 __global__ void task_count_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nb,
                                   uint32_t* __restrict__ tcount, uint32_t cap) {
+  ZKP_SORT_PRIO();
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b > nb) return;
   tcount[b] = b < nb ? (end[b] - start[b] + cap - 1) / cap : 0;
@@ -478,6 +492,7 @@ __global__ void task_count_kernel(const uint32_t* __restrict__ start, const uint
 __global__ __launch_bounds__(256) void zero_empty_buckets_kernel(const uint32_t* __restrict__ start,
                                                                  const uint32_t* __restrict__ end, uint32_t nb,
                                                                  char* __restrict__ buckets, uint32_t xb) {
+  ZKP_SORT_PRIO();
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb || end[b] != start[b]) return;
   uint4* p = reinterpret_cast<uint4*>(buckets + (size_t)b * xb);
@@ -492,6 +507,7 @@ __global__ __launch_bounds__(256) void task_fill_kernel(const uint32_t* __restri
                                                         uint32_t* __restrict__ task_dst,
                                                         uint32_t* __restrict__ long_list,
                                                         uint32_t* __restrict__ tmeta, uint32_t cap) {
+  ZKP_SORT_PRIO();
   __shared__ uint32_t hist[MSM_TASK_CAP + 1];
   for (int i = threadIdx.x; i <= (int)MSM_TASK_CAP; i += blockDim.x) hist[i] = 0;
   __syncthreads();
@@ -515,6 +531,7 @@ __global__ __launch_bounds__(256) void task_fill_kernel(const uint32_t* __restri
 
 // cursors: longest tasks first
 __global__ void task_cursor_kernel(uint32_t* tmeta) {
+  ZKP_SORT_PRIO();
   if (threadIdx.x || blockIdx.x) return;
   uint32_t acc = 0;
   for (int l = MSM_TASK_CAP; l >= 0; l--) {
@@ -528,6 +545,7 @@ __global__ __launch_bounds__(256) void task_order_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ task_dst,
                                                          const uint32_t* __restrict__ n_tasks_dev,
                                                          uint32_t* __restrict__ tmeta, uint4* __restrict__ desc) {
+  ZKP_SORT_PRIO();
   // counting-sort scatter: LDS histogram gives each task its rank among the block's tasks of equal length;
   // one global atomic per (block, length) reserves the block's slice of that length's output range.
   __shared__ uint32_t cnt[MSM_TASK_CAP + 1];

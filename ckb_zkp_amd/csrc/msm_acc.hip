@@ -102,12 +102,13 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
 #endif
     if (p.is_inf()) continue;
     const Fu<CfgFq> ux = Fu<CfgFq>::from_sat(p.x), uy = Fu<CfgFq>::from_sat(p.y);
-    if (!xyzz_madd_u<CfgFq>(acc, ux, uy, 0u - (v >> 31))) {   // the digit's sign goes into the formulas (R = +-S2 - Y1)
-      // the operand may equal +-accumulator (doubling / cancellation): leave the whole task to
-      // the exact kernel below instead of carrying the exceptional formulas through the hot loop's register budget
-      redo[1 + atomicAdd(redo, 1u)] = id;
-      return;
-    }
+    xyzz_madd_u<CfgFq>(acc, ux, uy, 0u - (v >> 31));   // the digit's sign goes into the formulas (R = +-S2 - Y1)
+  }
+  if (xyzz_u_degenerate<CfgFq>(acc)) {
+    // some operand equalled +-accumulator (doubling / cancellation; zz == 0 from then on): the whole task goes to the exact
+    // kernel below instead of carrying the exceptional formulas — or a test per addition — through the hot loop
+    redo[1 + atomicAdd(redo, 1u)] = id;
+    return;
   }
   BkPoint<F> r;
   r.v = acc;
@@ -121,11 +122,11 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
     Affine<F> p = Affine<F>::ZKP_GATHER(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
     if (p.is_inf()) continue;
     using U = Fu<CfgFq>;
-    if (!xyzz_madd_u2<CfgFq>(acc, U::from_sat(p.x.c0), U::from_sat(p.x.c1), U::from_sat(p.y.c0), U::from_sat(p.y.c1),
-                             0u - (v >> 31))) {
-      redo[1 + atomicAdd(redo, 1u)] = id;
-      return;
-    }
+    xyzz_madd_u2<CfgFq>(acc, U::from_sat(p.x.c0), U::from_sat(p.x.c1), U::from_sat(p.y.c0), U::from_sat(p.y.c1), 0u - (v >> 31));
+  }
+  if (xyzz_u2_degenerate<CfgFq>(acc)) {
+    redo[1 + atomicAdd(redo, 1u)] = id;
+    return;
   }
   BkPoint<F> r;
   r.v = acc;
