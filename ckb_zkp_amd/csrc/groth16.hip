@@ -52,7 +52,8 @@ struct zkp_groth16_pk {
   uint64_t hA = 0, hB1 = 0, hB2 = 0, hH = 0, hL = 0;
   bool share_b_sort = false;     // b_g1_query / b_g2_query: same length, window configuration and identity pattern
   bool share_al_sort = false;    // L (stored index-aligned with z) reuses A's bucket sort: same scalars, same identity pattern
-  bool share_l1 = false;         // A, B2 (+B1) and L share ONE level-1 sort pass over z (each filters its identities at level 2)
+  bool share_l1 = false;         // A, L and (b_in_l1) B2 (+B1) share ONE level-1 sort pass over z (each filters its identities at level 2)
+  bool b_in_l1 = false;          // the B queries have A's window configuration and take part in the shared pass
   // Base-sharded key (BASELINE configs[4]): this rank holds elements [q_lo, q_lo + q_n) of every
   // (extended) query; world == 0 means the whole key.  Index order: A, B1, B2, H, L.
   int shard_rank = 0, shard_world = 0;
@@ -168,7 +169,7 @@ static void shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* cnt)
 // flags_out (optional) receives the identity flags of the uploaded slice
 static uint64_t upload_ext(zkp_ctx* ctx, int curve, int group, const uint64_t* q, const uint8_t* inf, size_t n,
                            size_t limbs_per_point, const uint64_t* const tail[4], size_t lo, size_t cnt, size_t lead = 0,
-                           std::vector<uint8_t>* flags_out = nullptr) {
+                           std::vector<uint8_t>* flags_out = nullptr, int c_hint = 0, int cap_hint = 0) {
   std::vector<uint64_t> xy(std::max<size_t>(cnt, 1) * limbs_per_point, 0);
   std::vector<uint8_t> fl(std::max<size_t>(cnt, 1), 0);
   for (size_t j = 0; j < cnt; j++) {
@@ -187,7 +188,7 @@ static uint64_t upload_ext(zkp_ctx* ctx, int curve, int group, const uint64_t* q
     }
   }
   if (flags_out) *flags_out = fl;
-  return bases_upload(ctx, curve, group, xy.data(), fl.data(), cnt);
+  return bases_upload(ctx, curve, group, xy.data(), fl.data(), cnt, c_hint, cap_hint);
 }
 
 zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, int rank, int world) {
@@ -237,8 +238,32 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
     pk->q_n[4] = pk->q_n[0];
     std::vector<uint8_t> fA, fB1, fB2, fL;
     pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA, pk->q_lo[0], pk->q_n[0], 0, &fA);
-    pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1, pk->q_lo[1], pk->q_n[1], 0, &fB1);
-    pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2, pk->q_lo[2], pk->q_n[2], 0, &fB2);
+    // Window bits of the B queries (round 3).  A G2 bucket costs two Fq2 point additions in the reduction against 6 mixed
+    // additions' worth of accumulate per entry, and half of a typical B query are identity points: with the c = round(log2 n) of
+    // the G1 queries the B2 reduction (2^19 buckets) cost 0.70 ms per 2^20 proof beside 1.30 ms of accumulate.  Sized by the LIVE
+    // bases, c = round(log2 live) - 2 (17 for the MiMC chain: 15 windows, 2^16 buckets, tasks of <= 32 entries so that the
+    // accumulate kernel still fills the machine).  B1 takes the same configuration so that it keeps reusing B2's bucket sort.
+    int cB = 0, capB = 0;
+    {
+      // Measured (2^20 MiMC chain, same box): B2 MSM 3.72 -> 3.27-3.45 ms standalone, but the B queries then leave the shared
+      // level-1 pass (one more digit scan per proof) and their accumulate kernels run 18-30 % longer instead of the 15 % more
+      // entries: 139.2 (c = 17), 139.8 (c = 18), 137.2 (c = 16) vs 139.9 proofs/s with the shared configuration.  Off by
+      // default; ZKP_B_WINDOW=1 enables it (ZKP_B_WINDOW_BITS / ZKP_B_TASK_CAP override the choice).
+      static const bool on = getenv("ZKP_B_WINDOW") && atoi(getenv("ZKP_B_WINDOW")) != 0;
+      size_t live = 0;
+      for (size_t i = 0; i < d->b_g2_len; i++) live += !(d->b_g2_inf && d->b_g2_inf[i]);
+      int lg2 = 0;
+      while (((size_t)2 << lg2) <= std::max<size_t>(live, 1)) lg2++;
+      if (lg2 < 62 && (double)live >= 1.41421356 * (double)((size_t)1 << lg2)) lg2++;
+      if (on && world == 0 && live >= ((size_t)1 << 14) && !getenv("ZKP_MSM_C") && !getenv("ZKP_MSM_C_G2")) {
+        cB = std::max(12, std::min(20, lg2 - 2));
+        if (const char* e = getenv("ZKP_B_WINDOW_BITS")) cB = atoi(e);
+        capB = 32;
+        if (const char* e = getenv("ZKP_B_TASK_CAP")) capB = atoi(e);
+      }
+    }
+    pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1, pk->q_lo[1], pk->q_n[1], 0, &fB1, cB, capB);
+    pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2, pk->q_lo[2], pk->q_n[2], 0, &fB2, cB, capB);
     {
       // B1 reuses B2's bucket sort + task schedule (same scalars, window configuration and identity pattern): -0.55 ms of
       // memory-bound sort kernels per proof.  With 4 hardware queues this LOST 2 % (84.7 -> 83.0 proofs/s: the wait on
@@ -281,20 +306,22 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
       static const bool on_l1 = !(getenv("ZKP_SHARE_L1") && atoi(getenv("ZKP_SHARE_L1")) == 0);
       const bool aligned = fA.size() == fL.size() && fA.size() == fB2.size() && pk->q_lo[0] == pk->q_lo[4] &&
                            pk->q_lo[0] == pk->q_lo[2] && pk->q_n[0] > 0;
-      if (on_l1 && aligned && !pk->share_al_sort && pk->share_b_sort && bases_same_shape(ctx, pk->hL, pk->hA) &&
-          bases_same_shape(ctx, pk->hB1, pk->hA)) {
-        // (hB2 is a G2 table: same n, window configuration checked through hB1 / share_b_sort)
+      if (on_l1 && aligned && !pk->share_al_sort && bases_same_shape(ctx, pk->hL, pk->hA)) {
+        // (hB2 is a G2 table: same n, window configuration checked through hB1 / share_b_sort).  B queries with their own
+        // window configuration (above) run their own level-1 pass: the group is then A and L only.
+        const bool with_b = pk->share_b_sort && bases_same_shape(ctx, pk->hB1, pk->hA);
         std::vector<uint8_t> all(fA.size()), member(fA.size());
         for (size_t k = 0; k < fA.size(); k++) {
-          all[k] = fA[k] & fB2[k] & fL[k];
-          member[k] = all[k] ? 0 : (uint8_t)((fA[k] ? 1 : 0) | (fB2[k] ? 2 : 0) | (fL[k] ? 4 : 0));
+          all[k] = fA[k] & fL[k] & (with_b ? fB2[k] : (uint8_t)1);
+          member[k] = all[k] ? 0 : (uint8_t)((fA[k] ? 1 : 0) | (with_b && fB2[k] ? 2 : 0) | (fL[k] ? 4 : 0));
         }
         bases_set_sort_flags(ctx, pk->hA, all.data(), all.size());
         bases_set_group(ctx, pk->hA, member.data(), member.size());
         bases_set_filter_bit(ctx, pk->hA, 0);
-        bases_set_filter_bit(ctx, pk->hB2, 1);
+        if (with_b) bases_set_filter_bit(ctx, pk->hB2, 1);
         bases_set_filter_bit(ctx, pk->hL, 2);
         pk->share_l1 = true;
+        pk->b_in_l1 = with_b;
       }
       if (getenv("ZKP_DEBUG_MSM"))
         fprintf(stderr, "[groth16] A/L sort sharing: %d (flags differ at %zu of %zu bases), B1/B2: %d, shared level 1: %d\n",
@@ -484,10 +511,11 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
       //   ws2: B2 | ws1: A -> L | ws3: B1 (B2's sort), then s*g_a + r*g1_b as soon as A exists | main: witness_map -> H
       // (A is enqueued first: with a shared level-1 pass B2's stream waits on an event that A's stream must have recorded)
       const int l1 = pk->share_l1 ? 1 : -1;
-      if (!pk->share_l1) run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2);
+      const bool b_l1 = pk->share_l1 && pk->b_in_l1;
+      if (!b_l1) run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2);
       run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 1);
       ZKP_HIP(hipEventRecord(ctx->cur->ev_a, ctx->cur->ws[1].stream));
-      if (pk->share_l1) run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2, -1, l1);
+      if (b_l1) run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2, -1, l1);
       // proof.b needs B2 only: its into_affine runs on B2's stream as soon as the MSM is done instead of in the tail of the proof
       static const bool g2_early = !(getenv("ZKP_G2_EARLY") && atoi(getenv("ZKP_G2_EARLY")) == 0);
       if (!partial_out && g2_early) {
@@ -928,9 +956,10 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
               sort_src, nullptr, l1_src);
     };
     const int l1 = pk->share_l1 ? 1 : -1;
-    if (!pk->share_l1) run(2, pk->hB2, 2, -1, -1);
+    const bool b_l1 = pk->share_l1 && pk->b_in_l1;
+    if (!b_l1) run(2, pk->hB2, 2, -1, -1);
     run(0, pk->hA, 1, -1, -1);
-    if (pk->share_l1) run(2, pk->hB2, 2, -1, l1);
+    if (b_l1) run(2, pk->hB2, 2, -1, l1);
     run(1, pk->hB1, 3, pk->share_b_sort ? 2 : -1, -1);
     run(4, pk->hL, 1, pk->share_al_sort ? 1 : -1, l1);
   }

@@ -26,7 +26,10 @@ void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const
                      uint64_t* eval_out_host);
 
 // msm.hip
-uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, const uint8_t* inf_host, size_t n);
+// c_hint > 0: window bits chosen by the caller (Groth16: the B queries are sized by their NON-identity bases); cap_hint > 0:
+// entries per accumulate task
+uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, const uint8_t* inf_host, size_t n,
+                      int c_hint = 0, int cap_hint = 0);
 void bases_free(zkp_ctx* ctx, uint64_t handle);
 uint64_t bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t handle);
 size_t bases_len(zkp_ctx* ctx, uint64_t handle);

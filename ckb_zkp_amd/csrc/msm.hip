@@ -105,7 +105,8 @@ static int pick_window_bits(size_t n, int group) {
   return std::min(20, std::max(4, lg));
 }
 
-uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n) {
+uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n, int c_hint,
+                      int cap_hint) {
   auto e = std::make_shared<BasesEntry>();
   e->curve = curve;
   e->group = group;
@@ -118,7 +119,7 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, co
   // ZKP_MSM_BALANCED=0 restores equal widths.
   {
     static const bool balanced = !(getenv("ZKP_MSM_BALANCED") && atoi(getenv("ZKP_MSM_BALANCED")) == 0);
-    const int T = e->vt->scalar_bits + 1, c0 = pick_window_bits(n, group);
+    const int T = e->vt->scalar_bits + 1, c0 = c_hint >= 2 && c_hint <= 22 ? c_hint : pick_window_bits(n, group);
     e->W = (T + c0 - 1) / c0;
     e->c = balanced ? (T + e->W - 1) / e->W : c0;
     e->wide = balanced ? T - e->W * (e->c - 1) : e->W;
@@ -126,6 +127,7 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, co
   {
     const char* env = group == 2 ? getenv("ZKP_TASK_CAP_G2") : nullptr;
     if (!env) env = getenv("ZKP_TASK_CAP");
+    if (cap_hint >= 4) e->cap = std::min<uint32_t>(MSM_TASK_CAP, (uint32_t)cap_hint);
     if (env && atoi(env) >= 4) e->cap = std::min<uint32_t>(MSM_TASK_CAP, (uint32_t)atoi(env));
   }
   ZKP_REQUIRE((double)n * e->W < 2147483000.0, ZKP_ERR_BAD_ARG);
