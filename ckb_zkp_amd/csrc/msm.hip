@@ -393,8 +393,130 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
     }
   }
 }
-// (an LDS-staged variant of the level-1 scatter — entries grouped by bin in LDS, then written in coalesced runs — lost 4 %
-//  end to end: 92 KiB of LDS left one workgroup per CU; removed)
+// ------------------------------------------------------------------------------------------- staged level-1 scatter (round 3)
+// Counter increment for a wave in which many lanes may hit the SAME counter (skewed scalars: a boolean witness sends every
+// non-zero digit of window 0 to bucket 0, equal scalars collide in every window): the lanes that share the first active lane's
+// counter are found with a ballot, ranked with mbcnt and served by ONE LDS atomic; the rest fall through to individual atomics.
+// Returns the value of the counter before this lane's increment.  Must be called by all lanes of the wave.
+__device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* cnt, uint32_t idx, bool active) {
+  const uint64_t act = __ballot(active);
+  uint32_t res = 0;
+  if (act == 0) return 0;                                            // wave-uniform
+  const int leader = __ffsll((unsigned long long)act) - 1;
+  const uint32_t lidx = (uint32_t)__builtin_amdgcn_readlane((int)idx, leader);
+  const bool same = active && idx == lidx;
+  const uint64_t m = __ballot(same);
+  const uint32_t pc = (uint32_t)__popcll(m);
+  if (pc >= 8) {                                                     // wave-uniform: a heavy hitter
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&cnt[lidx], pc);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    if (same) res = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    else if (active) res = atomicAdd(&cnt[idx], 1u);
+  } else if (active) {
+    res = atomicAdd(&cnt[idx], 1u);
+  }
+  return res;
+}
+
+// Level-1 scatter with the entries of a sub-round (`sub` scalars, <= SORT_STAGE_BYTES of entries) grouped by bin in LDS first:
+// count per bin (LDS) -> exclusive scan -> entries placed bin by bin in the LDS stage -> copied out so that consecutive lanes
+// write consecutive entries of one (bin, tile) run.  The one-entry-per-lane version above turns every 8-byte store into a
+// 32-byte fabric write (PMC: 9.0 M 32-byte + 2.3 M 64-byte write requests = 434 MB for 125 MB of entries); here a run of k
+// entries costs ceil(8k / 32) + 1 requests at most.  The bin id rides in bits 45..57 of the staged word (level 2 ignores them).
+constexpr uint32_t SORT_STAGE_BYTES = 56 * 1024;
+template <class FrP>
+__global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t* __restrict__ scalars, size_t n,
+                                                                  size_t offset, const uint8_t* __restrict__ inf,
+                                                                  int montgomery, size_t ntab, int c, int W, int wide, uint32_t nb,
+                                                                  int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
+                                                                  uint32_t nblocks, uint32_t tile, uint64_t* __restrict__ kv,
+                                                                  int var, const uint8_t* __restrict__ group_flags, uint32_t sub) {
+  ZKP_SORT_PRIO();
+  extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+  __shared__ uint32_t pre[256];
+  uint32_t* cur = sm;                                     // [nbins1] next free slot of (bin, this tile) in kv
+  uint32_t* cnt = cur + nbins1;                           // [nbins1] counts -> cursors inside the stage
+  uint64_t* stage = reinterpret_cast<uint64_t*>(cnt + ((nbins1 + 3) & ~3u));
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < nbins1; i += 256) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
+  const uint32_t lmask = (1u << L) - 1;
+  const uint32_t per = (nbins1 + 255) / 256;
+  for (uint32_t s0 = 0; s0 < tile; s0 += sub) {
+    for (uint32_t i = tid; i < nbins1; i += 256) cnt[i] = 0;
+    __syncthreads();
+    // phase A: counts per bin
+    for (uint32_t rep = 0; rep < sub / 256; rep++) {
+      const size_t i = (size_t)blockIdx.x * tile + s0 + rep * 256 + tid;
+      const bool live = s0 + rep * 256 + tid < tile && i < n && !(inf && inf[offset + i]);
+      DigitIter it = load_scalar<FrP>(scalars, live ? i : 0, montgomery);
+      for (int w = 0; w < W; w++) {
+        uint32_t key, neg;
+        it.next(w, c, wide, nb, key, neg);
+        const uint32_t fk = var ? ((uint32_t)w << (c - 1)) | key : key;
+        (void)wave_agg_inc(cnt, fk >> L, live && key < nb);
+      }
+    }
+    __syncthreads();
+    // exclusive scan of the counts, in place
+    {
+      uint32_t acc = 0;
+      for (uint32_t k = 0; k < per; k++) {
+        const uint32_t idx = tid * per + k;
+        if (idx < nbins1) acc += cnt[idx];
+      }
+      pre[tid] = acc;
+      __syncthreads();
+      for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t add = tid >= d ? pre[tid - d] : 0;
+        __syncthreads();
+        pre[tid] += add;
+        __syncthreads();
+      }
+      uint32_t run = pre[tid] - acc;
+      for (uint32_t k = 0; k < per; k++) {
+        const uint32_t idx = tid * per + k;
+        if (idx < nbins1) {
+          const uint32_t v = cnt[idx];
+          cnt[idx] = run;
+          run += v;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t total = pre[255];
+    // phase B: entries into the stage, bin by bin
+    for (uint32_t rep = 0; rep < sub / 256; rep++) {
+      const size_t i = (size_t)blockIdx.x * tile + s0 + rep * 256 + tid;
+      const bool live = s0 + rep * 256 + tid < tile && i < n && !(inf && inf[offset + i]);
+      DigitIter it = load_scalar<FrP>(scalars, live ? i : 0, montgomery);
+      const uint64_t gbits = live && group_flags ? (uint64_t)(group_flags[offset + i] & 7u) << 61 : 0;
+      for (int w = 0; w < W; w++) {
+        uint32_t key, neg;
+        it.next(w, c, wide, nb, key, neg);
+        const uint32_t fk = var ? ((uint32_t)w << (c - 1)) | key : key;
+        const bool act = live && key < nb;
+        const uint32_t pos = wave_agg_inc(cnt, fk >> L, act);
+        if (act) {
+          const uint32_t val = (uint32_t)((var ? (size_t)0 : (size_t)w * ntab) + offset + i) | (neg << 31);
+          stage[pos] = gbits | ((uint64_t)(fk >> L) << 45) | ((uint64_t)(fk & lmask) << 32) | val;
+        }
+      }
+    }
+    __syncthreads();
+    // copy out: cnt[b] is now the END of bin b inside the stage, i.e. the start of bin b + 1
+    for (uint32_t j = tid; j < total; j += 256) {
+      const uint64_t e = stage[j];
+      const uint32_t b = (uint32_t)(e >> 45) & 0x1fffu;
+      const uint32_t lo = b ? cnt[b - 1] : 0;
+      kv[cur[b] + (j - lo)] = e;
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < nbins1; b += 256) cur[b] += cnt[b] - (b ? cnt[b - 1] : 0);
+    __syncthreads();
+  }
+}
 // (round 2: level 1 as ONE kernel per tile — LDS histogram, LDS scan, entries scattered into the tile's own contiguous region
 //  of kv so that the 8-byte stores merge in L2, level 2 gathering one run per tile — was built, bit-exact, and measured:
 //  the level-1 kernel alone took 0.26 ms, as much as histogram + count scan + scatter together before (the passes are bound
@@ -707,6 +829,16 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       ZKP_HIP(hipMemsetAsync(hist + hist_n - 1, 0, 4, st));
     }
     const uint8_t* grp = scan_inf == be->sort_inf ? be->group_flags : nullptr;   // group bits only with the group's scan flags
+    // staged level-1 scatter (sort_scatter_staged_kernel): sub-rounds of `staged_sub` scalars whose entries fit the LDS stage;
+    // not for > 2048 level-1 bins (the two counter arrays would leave one workgroup per CU) or very narrow windows
+    static const bool staged_on = !(getenv("ZKP_SORT_STAGED") && atoi(getenv("ZKP_SORT_STAGED")) == 0);
+    uint32_t staged_sub = 0;
+    size_t staged_lds = 0;
+    if (staged_on && nbins1 <= 2048 && (size_t)256 * W * 8 <= SORT_STAGE_BYTES) {
+      staged_sub = (uint32_t)(SORT_STAGE_BYTES / ((size_t)W * 8)) / 256 * 256;
+      staged_sub = std::min<uint32_t>(staged_sub, tile);
+      staged_lds = ((size_t)nbins1 + ((nbins1 + 3) & ~3u)) * 4 + (size_t)staged_sub * W * 8;
+    }
     const bool timed_scan = ms_scan && ctx->profiling && !reuse && !l1_reuse;      // K5 "scalar scan": histogram pass + count scan + scatter pass
     if (timed_scan) ZKP_HIP(hipEventRecord(ctx->ev2, st));
     if (reuse || l1_reuse) {
@@ -714,14 +846,22 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
                          wide, nb_w, LB, nbins1, hist, nblocks, tile, var);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-      hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
-                         be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp);
+      if (staged_sub)
+        hipLaunchKernelGGL(sort_scatter_staged_kernel<Bn254Fr>, dim3(nblocks), dim3(256), staged_lds, st, sc, n, offset, scan_inf,
+                           mont, be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp, staged_sub);
+      else
+        hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
+                           be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp);
     } else {
       hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
                          wide, nb_w, LB, nbins1, hist, nblocks, tile, var);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-      hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
-                         be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp);
+      if (staged_sub)
+        hipLaunchKernelGGL(sort_scatter_staged_kernel<Bls381Fr>, dim3(nblocks), dim3(256), staged_lds, st, sc, n, offset, scan_inf,
+                           mont, be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp, staged_sub);
+      else
+        hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
+                           be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp);
     }
     if (timed_scan) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
