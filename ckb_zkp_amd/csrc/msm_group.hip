@@ -357,6 +357,91 @@ namespace ZKP_CFG_SYM(cfg) {
 // ONLY the doubling chain (Jacobian dbl-2009-l, a = 0: 2M + 5S = 7 products per step instead of the 9 of the XYZZ doubling
 // plus ~5 of the conditional mixed addition) and publishes D_k = 2^k P to LDS; afterwards the 64 lanes of the wave sum the
 // D_k whose scalar bit is set (4 candidates per lane, then an LDS tree).  3.3 -> ~2 ms of single-lane latency.
+// GLV (round 3): both curves have j = 0, so phi(x, y) = (beta x, y) is an endomorphism with phi(P) = lambda P.  k = k1 + k2 lambda
+// (mod r) with |k1|, |k2| < 2^129 (glv_constants.inc, generated and checked by tools/gen_glv.py): k P = k1 P + k2 phi(P) needs a
+// doubling chain of 130 instead of 255 steps — the chain is the latency of this kernel (1.75 -> ~0.95 ms).
+#include "glv_constants.inc"
+// c = (k * g) >> 256, k: 8 words, g: 5 words
+__device__ __forceinline__ void glv_mulhi(const uint32_t* k, const uint32_t* g, uint32_t* c) {
+  uint32_t t[13];
+#pragma unroll
+  for (int i = 0; i < 13; i++) t[i] = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint64_t x = (uint64_t)k[i] * g[j] + t[i + j] + carry;
+      t[i + j] = (uint32_t)x;
+      carry = x >> 32;
+    }
+    t[8 + j] = (uint32_t)carry;
+  }
+#pragma unroll
+  for (int i = 0; i < 5; i++) c[i] = t[8 + i];
+}
+// acc (10 words, two's complement) += sign * x * y  (x, y: 5-word magnitudes; neg != 0 subtracts)
+__device__ __forceinline__ void glv_mac(uint32_t* acc, const uint32_t* x, const uint32_t* y, int neg) {
+  uint32_t t[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      uint64_t v = (uint64_t)x[i] * y[j] + t[i + j] + carry;
+      t[i + j] = (uint32_t)v;
+      carry = v >> 32;
+    }
+    t[5 + j] = (uint32_t)carry;
+  }
+  uint64_t c = neg ? 1 : 0;                                 // subtract = add the two's complement
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    c += (uint64_t)acc[i] + (neg ? ~t[i] : t[i]);
+    acc[i] = (uint32_t)c;
+    c >>= 32;
+  }
+}
+// 10-word two's complement -> 5-word magnitude + sign
+__device__ __forceinline__ int glv_abs(uint32_t* acc, uint32_t* out) {
+  const int neg = (int)(acc[9] >> 31);
+  uint64_t c = neg ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    c += neg ? (uint32_t)~acc[i] : acc[i];
+    acc[i] = (uint32_t)c;
+    c >>= 32;
+  }
+#pragma unroll
+  for (int i = 0; i < 5; i++) out[i] = acc[i];
+  return neg;
+}
+// k (canonical scalar, 8 words) -> |k1|, |k2| < 2^BITS and their signs: k = k1 + k2 lambda (mod r).  The identity holds for ANY
+// integers c1, c2 (a_i + b_i lambda = 0 mod r), so the truncated quotients only cost a bit of size (gen_glv.py checks the bound).
+template <class G>
+__device__ __forceinline__ void glv_decompose(const uint32_t* k, uint32_t* k1, int* neg1, uint32_t* k2, int* neg2) {
+  uint32_t g1[5], g2[5], a1[5], b1[5], a2[5], b2[5], c1[5], c2[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    g1[i] = G::G1[i]; g2[i] = G::G2[i]; a1[i] = G::A1[i]; b1[i] = G::B1[i]; a2[i] = G::A2[i]; b2[i] = G::B2[i];
+  }
+  glv_mulhi(k, g1, c1);                                     // |c1|, sign G1_NEG
+  glv_mulhi(k, g2, c2);
+  uint32_t acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) acc[i] = i < 8 ? k[i] : 0;
+  glv_mac(acc, c1, a1, !(G::G1_NEG ^ G::A1_NEG));           // k1 = k - c1 a1 - c2 a2
+  glv_mac(acc, c2, a2, !(G::G2_NEG ^ G::A2_NEG));
+  *neg1 = glv_abs(acc, k1);
+#pragma unroll
+  for (int i = 0; i < 10; i++) acc[i] = 0;
+  glv_mac(acc, c1, b1, !(G::G1_NEG ^ G::B1_NEG));           // k2 = -c1 b1 - c2 b2
+  glv_mac(acc, c2, b2, !(G::G2_NEG ^ G::B2_NEG));
+  *neg2 = glv_abs(acc, k2);
+}
+
 template <class F>
 __device__ __forceinline__ void jac_dbl(F& X, F& Y, F& Z) {
   F A = X.sqr(), B = Y.sqr();
@@ -374,15 +459,19 @@ __global__ __launch_bounds__(128) void assemble_g1_part1_kernel(char* __restrict
                                                                 uint32_t* __restrict__ out,
                                                                 uint32_t* __restrict__ flags) {
   using F = CfgF;
+  using G = GlvConst<CfgFq>;
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NB = CFG_BITS + 1;                             // bits 0 .. CFG_BITS of a canonical scalar
+  constexpr int NB = G::BITS;                                  // doubling-chain length: bits of |k1|, |k2|
   constexpr size_t JB = 3 * 4 * F::N;                          // bytes of a Jacobian point
   const int t = threadIdx.x, chain = t >> 6, lane = t & 63;
   char* D = smem + (size_t)chain * NB * JB;                    // D[k] = 2^k * P (Jacobian)
   char* red = smem + 2 * NB * JB + (size_t)chain * 64 * XYZZ<F>::BYTES;
   // chain 0: g_a (slot 0) times s ; chain 1: g1_b (slot 1) times r
   Fp<CfgFr> k = Fp<CfgFr>::load(rs + (chain == 0 ? 8 : 0)).from_mont();
+  uint32_t k1[5], k2[5];
+  int neg1, neg2;
+  glv_decompose<G>(k.v, k1, &neg1, k2, &neg2);                 // k P = k1 P + k2 phi(P)
   if (lane == 0) {
     XYZZ<F> p = XYZZ<F>::load(res + (size_t)chain * slot);
     Affine<F> a = p.to_affine();
@@ -399,9 +488,20 @@ __global__ __launch_bounds__(128) void assemble_g1_part1_kernel(char* __restrict
     }
   }
   __syncthreads();
+  F beta;
+#pragma unroll
+  for (int i = 0; i < F::N; i++) beta.v[i] = G::BETA_MONT[i];
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (int b = lane; b < NB; b += 64)
-    if ((k.v[b >> 5] >> (b & 31)) & 1) acc.add(jac_to_xyzz<F>(reinterpret_cast<const uint32_t*>(D + (size_t)b * JB)));
+  for (int b = lane; b < NB; b += 64) {
+    const bool t1 = (k1[b >> 5] >> (b & 31)) & 1, t2 = (k2[b >> 5] >> (b & 31)) & 1;
+    if (!(t1 || t2)) continue;
+    const F X = F::load(D + (size_t)b * JB), Y = F::load(D + (size_t)b * JB + 4 * F::N), Z = F::load(D + (size_t)b * JB + 8 * F::N);
+    if (Z.is_zero()) continue;
+    const F zz = Z.sqr();
+    const F zzz = zz * Z;
+    if (t1) acc.add(XYZZ<F>{X, neg1 ? Y.neg() : Y, zz, zzz});
+    if (t2) acc.add(XYZZ<F>{beta * X, neg2 ? Y.neg() : Y, zz, zzz});      // phi(X : Y : Z) = (beta X : Y : Z)
+  }
   acc.store(red + (size_t)lane * XYZZ<F>::BYTES);
   __syncthreads();
   for (int s2 = 32; s2 > 0; s2 >>= 1) {
@@ -504,7 +604,7 @@ void l_fixed_base(hipStream_t s, const uint32_t* base, const uint32_t* scalars, 
 }
 #if ZKP_CFG_GROUP == 1
 void l_assemble_g1_p1(hipStream_t s, char* res, size_t slot, const uint32_t* rs, uint32_t* out, uint32_t* flags) {
-  const size_t lds = 2 * (size_t)(CFG_BITS + 1) * 3 * 4 * F::N + 2 * 64 * XB;
+  const size_t lds = 2 * (size_t)GlvConst<CfgFq>::BITS * 3 * 4 * F::N + 2 * 64 * XB;
   hipLaunchKernelGGL(assemble_g1_part1_kernel, dim3(1), dim3(128), lds, s, res, slot, rs, out, flags);
 }
 void l_assemble_g1_p2(hipStream_t s, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int c_off_words) {
