@@ -45,6 +45,12 @@ class Groth16Timing(C.Structure):
                 ("ms_msm_acc", C.c_float * 5), ("msm_entries", C.c_uint64 * 5)]
 
 
+class MarlinTiming(C.Structure):
+    _fields_ = [("ms_round", C.c_double * 3), ("ms_commit", C.c_double * 3), ("ms_evaluations", C.c_double),
+                ("ms_open", C.c_double), ("ms_total", C.c_double), ("commit_points", C.c_uint64),
+                ("open_points", C.c_uint64), ("ntt_count", C.c_uint64), ("ntt_elements", C.c_uint64)]
+
+
 class MarlinIndexDesc(C.Structure):
     _fields_ = [("curve", C.c_int), ("num_inputs", C.c_uint32), ("n", C.c_uint32), ("pad_aux", C.c_uint32),
                 ("a", Csr), ("b", Csr), ("c", Csr)]
@@ -137,6 +143,7 @@ SIGNATURES = {
     "zkp_groth16_prove_batch": (C.c_int32, [vp, vp, C.c_size_t, vp, vp, vp, vp, vp]),
     "zkp_groth16_assemble": (C.c_int32, [vp, C.c_int, vp, vp, vp, vp, vp]),
     "zkp_groth16_last_timing": (C.c_int32, [vp, C.POINTER(Groth16Timing)]),
+    "zkp_marlin_last_timing": (C.c_int32, [vp, C.POINTER(MarlinTiming)]),
     "zkp_set_profiling": (C.c_int32, [vp, C.c_int32]),
     "zkp_marlin_index_upload": (C.c_int32, [vp, C.POINTER(MarlinIndexDesc), C.POINTER(vp)]),
     "zkp_marlin_index_free": (C.c_int32, [vp, vp]),

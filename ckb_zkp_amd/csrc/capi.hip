@@ -545,6 +545,11 @@ int32_t zkp_bench_mulmod(zkp_ctx* ctx, zkp_curve_t curve, int32_t field, int32_t
   if (!out || (curve != ZKP_BN254 && curve != ZKP_BLS12_381) || field < 0 || field > 1) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { *out = bench_mulmod(ctx, curve, field, unsaturated != 0); });
 }
+int32_t zkp_marlin_last_timing(zkp_ctx* ctx, zkp_marlin_timing* out) {
+  if (!ctx || !out) return ZKP_ERR_BAD_ARG;
+  *out = ctx->last_marlin_timing;
+  return ZKP_OK;
+}
 int32_t zkp_groth16_last_timing(zkp_ctx* ctx, zkp_groth16_timing* out) {
   if (!ctx || !out) return ZKP_ERR_BAD_ARG;
   *out = ctx->last_timing;

@@ -140,6 +140,7 @@ struct zkp_ctx {
   std::unordered_map<uint64_t, std::shared_ptr<zkp::BasesEntry>> bases;
   uint64_t next_handle = 1;
   zkp_groth16_timing last_timing{};
+  zkp_marlin_timing last_marlin_timing{};
   std::string last_error;
   // Single-process multi-GPU (zkp_ctx_create_multi): the ROOT context lists one context per requested device in rank order
   // (devs[0] == this; device ids may repeat: several ranks on one GPU).  Empty on an ordinary context and on the members.

@@ -13,6 +13,7 @@
 // sort of AHP::index (pure index manipulation, ahp/constraint_systems.rs:9-31,100-133), and the zk RNG: the mask
 // coefficients and commitment blinders are inputs (`zkp_marlin_rand`).
 #include <algorithm>
+#include <chrono>
 #include <array>
 #include <cstring>
 #include <map>
@@ -310,8 +311,17 @@ struct Backend {
     ntt_run(ctx, curve, reinterpret_cast<uint32_t*>(out.p), log2_of(size), o);
     return out;
   }
-  DVec fft(DVec v, size_t size) { return ntt(v, size, ZKP_NTT_FFT); }
-  DVec ifft(DVec v, size_t size) { return ntt(v, size, ZKP_NTT_IFFT); }
+  uint64_t ntt_count = 0, ntt_elements = 0;            // bookkeeping for zkp_marlin_last_timing
+  DVec fft(DVec v, size_t size) {
+    ntt_count++;
+    ntt_elements += size;
+    return ntt(v, size, ZKP_NTT_FFT);
+  }
+  DVec ifft(DVec v, size_t size) {
+    ntt_count++;
+    ntt_elements += size;
+    return ntt(v, size, ZKP_NTT_IFFT);
+  }
   DVec pmul(DVec a, DVec b) {
     size_t size = next_pow2(a.n + b.n - 1);
     return ifft(mul(fft(a, size), fft(b, size)), size).view(0, a.n + b.n - 1);
@@ -607,6 +617,15 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     ~Release() { p->release_all(); }
   } release{&ix->pool};
 
+  zkp_marlin_timing tm{};
+  auto clk = [] { return std::chrono::steady_clock::now(); };
+  auto t_begin = clk(), t_mark = t_begin;
+  auto lap = [&](double* dst) {                          // phase boundary: the stream is drained, the host clock read
+    ZKP_HIP(hipStreamSynchronize(st));
+    auto now = clk();
+    *dst += std::chrono::duration<double, std::milli>(now - t_mark).count();
+    t_mark = now;
+  };
   Challenger chal;
   chal.curve = curve;
   chal.Fr = F;
@@ -699,6 +718,7 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
         slot.push_back({l, true});
       }
     }
+    for (size_t nn : ns) tm.commit_points += nn;
     std::vector<uint64_t> jac(slot.size() * jw64);
     msm_run_batch(ctx, powers_g, slot.size(), offs.data(), ptrs.data(), ns.data(), true, jac.data());
     std::vector<size_t> boffs, bns;
@@ -738,7 +758,9 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     chal.absorb(bytes);
   };
 
+  lap(&tm.ms_round[0]);
   commit_round({W_, ZA_, ZB_, MASK_});                                     // lib.rs:109-112
+  lap(&tm.ms_commit[0]);
   const FrE alpha = chal.rng ? chal.outside() : chal.fixed_at(0);          // ahp/verifier.rs:53-56
   const FrE ea = chal.rng ? chal.rand_fr() : chal.fixed_at(1);
   const FrE eb = chal.rng ? chal.rand_fr() : chal.fixed_at(2);
@@ -764,7 +786,9 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     poly[G1_] = hx.second.view(1, hs);
     poly[H1_] = hx.first.view(0, 2 * hs);
   }
+  lap(&tm.ms_round[1]);
   commit_round({T_, G1_, H1_});                                            // lib.rs:117-120
+  lap(&tm.ms_commit[1]);
   const FrE beta = chal.rng ? chal.outside() : chal.fixed_at(4);           // ahp/verifier.rs:76
   // ---- third round (prover.rs:331-427)
   const FrE v_beta = F.sub(F.pow2k(beta, log2_of(hs)), one);
@@ -789,7 +813,9 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     poly[G2_] = t3.view(1, ks);
     poly[H2_] = h2.view(0, 3 * ks - 3);
   }
+  lap(&tm.ms_round[2]);
   commit_round({G2_, H2_});                                                // lib.rs:124-127
+  lap(&tm.ms_commit[2]);
   const FrE gamma = chal.rng ? chal.rand_fr() : chal.fixed_at(5);          // ahp/verifier.rs:86
   // ---- evaluations in query-set order: BTreeSet<(label, point)>, i.e. by label (lib.rs:147-156)
   struct Q {
@@ -816,6 +842,7 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     ev_bytes.insert(ev_bytes.end(), b, b + 32);
   }
   chal.absorb(ev_bytes);                                                   // lib.rs:157
+  lap(&tm.ms_evaluations);
   FrE xi;
   uint64_t xi128[2] = {0, 0};
   if (chal.rng) {
@@ -861,6 +888,7 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     std::vector<const uint64_t*> ptrs;
     for (int k = 0; k < npts; k++) ptrs.push_back(wq[k].p);
     std::vector<uint64_t> wjac(npts * jw64);
+    tm.open_points += (uint64_t)npts * D;
     msm_run_batch(ctx, powers_g, npts, offs.data(), ptrs.data(), ns.data(), true, wjac.data());
     out->num_opening_proofs = (uint32_t)npts;
     for (int k = 0; k < npts; k++) {
@@ -900,7 +928,11 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   const FrE* chs[6] = {&alpha, &ea, &eb, &ec, &beta, &gamma};
   for (int i = 0; i < 6; i++) memcpy(out->challenges + 4 * i, chs[i]->data(), 32);
   memcpy(out->challenges + 24, xi.data(), 32);
-  ZKP_HIP(hipStreamSynchronize(st));
+  lap(&tm.ms_open);
+  tm.ms_total = std::chrono::duration<double, std::milli>(clk() - t_begin).count();
+  tm.ntt_count = be.ntt_count;
+  tm.ntt_elements = be.ntt_elements;
+  ctx->last_marlin_timing = tm;
 }
 
 }  // namespace zkp

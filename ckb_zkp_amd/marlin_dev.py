@@ -775,4 +775,10 @@ def prove_native(ctx: Context, nidx: NativeIndex, ck: kzg10.CommitterKey, ivk: d
     rv = codec.fr_from_mont(np.array(out.opening_rand_v, dtype=np.uint64).reshape(2, 4), c)
     proofs = [(g1(ow[k], out.opening_w_inf[k]), rv[k] if out.opening_has_rand[k] else None)
               for k in range(out.num_opening_proofs)]
-    return dict(commitments=comms, evaluations=evals, opening_proofs=proofs, query=query, challenges=chd)
+    tm = _lib.MarlinTiming()
+    _lib.check(ctx.lib.zkp_marlin_last_timing(ctx.h, C.byref(tm)), "zkp_marlin_last_timing")
+    timing = dict(ms_round=[float(x) for x in tm.ms_round], ms_commit=[float(x) for x in tm.ms_commit],
+                  ms_evaluations=float(tm.ms_evaluations), ms_open=float(tm.ms_open), ms_total=float(tm.ms_total),
+                  commit_points=int(tm.commit_points), open_points=int(tm.open_points), ntt_count=int(tm.ntt_count),
+                  ntt_elements=int(tm.ntt_elements))
+    return dict(commitments=comms, evaluations=evals, opening_proofs=proofs, query=query, challenges=chd, timing=timing)

@@ -392,6 +392,22 @@ typedef struct {
   uint64_t msm_entries[5]; /* entries (= mixed additions: identity bases and zero digits are dropped by the scan) per MSM */
 } zkp_groth16_timing;
 int32_t zkp_groth16_last_timing(zkp_ctx* ctx, zkp_groth16_timing* out);
+/* Phases of the last zkp_marlin_prove on this context (host clock around stream synchronisations that the prover performs
+ * anyway between a round and its PC::commit, marlin/src/lib.rs:105-181): rounds = AHP prover rounds (sparse products, NTTs,
+ * pointwise work), commits = the batched commitment MSMs of the round + the transcript, evaluations = 21 Horner evaluations,
+ * open = batch_open (linear combinations, two witness divisions, two opening MSMs). */
+typedef struct {
+  double ms_round[3];
+  double ms_commit[3];
+  double ms_evaluations;
+  double ms_open;
+  double ms_total;
+  uint64_t commit_points;  /* sum of the lengths of the committed coefficient vectors (incl. shifted commitments) */
+  uint64_t open_points;    /* lengths of the opening-witness MSMs */
+  uint64_t ntt_count;      /* transforms run by the three rounds */
+  uint64_t ntt_elements;   /* sum of their sizes */
+} zkp_marlin_timing;
+int32_t zkp_marlin_last_timing(zkp_ctx* ctx, zkp_marlin_timing* out);
 int32_t zkp_set_profiling(zkp_ctx* ctx, int32_t enable); /* per-phase HIP events (adds sync points) */
 /* Sustained rate (1e9 products / s) of the library's own Montgomery multipliers with every CU saturated: the integer-VALU
  * roof the MSM / NTT kernels are bound by, measured in the calling process (bench.py `valu_roof`).

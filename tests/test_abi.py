@@ -52,6 +52,16 @@ def test_desc_struct_layout_matches_header():
     assert nums[0] == ctypes.sizeof(_lib.Groth16Timing)
     assert nums[1:1 + len(fields)] == [getattr(_lib.Groth16Timing, f).offset for f in fields]
     assert nums[-2:] == [ctypes.sizeof(_lib.Groth16PkDesc), ctypes.sizeof(_lib.Csr)]
+    # zkp_marlin_timing likewise
+    mf = [f[0] for f in _lib.MarlinTiming._fields_]
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"zkp_accel.h\"\nint main(void){printf(\"%zu\", sizeof(zkp_marlin_timing));" + \
+        "".join(f'printf(" %zu", offsetof(zkp_marlin_timing, {f}));' for f in mf) + "return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "t.c").write_text(prog)
+        subprocess.run(["gcc", "-std=c99", f"-I{ROOT / 'include'}", str(Path(d) / "t.c"), "-o", str(Path(d) / "t")], check=True)
+        nums = [int(x) for x in subprocess.run([str(Path(d) / "t")], capture_output=True, text=True, check=True).stdout.split()]
+    assert nums[0] == ctypes.sizeof(_lib.MarlinTiming)
+    assert nums[1:] == [getattr(_lib.MarlinTiming, f).offset for f in mf]
 
 
 def test_product_does_not_import_oracle():

@@ -16,7 +16,7 @@ SCALAR = {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usi
           "double": "f64", "uint8_t": "u8", "void": "c_void", "char": "c_char", "zkp_curve_t": "c_int"}
 OPAQUE = ["zkp_ctx", "zkp_groth16_pk", "zkp_groth16_pk_multi", "zkp_fs_rng", "zkp_marlin_index"]
 STRUCTS = ["zkp_csr", "zkp_groth16_pk_desc", "zkp_marlin_index_desc", "zkp_marlin_rand", "zkp_marlin_proof",
-           "zkp_groth16_timing"]
+           "zkp_groth16_timing", "zkp_marlin_timing"]
 
 
 def strip_comments(t):
