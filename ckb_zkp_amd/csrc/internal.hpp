@@ -63,6 +63,9 @@ void msm_var_run(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, co
 void msm_free_all(zkp_ctx* ctx);
 void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz_host);
 void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, uint64_t* xy_out, uint8_t* inf_out);
+// k Jacobian points a_i (+ b_i where has_b[i]) -> affine, one launch; host in / host out (slot strides: 3 fN / 2 fN words)
+void points_fold_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* a_xyz_host, const uint64_t* b_xyz_host,
+                             const uint8_t* has_b, size_t k, uint64_t* xy_out, uint8_t* inf_out);
 void fixed_base_mul(zkp_ctx* ctx, int curve, int group, const uint64_t* base_xy, const uint64_t* scalars_host, size_t n,
                     uint64_t* out_xy, uint8_t* out_inf);
 

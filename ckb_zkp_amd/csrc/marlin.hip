@@ -734,18 +734,22 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     std::vector<uint64_t> bjac(std::max<size_t>(bptrs.size(), 1) * jw64);
     if (!bptrs.empty())
       msm_run_batch(ctx, powers_gamma_g, bptrs.size(), boffs.data(), bptrs.data(), bns.data(), true, bjac.data());
-    for (size_t k = 0; k < slot.size(); k++) {
-      std::vector<uint64_t> pt(jac.begin() + k * jw64, jac.begin() + (k + 1) * jw64);
-      if (bslot[k] != (size_t)-1) {
-        std::vector<uint64_t> two(2 * jw64);
-        memcpy(two.data(), pt.data(), jw64 * 8);
-        memcpy(two.data() + jw64, bjac.data() + bslot[k] * jw64, jw64 * 8);
-        point_fold(ctx, curve, 1, two.data(), 2, pt.data());
+    {
+      // commitment k = affine(MSM_k + blinding MSM_k): all of the round in ONE launch (a single-lane inversion each, side by side)
+      std::vector<uint64_t> bj(slot.size() * jw64, 0), axy(slot.size() * aw64);
+      std::vector<uint8_t> has(slot.size(), 0), ainf(slot.size(), 0);
+      for (size_t k = 0; k < slot.size(); k++)
+        if (bslot[k] != (size_t)-1) {
+          has[k] = 1;
+          memcpy(bj.data() + k * jw64, bjac.data() + bslot[k] * jw64, jw64 * 8);
+        }
+      points_fold_into_affine(ctx, curve, 1, jac.data(), bj.data(), has.data(), slot.size(), axy.data(), ainf.data());
+      for (size_t k = 0; k < slot.size(); k++) {
+        Commitment& c = comm[slot[k].first];
+        std::vector<uint64_t>& dst = slot[k].second ? c.sxy : c.xy;
+        dst.assign(axy.begin() + k * aw64, axy.begin() + (k + 1) * aw64);
+        (slot[k].second ? c.sinf : c.inf) = ainf[k];
       }
-      Commitment& c = comm[slot[k].first];
-      std::vector<uint64_t>& dst = slot[k].second ? c.sxy : c.xy;
-      dst.assign(aw64, 0);
-      point_into_affine(ctx, curve, 1, pt.data(), dst.data(), slot[k].second ? &c.sinf : &c.inf);
     }
     // to_bytes![round commitments]: comm, shifted_exists byte, shifted or the empty commitment (pc/data_structures.rs:143-154)
     std::vector<uint8_t> bytes;

@@ -1148,6 +1148,32 @@ void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz, 
   *inf_out = (uint8_t)flag;
 }
 
+void points_fold_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* a, const uint64_t* b, const uint8_t* has_b,
+                             size_t k, uint64_t* xy_out, uint8_t* inf_out) {
+  if (k == 0) return;
+  const MsmVtbl* vt = msm_vtbl(curve, group);
+  const size_t jw = 3 * (size_t)vt->fN, aw = 2 * (size_t)vt->fN;
+  uint32_t* d = ctx->msm_misc.as<uint32_t>(k * (2 * jw + aw + 2) + 16);
+  uint32_t* da = d;
+  uint32_t* db = da + k * jw;
+  uint32_t* dh = db + k * jw;
+  uint32_t* dxy = dh + k;
+  uint32_t* dinf = dxy + k * aw;
+  hipStream_t st = ctx->cur->stream;
+  std::vector<uint32_t> hb(k);
+  for (size_t i = 0; i < k; i++) hb[i] = has_b && has_b[i] ? 1u : 0u;
+  ZKP_HIP(hipMemcpyAsync(da, a, k * jw * 4, hipMemcpyHostToDevice, st));
+  if (b) ZKP_HIP(hipMemcpyAsync(db, b, k * jw * 4, hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipMemcpyAsync(dh, hb.data(), k * 4, hipMemcpyHostToDevice, st));
+  vt->fold_affine_batch(st, da, db, dh, (int)k, dxy, dinf);
+  ZKP_HIP(hipGetLastError());
+  std::vector<uint32_t> hinf(k);
+  ZKP_HIP(hipMemcpyAsync(xy_out, dxy, k * aw * 4, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(hinf.data(), dinf, k * 4, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipStreamSynchronize(st));
+  for (size_t i = 0; i < k; i++) inf_out[i] = (uint8_t)hinf[i];
+}
+
 void fixed_base_mul(zkp_ctx* ctx, int curve, int group, const uint64_t* base_xy, const uint64_t* scalars, size_t n,
                     uint64_t* out_xy, uint8_t* out_inf) {
   if (n == 0) return;

@@ -322,6 +322,19 @@ __global__ void into_affine_kernel(const uint32_t* jac, uint32_t* xy, uint32_t* 
 }
 
 template <class F>
+__global__ void fold_affine_batch_kernel(const uint32_t* __restrict__ ja, const uint32_t* __restrict__ jb,
+                                         const uint32_t* __restrict__ has_b, int k, uint32_t* __restrict__ xy,
+                                         uint32_t* __restrict__ inf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  XYZZ<F> p = jac_to_xyzz<F>(ja + (size_t)i * 3 * F::N);
+  if (has_b[i]) p.add(jac_to_xyzz<F>(jb + (size_t)i * 3 * F::N));
+  Affine<F> a = p.to_affine();
+  a.store(xy + (size_t)i * 2 * F::N);
+  inf[i] = p.is_inf() ? 1 : 0;
+}
+
+template <class F>
 __global__ void from_jacobian_kernel(const uint32_t* jac, char* out) {
   if (threadIdx.x || blockIdx.x) return;
   jac_to_xyzz<F>(jac).store(out);
@@ -594,6 +607,10 @@ void l_fold_slots(hipStream_t s, const char* gathered, size_t rank_stride, int w
 void l_into_affine(hipStream_t s, const uint32_t* jac, uint32_t* xy, uint32_t* inf) {
   hipLaunchKernelGGL(into_affine_kernel<F>, dim3(1), dim3(64), 0, s, jac, xy, inf);
 }
+void l_fold_affine_batch(hipStream_t s, const uint32_t* ja, const uint32_t* jb, const uint32_t* has_b, int k, uint32_t* xy,
+                         uint32_t* inf) {
+  if (k > 0) hipLaunchKernelGGL(fold_affine_batch_kernel<F>, dim3((k + 63) / 64), dim3(64), 0, s, ja, jb, has_b, k, xy, inf);
+}
 void l_from_jacobian(hipStream_t s, const uint32_t* jac, char* out) {
   hipLaunchKernelGGL(from_jacobian_kernel<F>, dim3(1), dim3(64), 0, s, jac, out);
 }
@@ -621,7 +638,7 @@ const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
   static const MsmVtbl v = {
       F::N, Affine<F>::BYTES, XYZZ<F>::BYTES, BkPoint<F>::BYTES, CFG_BITS,
       l_ingest, l_precompute, ZKP_CFG_SYM(msm_accumulate_launch), l_combine, l_pair, l_segsum, l_final, l_identity, l_fold,
-      l_into_affine, l_from_jacobian, l_fixed_base, l_segsum_desc, l_final_var, l_fold_slots,
+      l_into_affine, l_fold_affine_batch, l_from_jacobian, l_fixed_base, l_segsum_desc, l_final_var, l_fold_slots,
 #if ZKP_CFG_GROUP == 1
       l_assemble_g1_p1, l_assemble_g1_p2, nullptr,
 #else

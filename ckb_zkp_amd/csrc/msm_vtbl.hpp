@@ -52,6 +52,10 @@ struct MsmVtbl {
   void (*write_identity)(hipStream_t, char* out_xyzz, uint32_t* out_jac);
   void (*fold)(hipStream_t, const uint32_t* pts, int k, uint32_t* out_jac);
   void (*into_affine)(hipStream_t, const uint32_t* jac, uint32_t* xy, uint32_t* inf);
+  // k points at once, one lane each: out_i = affine(a_i + b_i) (b_i Jacobian too; has_b[i] == 0: a_i alone) — the k
+  // commitments of a Marlin round share ONE launch instead of k single-lane inversions (0.3 ms each) one after the other
+  void (*fold_affine_batch)(hipStream_t, const uint32_t* jac_a, const uint32_t* jac_b, const uint32_t* has_b, int k,
+                            uint32_t* xy, uint32_t* inf);
   void (*from_jacobian)(hipStream_t, const uint32_t* jac, char* out_xyzz);
   void (*fixed_base)(hipStream_t, const uint32_t* base, const uint32_t* scalars, size_t n, char* out_xy,
                      uint8_t* out_inf);
