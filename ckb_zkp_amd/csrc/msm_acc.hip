@@ -203,8 +203,14 @@ void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const 
     }
   } redo_after{s, table, vals, desc, buckets, partial, redo};
 #if ZKP_CFG_GROUP == 1 && defined(ZKP_ACC_UNSAT)
-  hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
-                     n_tasks_dev, buckets, partial, dbg_mask(), redo);
+  // BLS12-381 G1: 169 VGPRs = one register over three waves per SIMD; ZKP_G1_ACC_WAVES=3 compiles for three (A/B switch)
+  static const int g1w = [] { const char* e = getenv("ZKP_G1_ACC_WAVES"); return e ? atoi(e) : 0; }();
+  if (g1w == 3)
+    hipLaunchKernelGGL(accumulate_kernel<3>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
+  else
+    hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
   return;
 #endif
   if (ZKP_CFG_GROUP == 1 && occ1 == 4)
