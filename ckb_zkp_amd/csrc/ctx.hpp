@@ -129,6 +129,7 @@ struct zkp_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // zkp_timer_*
   hipEvent_t ev2 = nullptr, ev3 = nullptr;   // internal per-kernel timing
   bool profiling = false;
+  size_t table_bytes = 0;      // resident window tables of this context (ZKP_TABLE_BUDGET_GB accounting)
   bool dbg_skip_k8 = false;    // ABLATION ONLY (ZKP_DEBUG_SKIP_K8_MASK): the next MSM skips its bucket reduction — wrong results, timing experiments
   bool batch_mode = false;     // inside zkp_groth16_prove_batch*: kernels are tuned for throughput of many proofs in flight, not latency
   std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)

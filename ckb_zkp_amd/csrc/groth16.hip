@@ -169,7 +169,7 @@ static void shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* cnt)
 // flags_out (optional) receives the identity flags of the uploaded slice
 static uint64_t upload_ext(zkp_ctx* ctx, int curve, int group, const uint64_t* q, const uint8_t* inf, size_t n,
                            size_t limbs_per_point, const uint64_t* const tail[4], size_t lo, size_t cnt, size_t lead = 0,
-                           std::vector<uint8_t>* flags_out = nullptr, int c_hint = 0, int cap_hint = 0) {
+                           std::vector<uint8_t>* flags_out = nullptr, int c_hint = 0, int cap_hint = 0, int lgk = -1) {
   std::vector<uint64_t> xy(std::max<size_t>(cnt, 1) * limbs_per_point, 0);
   std::vector<uint8_t> fl(std::max<size_t>(cnt, 1), 0);
   for (size_t j = 0; j < cnt; j++) {
@@ -188,7 +188,7 @@ static uint64_t upload_ext(zkp_ctx* ctx, int curve, int group, const uint64_t* q
     }
   }
   if (flags_out) *flags_out = fl;
-  return bases_upload(ctx, curve, group, xy.data(), fl.data(), cnt, c_hint, cap_hint);
+  return bases_upload(ctx, curve, group, xy.data(), fl.data(), cnt, c_hint, cap_hint, lgk);
 }
 
 zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, int rank, int world) {
@@ -236,8 +236,17 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
     // slice as A / B1 / B2 and can reuse their bucket sort
     pk->q_lo[4] = pk->q_lo[0];
     pk->q_n[4] = pk->q_n[0];
+    // Window-group size for the WHOLE key (msm.hip BasesEntry::lgk): the five queries are sized together so that they keep one
+    // window configuration (sort sharing) and their tables fit ZKP_TABLE_BUDGET_GB / the free device memory.
+    int lgk = 0;
+    {
+      const int groups[5] = {1, 1, 2, 1, 1};
+      const size_t ns[5] = {pk->q_n[0], pk->q_n[1], pk->q_n[2], world > 0 ? pk->q_n[3] : (size_t)d->h_len, pk->q_n[4]};
+      lgk = bases_plan_lgk(ctx, d->curve, groups, ns, 5);
+      if (lgk > 0 && getenv("ZKP_DEBUG_MSM")) fprintf(stderr, "[groth16] window tables do not fit: window groups of %d\n", 1 << lgk);
+    }
     std::vector<uint8_t> fA, fB1, fB2, fL;
-    pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA, pk->q_lo[0], pk->q_n[0], 0, &fA);
+    pk->hA = upload_ext(ctx, d->curve, 1, d->a_query, d->a_inf, d->a_len, 2 * fq, tA, pk->q_lo[0], pk->q_n[0], 0, &fA, 0, 0, lgk);
     // Window bits of the B queries (round 3).  A G2 bucket costs two Fq2 point additions in the reduction against 6 mixed
     // additions' worth of accumulate per entry, and half of a typical B query are identity points: with the c = round(log2 n) of
     // the G1 queries the B2 reduction (2^19 buckets) cost 0.70 ms per 2^20 proof beside 1.30 ms of accumulate.  Sized by the LIVE
@@ -262,8 +271,8 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
         if (const char* e = getenv("ZKP_B_TASK_CAP")) capB = atoi(e);
       }
     }
-    pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1, pk->q_lo[1], pk->q_n[1], 0, &fB1, cB, capB);
-    pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2, pk->q_lo[2], pk->q_n[2], 0, &fB2, cB, capB);
+    pk->hB1 = upload_ext(ctx, d->curve, 1, d->b_g1_query, d->b_g1_inf, d->b_g1_len, 2 * fq, tB1, pk->q_lo[1], pk->q_n[1], 0, &fB1, cB, capB, lgk);
+    pk->hB2 = upload_ext(ctx, d->curve, 2, d->b_g2_query, d->b_g2_inf, d->b_g2_len, 4 * fq, tB2, pk->q_lo[2], pk->q_n[2], 0, &fB2, cB, capB, lgk);
     {
       // B1 reuses B2's bucket sort + task schedule (same scalars, window configuration and identity pattern): -0.55 ms of
       // memory-bound sort kernels per proof.  With 4 hardware queues this LOST 2 % (84.7 -> 83.0 proofs/s: the wait on
@@ -274,9 +283,9 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
       pk->share_b_sort = on && same_inf && bases_same_shape(ctx, pk->hB1, pk->hB2);
     }
     pk->hH = bases_upload(ctx, d->curve, 1, d->h_query ? d->h_query + pk->q_lo[3] * 2 * fq : nullptr,
-                          d->h_inf ? d->h_inf + pk->q_lo[3] : nullptr, world > 0 ? pk->q_n[3] : (size_t)d->h_len);
+                          d->h_inf ? d->h_inf + pk->q_lo[3] : nullptr, world > 0 ? pk->q_n[3] : (size_t)d->h_len, 0, 0, lgk);
     pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL, pk->q_lo[4], pk->q_n[4],
-                        d->num_inputs, &fL);
+                        d->num_inputs, &fL, 0, 0, lgk);
     {
       // L reuses A's bucket sort + task schedule (L is stored index-aligned with z, so both MSMs run over the same scalar
       // slice): one digit scan + level-2 sort + schedule less per proof.  The shared sort drops a base only if it is the
@@ -350,7 +359,7 @@ void groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk) {
     if (PL.graph) (void)hipGraphDestroy(PL.graph);
   }
   for (uint64_t h : {pk->hA, pk->hB1, pk->hB2, pk->hH, pk->hL})
-    if (h) ctx->bases.erase(h);
+    if (h) bases_drop(ctx, h);
   for (auto& m : pk->m) {
     if (m.row_ptr) (void)hipFree(m.row_ptr);
     if (m.col) (void)hipFree(m.col);

@@ -28,8 +28,14 @@ void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const
 // msm.hip
 // c_hint > 0: window bits chosen by the caller (Groth16: the B queries are sized by their NON-identity bases); cap_hint > 0:
 // entries per accumulate task
+// lgk_hint >= 0: window-group size 2^lgk chosen by the caller (a Groth16 key sizes all five queries together); -1: chosen here
+// from ZKP_TABLE_BUDGET_GB / the free device memory (msm.hip BasesEntry::lgk)
 uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, const uint8_t* inf_host, size_t n,
-                      int c_hint = 0, int cap_hint = 0);
+                      int c_hint = 0, int cap_hint = 0, int lgk_hint = -1);
+// bytes of the resident window tables of n points at group size 2^lgk, and the smallest lgk whose tables (sum over `count`
+// queries) fit the budget
+size_t bases_table_bytes(int curve, int group, size_t n, int lgk);
+int bases_plan_lgk(zkp_ctx* ctx, int curve, const int* groups, const size_t* ns, int count);
 void bases_free(zkp_ctx* ctx, uint64_t handle);
 uint64_t bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t handle);
 size_t bases_len(zkp_ctx* ctx, uint64_t handle);
@@ -61,6 +67,7 @@ void msm_run_multi(zkp_ctx* ctx, size_t count, const uint64_t* handles, const si
 void msm_var_run(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, const uint8_t* inf_host,
                  const uint64_t* scalars_host, size_t n, bool montgomery, uint64_t* out_xyz_host);
 void msm_free_all(zkp_ctx* ctx);
+void bases_drop(zkp_ctx* ctx, uint64_t handle);
 void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz_host);
 void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, uint64_t* xy_out, uint8_t* inf_out);
 // k Jacobian points a_i (+ b_i where has_b[i]) -> affine, one launch; host in / host out (slot strides: 3 fN / 2 fN words)

@@ -65,11 +65,17 @@ struct BasesEntry {
   int c = 0, W = 0;            // bucket bits (= width of the wide windows), number of windows
   int wide = 0;                // the first `wide` windows are c bits wide, the remaining W - wide are c - 1 (balanced windows)
   uint32_t cap = MSM_TASK_CAP; // entries per task (<= MSM_TASK_CAP): smaller = more lanes for MSMs with few, long buckets
-  char* table = nullptr;       // W * n affine points: T[w][i] = 2^(c*w) * P_i
+  char* table = nullptr;       // W * n affine points: T[w][i] = 2^(c*w) * P_i (J copies with window groups, lgk below)
+  size_t table_bytes = 0;
   uint8_t* inf = nullptr;      // n identity flags (device) or nullptr
   // Variable-base mode (zkp_msm_g*_var): no window tables — `table` holds the n points as uploaded, the digit scan emits
   // entry (bucket w * 2^(c-1) + |d| - 1, point i) into W SEPARATE bucket sets, and the reduction weights window w by 2^(c*w).
   bool var = false;
+  // Window GROUPS (round 3: graceful path when the W window tables do not fit).  k = 2^lgk consecutive windows share ONE table copy:
+  // window w = k*j + m uses T[j] = 2^(c*k*j) * P and bucket set m (weight 2^(c*m), applied by the reduction with c*m doublings), so
+  // only J = ceil(W / k) copies are resident.  k = 1: the fixed-base plan above (var == false); k > 1: var == true with k bucket sets
+  // of 2^(c-1) buckets; k >= W (J = 1): the variable-base plan.  Equal window widths (wide == W) whenever k > 1.
+  int lgk = 0;
   bool owns = true;            // false: table / inf live in context scratch
   // Optional flags used ONLY by the digit scan when this entry owns a bucket sort that other MSMs reuse (Groth16: A, B1, B2
   // and L share one sort of z): a point is skipped by the scan only if it is the identity in EVERY sharing query; each
@@ -105,25 +111,89 @@ static int pick_window_bits(size_t n, int group) {
   return std::min(20, std::max(4, lg));
 }
 
+// Window plan of a resident base vector at group size k = 2^lgk: c window bits, W windows, J resident table copies.
+struct WindowPlan {
+  int c, W, wide, lgk, J;
+};
+static WindowPlan window_plan(int scalar_bits, size_t n, int group, int c_hint, int lgk) {
+  static const bool balanced = !(getenv("ZKP_MSM_BALANCED") && atoi(getenv("ZKP_MSM_BALANCED")) == 0);
+  const int T = scalar_bits + 1, c0 = c_hint >= 2 && c_hint <= 22 ? c_hint : pick_window_bits(n, group);
+  WindowPlan p{};
+  if (lgk <= 0) {
+    // Balanced windows: T = scalar_bits + 1 (one spare bit absorbs the last signed-digit carry) is spread over W = ceil(T / c)
+    // windows of ceil(T / W) and floor(T / W) bits instead of W - 1 full windows and a thin top one.  With c = 20 on a 254-bit
+    // field the top window was 14 bits wide: its n digits fell on 1/64 of the buckets (6x the average load: 16 of the 1024
+    // level-1 sort bins oversized, three tasks per hot bucket and a combine step); now 8 windows are 20 and 5 are 19 bits wide.
+    // ZKP_MSM_BALANCED=0 restores equal widths.
+    p.W = (T + c0 - 1) / c0;
+    p.c = balanced ? (T + p.W - 1) / p.W : c0;
+    p.wide = balanced ? T - p.W * (p.c - 1) : p.W;
+    p.lgk = 0;
+    p.J = p.W;
+    return p;
+  }
+  // window groups: k bucket sets keep the bucket count at 2^(c0 - 1) (c = c0 - lgk), equal widths, J = ceil(W / k) table copies
+  p.c = std::max(4, c0 - lgk);
+  p.W = (T + p.c - 1) / p.c;
+  p.wide = p.W;
+  p.lgk = lgk;
+  if ((1 << lgk) >= p.W) {                                     // one copy: k = the next power of two >= W
+    p.lgk = 0;
+    while ((1 << p.lgk) < p.W) p.lgk++;
+  }
+  p.J = (p.W + (1 << p.lgk) - 1) >> p.lgk;
+  return p;
+}
+size_t bases_table_bytes(int curve, int group, size_t n, int lgk) {
+  const MsmVtbl* vt = msm_vtbl(curve, group);
+  return std::max<size_t>(1, n) * (size_t)window_plan(vt->scalar_bits, n, group, 0, lgk).J * vt->aff_bytes;
+}
+// Budget for resident window tables: ZKP_TABLE_BUDGET_GB (whole context) if set, else the free device memory minus a quarter of
+// the device for MSM / NTT scratch; what the context already holds is subtracted.
+static double table_budget_left(zkp_ctx* ctx) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 1e30;
+  double left = (double)free_b - 0.25 * (double)total_b;
+  if (const char* e = getenv("ZKP_TABLE_BUDGET_GB")) {
+    const double b = atof(e) * 1073741824.0 - (double)ctx->table_bytes;
+    left = std::min(left + 0.25 * (double)total_b - 1073741824.0, b);     // an explicit budget only keeps 1 GiB back
+  }
+  return left;
+}
+int bases_plan_lgk(zkp_ctx* ctx, int curve, const int* groups, const size_t* ns, int count) {
+  if (const char* e = getenv("ZKP_TABLE_K")) {                   // forced group size (tests)
+    int k = atoi(e), lg = 0;
+    while ((1 << lg) < k) lg++;
+    return std::min(lg, 6);
+  }
+  const double left = table_budget_left(ctx);
+  for (int lgk = 0; lgk <= 6; lgk++) {
+    double need = 0;
+    for (int q = 0; q < count; q++) need += (double)bases_table_bytes(curve, groups[q], ns[q], lgk);
+    if (need <= left) return lgk;
+  }
+  return 6;                                                      // one copy per query: let the allocation decide
+}
+
 uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n, int c_hint,
-                      int cap_hint) {
+                      int cap_hint, int lgk_hint) {
   auto e = std::make_shared<BasesEntry>();
   e->curve = curve;
   e->group = group;
   e->vt = msm_vtbl(curve, group);
   e->n = n;
-  // Balanced windows: T = scalar_bits + 1 (one spare bit absorbs the last signed-digit carry) is spread over W = ceil(T / c)
-  // windows of ceil(T / W) and floor(T / W) bits instead of W - 1 full windows and a thin top one.  With c = 20 on a 254-bit
-  // field the top window was 14 bits wide: its n digits fell on 1/64 of the buckets (6x the average load: 16 of the 1024
-  // level-1 sort bins oversized, three tasks per hot bucket and a combine step); now 8 windows are 20 and 5 are 19 bits wide.
-  // ZKP_MSM_BALANCED=0 restores equal widths.
-  {
-    static const bool balanced = !(getenv("ZKP_MSM_BALANCED") && atoi(getenv("ZKP_MSM_BALANCED")) == 0);
-    const int T = e->vt->scalar_bits + 1, c0 = c_hint >= 2 && c_hint <= 22 ? c_hint : pick_window_bits(n, group);
-    e->W = (T + c0 - 1) / c0;
-    e->c = balanced ? (T + e->W - 1) / e->W : c0;
-    e->wide = balanced ? T - e->W * (e->c - 1) : e->W;
-  }
+  // Graceful path when the window tables do not fit (round 3): instead of ZKP_ERR_OOM the plan degrades to window groups —
+  // k = 2, 4, 8, ... consecutive windows share one table copy and use k bucket sets (BasesEntry::lgk) — down to ONE copy, the
+  // variable-base plan.  Cost at 2^20 points: tables 13 / 7 / 4 / 2 / 1 copies, entries x1.00 / 1.08 / 1.15 / 1.15 / 1.23, and a
+  // reduction tail of (c k - 1) doublings.
+  int lgk = lgk_hint;
+  if (lgk < 0) lgk = c_hint > 0 ? 0 : bases_plan_lgk(ctx, curve, &group, &n, 1);
+  const WindowPlan wp = window_plan(e->vt->scalar_bits, n, group, c_hint, lgk);
+  e->c = wp.c;
+  e->W = wp.W;
+  e->wide = wp.wide;
+  e->lgk = wp.lgk;
+  e->var = wp.lgk > 0;
   {
     const char* env = group == 2 ? getenv("ZKP_TASK_CAP_G2") : nullptr;
     if (!env) env = getenv("ZKP_TASK_CAP");
@@ -132,8 +202,10 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, co
   }
   ZKP_REQUIRE((double)n * e->W < 2147483000.0, ZKP_ERR_BAD_ARG);
   const size_t ab = e->vt->aff_bytes;
-  size_t bytes = std::max<size_t>(1, n) * e->W * ab;
+  size_t bytes = std::max<size_t>(1, n) * wp.J * ab;
   if (hipMalloc(&e->table, bytes) != hipSuccess) throw StatusError{ZKP_ERR_OOM};
+  e->table_bytes = bytes;
+  ctx->table_bytes += bytes;
   if (n) {
     ZKP_HIP(hipMemcpyAsync(e->table, xy, n * ab, hipMemcpyHostToDevice, ctx->cur->stream));
     if (inf) {
@@ -141,10 +213,15 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, co
       ZKP_HIP(hipMemcpyAsync(e->inf, inf, n, hipMemcpyHostToDevice, ctx->cur->stream));
       e->vt->ingest(ctx->cur->stream, e->table, e->inf, n);
     }
-    e->vt->precompute(ctx->cur->stream, e->table, n, e->c, e->W, e->wide);
+    // copy j = 2^(c k j) * P: the precompute kernel sees J "windows" of c*k bits (all of them full width) when k > 1
+    if (wp.lgk > 0) e->vt->precompute(ctx->cur->stream, e->table, n, e->c << wp.lgk, wp.J, wp.J);
+    else e->vt->precompute(ctx->cur->stream, e->table, n, e->c, e->W, e->wide);
     ZKP_HIP(hipGetLastError());
     ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
   }
+  if (getenv("ZKP_DEBUG_MSM"))
+    fprintf(stderr, "[msm] bases group=%d n=%zu: c=%d W=%d wide=%d k=%d copies=%d (%.2f GiB)\n", group, n, e->c, e->W, e->wide,
+            1 << e->lgk, wp.J, (double)bytes / 1073741824.0);
   uint64_t h = ctx->next_handle++;
   ctx->bases[h] = e;
   return h;
@@ -157,12 +234,22 @@ static std::shared_ptr<BasesEntry> get_bases(zkp_ctx* ctx, uint64_t handle) {
 }
 void bases_free(zkp_ctx* ctx, uint64_t handle) {
   ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
-  if (ctx->bases.erase(handle) == 0) throw StatusError{ZKP_ERR_BAD_HANDLE};
+  auto it = ctx->bases.find(handle);
+  if (it == ctx->bases.end()) throw StatusError{ZKP_ERR_BAD_HANDLE};
+  if (it->second.use_count() == 1) ctx->table_bytes -= std::min(ctx->table_bytes, it->second->table_bytes);
+  ctx->bases.erase(it);
 }
 size_t bases_len(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->n; }
 int bases_group(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->group; }
+void bases_drop(zkp_ctx* ctx, uint64_t handle) {              // like bases_free, for owners that tear a key down (no throw)
+  auto it = ctx->bases.find(handle);
+  if (it == ctx->bases.end()) return;
+  if (it->second.use_count() == 1) ctx->table_bytes -= std::min(ctx->table_bytes, it->second->table_bytes);
+  ctx->bases.erase(it);
+}
 void msm_free_all(zkp_ctx* ctx) {
   ctx->bases.clear();
+  ctx->table_bytes = 0;
   ctx->var_plans.clear();
 }
 uint64_t bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t handle) {
@@ -198,7 +285,7 @@ void bases_set_filter_bit(zkp_ctx* ctx, uint64_t handle, int bit) {
 }
 bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2) {
   auto a = get_bases(ctx, h1), b = get_bases(ctx, h2);
-  return a->curve == b->curve && a->n == b->n && a->c == b->c && a->W == b->W && a->wide == b->wide && a->cap == b->cap;
+  return a->curve == b->curve && a->n == b->n && a->c == b->c && a->W == b->W && a->wide == b->wide && a->cap == b->cap && a->lgk == b->lgk;
 }
 
 // ------------------------------------------------------------------------------------------- K5 digit scan
@@ -342,8 +429,9 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restri
                                                         const uint8_t* __restrict__ inf, int montgomery, int c, int W, int wide,
                                                         uint32_t nb, int L, uint32_t nbins1,
                                                         uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t tile,
-                                                        int var) {
+                                                        int lgk) {
   ZKP_SORT_PRIO();
+  const uint32_t gmask = (1u << lgk) - 1;                          // window w -> bucket set w & gmask, table copy w >> lgk
   __shared__ uint32_t cnt[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i <= nbins1; i += 256) cnt[i] = 0;
   __syncthreads();
@@ -354,7 +442,7 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restri
       for (int w = 0; w < W; w++) {
         uint32_t key, neg;
         it.next(w, c, wide, nb, key, neg);
-        if (key < nb) atomicAdd(&cnt[(var ? ((uint32_t)w << (c - 1)) | key : key) >> L], 1u);
+        if (key < nb) atomicAdd(&cnt[((((uint32_t)w & gmask) << (c - 1)) | key) >> L], 1u);
       }
     }
   }
@@ -367,9 +455,10 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
                                                            int montgomery, size_t ntab, int c, int W, int wide, uint32_t nb,
                                                            int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
                                                            uint32_t nblocks, uint32_t tile,
-                                                           uint64_t* __restrict__ kv, int var,
+                                                           uint64_t* __restrict__ kv, int lgk,
                                                            const uint8_t* __restrict__ group_flags) {   // (low key << 32) | val
   ZKP_SORT_PRIO();
+  const uint32_t gmask = (1u << lgk) - 1;
   __shared__ uint32_t cur[(1 << SORT_H1_MAX) + 1];
   for (uint32_t i = threadIdx.x; i < nbins1; i += 256) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
   __syncthreads();
@@ -384,9 +473,9 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
         uint32_t key, neg;
         it.next(w, c, wide, nb, key, neg);
         if (key < nb) {                                // zero digits are dropped here
-          const uint32_t fk = var ? ((uint32_t)w << (c - 1)) | key : key;     // variable-base: one bucket set per window
+          const uint32_t fk = (((uint32_t)w & gmask) << (c - 1)) | key;     // window w = k*j + m: bucket set m, table copy j
           uint32_t pos = atomicAdd(&cur[fk >> L], 1u);
-          uint32_t val = (uint32_t)((var ? (size_t)0 : (size_t)w * ntab) + offset + i) | (neg << 31);
+          uint32_t val = (uint32_t)((size_t)(w >> lgk) * ntab + offset + i) | (neg << 31);
           kv[pos] = gbits | ((uint64_t)(fk & lmask) << 32) | val;   // one 8-B store per entry
         }
       }
@@ -432,8 +521,9 @@ __global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t
                                                                   int montgomery, size_t ntab, int c, int W, int wide, uint32_t nb,
                                                                   int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
                                                                   uint32_t nblocks, uint32_t tile, uint64_t* __restrict__ kv,
-                                                                  int var, const uint8_t* __restrict__ group_flags, uint32_t sub) {
+                                                                  int lgk, const uint8_t* __restrict__ group_flags, uint32_t sub) {
   ZKP_SORT_PRIO();
+  const uint32_t gmask = (1u << lgk) - 1;
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
   __shared__ uint32_t pre[256];
   uint32_t* cur = sm;                                     // [nbins1] next free slot of (bin, this tile) in kv
@@ -454,7 +544,7 @@ __global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t
       for (int w = 0; w < W; w++) {
         uint32_t key, neg;
         it.next(w, c, wide, nb, key, neg);
-        const uint32_t fk = var ? ((uint32_t)w << (c - 1)) | key : key;
+        const uint32_t fk = (((uint32_t)w & gmask) << (c - 1)) | key;
         (void)wave_agg_inc(cnt, fk >> L, live && key < nb);
       }
     }
@@ -495,11 +585,11 @@ __global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t
       for (int w = 0; w < W; w++) {
         uint32_t key, neg;
         it.next(w, c, wide, nb, key, neg);
-        const uint32_t fk = var ? ((uint32_t)w << (c - 1)) | key : key;
+        const uint32_t fk = (((uint32_t)w & gmask) << (c - 1)) | key;
         const bool act = live && key < nb;
         const uint32_t pos = wave_agg_inc(cnt, fk >> L, act);
         if (act) {
-          const uint32_t val = (uint32_t)((var ? (size_t)0 : (size_t)w * ntab) + offset + i) | (neg << 31);
+          const uint32_t val = (uint32_t)((size_t)(w >> lgk) * ntab + offset + i) | (neg << 31);
           stage[pos] = gbits | ((uint64_t)(fk >> L) << 45) | ((uint64_t)(fk & lmask) << 32) | val;
         }
       }
@@ -782,11 +872,10 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
   } else {
     const int c = be->c, W = be->W, wide = be->wide;
     const int var = be->var ? 1 : 0;
-    int lgW = 0;
-    while ((1 << lgW) < W) lgW++;
-    ZKP_REQUIRE(!var || (1 << lgW) == W, ZKP_ERR_BAD_ARG);
+    const int lgk = be->lgk, K = 1 << lgk;                             // bucket sets (window groups, BasesEntry::lgk)
+    ZKP_REQUIRE(var == (lgk > 0), ZKP_ERR_BAD_ARG);
     const uint32_t nb_w = 1u << (c - 1);                               // buckets of one window (digit range)
-    const int kbits = (c - 1) + (var ? lgW : 0);                       // bits of a bucket id
+    const int kbits = (c - 1) + lgk;                                   // bits of a bucket id
     const uint32_t nb = 1u << kbits;                                   // all buckets
     const size_t E = n * (size_t)W;
     ZKP_REQUIRE(E < 2147483000ull, ZKP_ERR_BAD_ARG);
@@ -844,24 +933,24 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     if (reuse || l1_reuse) {
     } else if (be->curve == ZKP_BN254) {
       hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
-                         wide, nb_w, LB, nbins1, hist, nblocks, tile, var);
+                         wide, nb_w, LB, nbins1, hist, nblocks, tile, lgk);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
       if (staged_sub)
         hipLaunchKernelGGL(sort_scatter_staged_kernel<Bn254Fr>, dim3(nblocks), dim3(256), staged_lds, st, sc, n, offset, scan_inf,
-                           mont, be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp, staged_sub);
+                           mont, be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, lgk, grp, staged_sub);
       else
         hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
-                           be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp);
+                           be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, lgk, grp);
     } else {
       hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
-                         wide, nb_w, LB, nbins1, hist, nblocks, tile, var);
+                         wide, nb_w, LB, nbins1, hist, nblocks, tile, lgk);
       exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
       if (staged_sub)
         hipLaunchKernelGGL(sort_scatter_staged_kernel<Bls381Fr>, dim3(nblocks), dim3(256), staged_lds, st, sc, n, offset, scan_inf,
-                           mont, be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp, staged_sub);
+                           mont, be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, lgk, grp, staged_sub);
       else
         hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
-                           be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, var, grp);
+                           be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, lgk, grp);
     }
     if (timed_scan) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
@@ -942,19 +1031,19 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     if (var) {
       // K8, variable-base: the pairwise pyramid runs over all W bucket sets at once (pairs never straddle windows), c - 1
       // levels deep; two descriptor-driven segmented sums give R_t; 256 lanes weigh them by 2^t (<= 255 doublings each)
-      VarPlan& vp = var_plan(ctx, c, W, st);
+      VarPlan& vp = var_plan(ctx, c, K, st);
       uint32_t lvl_off = 0, cnt = nb;
       for (int l = 0; l < c - 1; l++) {
         vt->pair(st, buckets + (size_t)lvl_off * XB, buckets + (size_t)(lvl_off + cnt) * XB, cnt / 2);
         lvl_off += cnt;
         cnt /= 2;
       }
-      const char* roots = buckets + (size_t)lvl_off * XB;            // cnt == W
+      const char* roots = buckets + (size_t)lvl_off * XB;            // cnt == K (one root per bucket set)
       char* partial = reinterpret_cast<char*>(ws.tmp.get(((size_t)vp.n1 + 256 + 8) * XB));
       char* R = partial + (size_t)vp.n1 * XB;
       vt->segsum_desc(st, buckets, vp.d1.as<SegDesc>(vp.n1), vp.n1, partial);
       vt->segsum_desc(st, partial, vp.d2.as<SegDesc>(256), 256, R);
-      vt->final_var(st, R, roots, c, W, (char*)out_dev_xyzz, out_jac);
+      vt->final_var(st, R, roots, c, K, (char*)out_dev_xyzz, out_jac);
       ZKP_HIP(hipGetLastError());
       if (out_xyz_host) {
         ZKP_HIP(hipMemcpyAsync(out_xyz_host, out_jac, jac_words * 4, hipMemcpyDeviceToHost, st));
@@ -1105,6 +1194,7 @@ void msm_var_run(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_host, co
   }
   e.W = 256 / e.c;
   e.wide = e.W;                // equal widths: the variable-base reduction weighs window w by 2^(c*w)
+  while ((1 << e.lgk) < e.W) e.lgk++;          // one bucket set per window: the single "table copy" is the points themselves
   ZKP_REQUIRE((double)n * e.W < 2147483000.0, ZKP_ERR_BAD_ARG);
   hipStream_t st = ctx->cur->stream;
   const size_t ab = e.vt->aff_bytes;
