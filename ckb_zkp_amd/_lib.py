@@ -137,6 +137,7 @@ SIGNATURES = {
     "zkp_groth16_witness_map": (C.c_int32, [vp, vp, vp, vp]),
     "zkp_groth16_witness_map_dev": (C.c_int32, [vp, vp, vp, vp]),
     "zkp_groth16_domain_size": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
+    "zkp_groth16_pk_info": (C.c_int32, [vp, vp, C.POINTER(C.c_uint64)]),
     "zkp_groth16_prove": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp]),
     "zkp_groth16_prove_dev": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp]),
     "zkp_groth16_prove_batch_dev": (C.c_int32, [vp, vp, C.c_size_t, vp, vp, vp, vp, vp]),

@@ -474,6 +474,10 @@ int32_t zkp_groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk) {
   if (!pk) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { groth16_pk_free(ctx, pk); });
 }
+int32_t zkp_groth16_pk_info(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t info[8]) {
+  if (!ctx || !pk || !info) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { groth16_pk_info(ctx, pk, info); });
+}
 int32_t zkp_groth16_domain_size(zkp_groth16_pk* pk, uint64_t* n) {
   if (!pk || !n) return ZKP_ERR_BAD_ARG;
   *n = groth16_domain_size(pk);

@@ -369,6 +369,24 @@ void groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk) {
 }
 
 uint64_t groth16_domain_size(zkp_groth16_pk* pk) { return pk->N; }
+void groth16_pk_info(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t info[8]) {
+  for (int i = 0; i < 8; i++) info[i] = 0;
+  if (!pk->hA) return;
+  uint64_t a[5], b[5];
+  bases_info(ctx, pk->hA, a);
+  bases_info(ctx, pk->hB2, b);
+  info[0] = a[2];
+  for (uint64_t h : {pk->hA, pk->hB1, pk->hB2, pk->hH, pk->hL}) {
+    uint64_t t[5];
+    bases_info(ctx, h, t);
+    info[1] += t[4];
+  }
+  info[2] = a[0];
+  info[3] = a[1];
+  info[4] = a[3];
+  info[5] = b[0];
+  info[6] = (pk->share_b_sort ? 1 : 0) | (pk->share_al_sort ? 2 : 0) | (pk->share_l1 ? 4 : 0);
+}
 
 // z_dev: nz Fr (device).  Leaves h (N Fr, Montgomery) in pk->abc[0..N)
 template <class P>

@@ -85,6 +85,8 @@ void groth16_fold_assemble(zkp_ctx* ctx, int curve, const void* gathered_dev, in
                            const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 void groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk);
 uint64_t groth16_domain_size(zkp_groth16_pk* pk);
+void groth16_pk_info(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t info[8]);
+void bases_info(zkp_ctx* ctx, uint64_t handle, uint64_t info[5]);   // c, W, k, copies, table bytes
 void groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, uint64_t* h, bool on_device);
 void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_on_device, const uint64_t* r,
                    const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);

@@ -241,6 +241,14 @@ void bases_free(zkp_ctx* ctx, uint64_t handle) {
 }
 size_t bases_len(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->n; }
 int bases_group(zkp_ctx* ctx, uint64_t handle) { return get_bases(ctx, handle)->group; }
+void bases_info(zkp_ctx* ctx, uint64_t handle, uint64_t info[5]) {
+  auto e = get_bases(ctx, handle);
+  info[0] = (uint64_t)e->c;
+  info[1] = (uint64_t)e->W;
+  info[2] = (uint64_t)1 << e->lgk;
+  info[3] = e->lgk ? (uint64_t)((e->W + (1 << e->lgk) - 1) >> e->lgk) : (uint64_t)e->W;
+  info[4] = e->table_bytes;
+}
 void bases_drop(zkp_ctx* ctx, uint64_t handle) {              // like bases_free, for owners that tear a key down (no throw)
   auto it = ctx->bases.find(handle);
   if (it == ctx->bases.end()) return;

@@ -227,6 +227,14 @@ class ProvingKey:
         self.domain_size = n.value
         self.nz = inst.num_inputs + inst.num_aux
 
+    def table_plan(self) -> dict:
+        """zkp_groth16_pk_info: how the window tables of this key are laid out (window groups when they did not fit)."""
+        info = (C.c_uint64 * 8)()
+        _lib.check(self.ctx.lib.zkp_groth16_pk_info(self.ctx.h, self.h, info), "zkp_groth16_pk_info")
+        return {"window_group": int(info[0]), "table_bytes": int(info[1]), "window_bits": int(info[2]), "windows": int(info[3]),
+                "table_copies": int(info[4]), "window_bits_b": int(info[5]), "b1_reuses_b2_sort": bool(info[6] & 1),
+                "l_reuses_a_sort": bool(info[6] & 2), "shared_level1_pass": bool(info[6] & 4)}
+
     def free(self):
         if self.h:
             _lib.check(self.ctx.lib.zkp_groth16_pk_free(self.ctx.h, self.h), "zkp_groth16_pk_free")

@@ -211,6 +211,11 @@ int32_t zkp_groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk);
 int32_t zkp_groth16_witness_map(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_host, uint64_t* h_host);
 int32_t zkp_groth16_witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_dev, uint64_t* h_dev);
 int32_t zkp_groth16_domain_size(zkp_groth16_pk* pk, uint64_t* n);
+/* Window-table plan of a resident key: info[0] = window-group size k (1 = one table copy per window; > 1: the tables did not
+ * fit ZKP_TABLE_BUDGET_GB / the free device memory and k consecutive windows share a copy), info[1] = bytes of the five
+ * queries' tables, info[2..4] = window bits / windows / resident copies of the A query, info[5] = window bits of the B queries,
+ * info[6] = sort sharing (bit 0: B1 reuses B2's bucket sort, bit 1: L reuses A's, bit 2: shared level-1 pass), info[7] = 0. */
+int32_t zkp_groth16_pk_info(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t info[8]);
 
 /* create_proof(params, circuit, r, s): z = full assignment (Montgomery), r/s Fr Montgomery (4 limbs).
  * proof_out: A (G1 affine) | B (G2 affine) | C (G1 affine), Montgomery; inf_out[3] identity flags. */
