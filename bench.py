@@ -429,14 +429,14 @@ def main():
         # algorithmic bytes: scalars read once (32 B) + affine bases read once, per MSM
         msm_bytes = [(nz + 4) * (32 + 2 * fq), (nz + 4) * (32 + 2 * fq), (nz + 4) * (32 + 4 * fq),
                      (pk.domain_size - 1) * (32 + 2 * fq), (inst.num_aux + 4) * (32 + 2 * fq)]
-        bytes_per_launch = sum(msm_bytes) / 5.0
+        bytes_per_launch = sum(msm_bytes) / max(tm_last["msm_accumulate_launches"], 1)
         avg_ms = acc_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch: PMC counters cannot be read from inside the process; they come from the separate
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command recorded under profiles/
         traffic, traffic_src = None, None
         here = os.path.dirname(os.path.abspath(__file__))
-        for name in ("r02_pmc_accumulate.json", "r01_pmc_accumulate.json"):
+        for name in ("r03_pmc_accumulate.json", "r02_pmc_accumulate.json", "r01_pmc_accumulate.json"):
             pmc = os.path.join(here, "profiles", name)
             if args.log_n == 20 and c.name == "bn254" and os.path.exists(pmc):
                 traffic, traffic_src = json.load(open(pmc))["traffic_bytes_per_launch"], "profiles/" + name
