@@ -632,6 +632,7 @@ def main():
                         "phase_ms": [round(x, 1) for x in ph.tolist()]}
 
     marlin = None
+    table_plan = pk.table_plan() if rank == 0 else None
     if rank == 0 and world == 1 and not args.no_marlin and args.log_n == 20 and c.name == "bn254":
         pk.free()                                              # the Groth16 key's window tables make room for the SRS
         try:
@@ -650,7 +651,7 @@ def main():
             "config": {"workload": f"Groth16 prove, MiMC-chain R1CS, {inst.num_constraints()} constraints "
                                    f"(domain 2^{args.log_n}), {inst.num_aux} aux, {c.name}, G1 x4 + G2 x1 MSM + 7 NTT",
                        "curve": c.name, "log_domain": args.log_n, "parallelism": f"independent proofs x{world}",
-                       "table_plan": pk.table_plan(),
+                       "table_plan": table_plan,
                        "pipelining": "none" if args.no_pipeline else f"{os.environ.get('ZKP_LANES', '8 (4 above 2^22)')} proofs in flight per GPU (zkp_groth16_prove_batch_dev), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}"},
             "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_scan": roofline_scan, "valu_roof": valu_roof,
             "with_h2d": with_h2d, "latency": latency, "cpu_baseline": cpu_baseline, "parity_check": parity_check,
