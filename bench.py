@@ -490,7 +490,7 @@ def main():
         if phases:
             ceil_u = ctx.bench_mulmod(c, 1, True)
             ceil_s = ctx.bench_mulmod(c, 1, False)
-            ceil_fr = ctx.bench_mulmod(c, 0, False)
+            ceil_fr = ctx.bench_mulmod(c, 0, True)                # the NTT products run on the unsaturated multiplier since round 3
             g1 = [i for i in (0, 1, 3, 4)]
             t_g1 = sum(phases["ms_msm_acc"][i] for i in g1)
             e_g1 = sum(phases["msm_entries"][i] for i in g1)
@@ -507,7 +507,7 @@ def main():
                                            "multiplier": "unsaturated limbs, schoolbook Fq2 with lazily reduced sums (unsat_dev.hpp)"},
                          "ntt": {"achieved": roofline_ntt["valu"]["gmulmod_per_s"], "ceiling": round(ceil_fr, 1),
                                  "frac": round(roofline_ntt["valu"]["gmulmod_per_s"] / ceil_fr, 3),
-                                 "multiplier": "saturated Fr"},
+                                 "multiplier": "unsaturated Fr products, saturated carry-chain add / sub (ntt.hip)"},
                          "saturated_fq_ceiling": round(ceil_s, 1),
                          "note": "ceilings = zkp_bench_mulmod (better of 2 and 4 independent product chains per lane, 8 workgroups per CU), "
                                  "measured in this process; the accumulate / NTT kernels are bound by this roof, not by HBM"}

@@ -416,7 +416,7 @@ int32_t zkp_marlin_last_timing(zkp_ctx* ctx, zkp_marlin_timing* out);
 int32_t zkp_set_profiling(zkp_ctx* ctx, int32_t enable); /* per-phase HIP events (adds sync points) */
 /* Sustained rate (1e9 products / s) of the library's own Montgomery multipliers with every CU saturated: the integer-VALU
  * roof the MSM / NTT kernels are bound by, measured in the calling process (bench.py `valu_roof`).
- * field: 0 = Fr, 1 = Fq; unsaturated: 0 = 32-bit saturated limbs (field_dev.hpp), 1 = 29/28-bit limbs (unsat_dev.hpp, Fq only). */
+ * field: 0 = Fr, 1 = Fq; unsaturated: 0 = 32-bit saturated limbs (field_dev.hpp), 1 = 29/28-bit limbs (unsat_dev.hpp). */
 int32_t zkp_bench_mulmod(zkp_ctx* ctx, zkp_curve_t curve, int32_t field, int32_t unsaturated, double* gmulmod_per_s);
 
 #ifdef __cplusplus
