@@ -51,6 +51,8 @@ ZKP_DEV void fu_store(void* p, const Fu<P>& a) {
 
 template <class F>
 struct BkPoint;
+template <class F>
+__device__ __noinline__ void bk_same_x_mem(const char* a, char* out, bool same_y);
 // P = +-Q inside an addition (same x): doubling or the identity.  Out of line — one copy of the doubling formulas per
 // translation unit instead of one per call site of add() (the BLS12-381 G2 unit took 5 minutes to compile with it inline);
 // the callee needs fewer registers than add() itself, so it does not raise the callers' register budget.
@@ -107,6 +109,13 @@ struct BkPoint<Fp<P>> {
   ZKP_DEV XYZZ<F> to_sat() const {
     if (v.inf) return XYZZ<F>::inf();
     return {v.x.f.to_sat(), v.y.f.to_sat(), v.zz.f.to_sat(), v.zzz.f.to_sat()};
+  }
+  static constexpr bool MEM_ADD = false;                   // G1 additions keep both operands in registers (115-120 VGPRs)
+  ZKP_DEV static void dbl_mem(const char* a, char* out) { load(a).dbl().store(out); }
+  ZKP_DEV static void add_mem(const char* a, const char* b, char* out) {
+    BkPoint pa = load(a);
+    pa.add(load(b));
+    pa.store(out);
   }
   // this += o   (add-2008-s)
   ZKP_DEV void add(const BkPoint& o) {
@@ -257,6 +266,130 @@ struct BkPoint<Fp2<P>> {
     v.x = x3;
     v.y = {y30, y31};
   }
+  // out = a + b with the operands STREAMED from memory (global or LDS; out may be a): at no time are both points in registers —
+  // the eight Fq2 coordinates of two G2 points are 144 VGPRs before the first product, and add() above compiled to 254 VGPRs + 312 B
+  // of scratch (one or two waves per SIMD) in every reduction kernel.  zz1 zz2 and zzz1 zzz2 are parked in out.zz / out.zzz until
+  // pp / ppp exist.  Round 3: the G2 reduction cost 0.70 ms of a 7.3 ms proof for 0.23 ms of multiplier work.
+  static constexpr bool MEM_ADD = true;
+#define ZKP_SCHED_FENCE() __asm__ volatile("" ::: "memory")
+  ZKP_DEV static UB2<P, 2> ld2(const char* q, int slot) { return {{fu_load<P>(q + (2 * slot) * EB)}, {fu_load<P>(q + (2 * slot + 1) * EB)}}; }
+  ZKP_DEV static void st2(char* q, int slot, const Fu<P>& c0, const Fu<P>& c1) {
+    fu_store<P>(q + (2 * slot) * EB, c0);
+    fu_store<P>(q + (2 * slot + 1) * EB, c1);
+  }
+  ZKP_DEV static void copy_point(char* out, const char* in) {
+    if (out == in) return;
+#pragma unroll
+    for (int k = 0; k < 8; k++) fu_store<P>(out + k * EB, fu_load<P>(in + k * EB));
+  }
+  template <int KA>
+  ZKP_DEV static UB2<P, 2> sqr_c(const UB2<P, KA>& a) {    // complex squaring: (a0 + a1)(a0 - a1 + KA p), (2 a0) a1
+    return {ub_mul(ub_add(a.c0, a.c1), ub_sub(a.c0, a.c1)), ub_mul(ub_dbl(a.c0), a.c1)};
+  }
+  // out = 2 a, operands streamed like add_mem (out may be a; a is not the identity)
+  ZKP_DEV static void dbl_mem(const char* a, char* out) {
+    UB2<P, 2> vv;
+    {
+      const auto u = ub2_dbl(ld2(a, 1));                   // 2y < 4p
+      vv = sqr_c(u);
+      const auto zz3 = ub2_mul(vv, ld2(a, 2));
+      st2(out, 2, zz3.c0.f, zz3.c1.f);
+    }
+    ZKP_SCHED_FENCE();
+    UB2<P, 6> m;
+    UB2<P, 6> t;
+    {
+      const UB2<P, 4> x = {UB<P, 4>{fu_load<P>(a)}, UB<P, 4>{fu_load<P>(a + EB)}};
+      const auto s = ub2_mul(x, vv);
+      const auto x2 = sqr_c(x);
+      m = {ub_add3(ub_dbl(x2.c0), x2.c0), ub_add3(ub_dbl(x2.c1), x2.c1)};
+      const auto mm = sqr_c(m);                            // 12 * 12 = 144
+      const auto x3w = ub2_sub(mm, ub2_dbl(s));            // (0, 6p)
+      const UB2<P, 4> x3 = {UB<P, 4>{U::template csub<4>(x3w.c0.f)}, UB<P, 4>{U::template csub<4>(x3w.c1.f)}};
+      t = ub2_sub(s, x3);                                  // (0, 6p)
+      st2(out, 0, x3.c0.f, x3.c1.f);
+    }
+    ZKP_SCHED_FENCE();
+    const UB2<P, 2> y = ld2(a, 1);                         // out.y is written last: out may be a
+    const auto w = ub2_mul(ub2_dbl(y), vv);                // (2y)^3
+    {
+      const auto zzz3 = ub2_mul(w, ld2(a, 3));
+      st2(out, 3, zzz3.c0.f, zzz3.c1.f);
+    }
+    static_assert(6 * 6 + 6 * 7 + 2 * 2 * 2 <= UBLimits<P>::MULCAP, "y3 exceeds the slack");
+    const auto ny0 = ub_neg<2>(y.c0);
+    const Fu<P> y30 = U::mul_add4(m.c0.f, t.c0.f, m.c1.f, ub_neg_lazy(t.c1).f, w.c0.f, ny0.f, w.c1.f, y.c1.f);
+    const Fu<P> y31 = U::mul_add4(m.c0.f, t.c1.f, m.c1.f, t.c0.f, w.c0.f, ub_neg_lazy(y.c1).f, w.c1.f, ny0.f);
+    st2(out, 1, y30, y31);
+  }
+  ZKP_DEV static void add_mem(const char* a, const char* b, char* out) {
+    const UB2<P, 2> zz1 = ld2(a, 2), zz2 = ld2(b, 2);
+    const bool inf1 = fu_is_zero(zz1.c0.f) && fu_is_zero(zz1.c1.f), inf2 = fu_is_zero(zz2.c0.f) && fu_is_zero(zz2.c1.f);
+    if (inf2) {
+      copy_point(out, a);
+      return;
+    }
+    if (inf1) {
+      copy_point(out, b);
+      return;
+    }
+    UB2<P, 4> pd;
+    UB2<P, 2> u1;
+    {
+      const UB2<P, 4> x1 = {UB<P, 4>{fu_load<P>(a)}, UB<P, 4>{fu_load<P>(a + EB)}};
+      u1 = ub2_mul(x1, zz2);
+      const UB2<P, 4> x2 = {UB<P, 4>{fu_load<P>(b)}, UB<P, 4>{fu_load<P>(b + EB)}};
+      pd = ub2_sub(ub2_mul(x2, zz1), u1);                  // (0, 4p)
+    }
+    const bool same_x = pd.c0.f.template maybe_multiple_of_p<4>() && pd.c1.f.template maybe_multiple_of_p<4>() &&
+                        pd.c0.f.template is_multiple_of_p<4>() && pd.c1.f.template is_multiple_of_p<4>();
+    if (!same_x) {                                         // (the exceptional path below still needs a's coordinates in place)
+      const UB2<P, 2> zzp = ub2_mul(zz1, zz2);
+      st2(out, 2, zzp.c0.f, zzp.c1.f);                     // parked: a's and b's zz are consumed
+    }
+    ZKP_SCHED_FENCE();                                     // keep the next stage's loads below this point (register pressure)
+    UB2<P, 2> s1;
+    UB2<P, 4> rd;
+    {
+      const UB2<P, 2> zzz1 = ld2(a, 3), zzz2 = ld2(b, 3);
+      const UB2<P, 2> y1 = ld2(a, 1);
+      s1 = ub2_mul(y1, zzz2);
+      const UB2<P, 2> y2 = ld2(b, 1);
+      rd = ub2_sub(ub2_mul(y2, zzz1), s1);                 // (0, 4p)
+      if (same_x) {                                        // P = +-Q (crafted inputs only): doubling or the identity, out of line
+        bk_same_x_mem<F>(a, out, rd.c0.f.template is_multiple_of_p<4>() && rd.c1.f.template is_multiple_of_p<4>());
+        return;
+      }
+      const UB2<P, 2> zzzp = ub2_mul(zzz1, zzz2);
+      st2(out, 3, zzzp.c0.f, zzzp.c1.f);                   // parked likewise
+      st2(out, 1, s1.c0.f, s1.c1.f);                       // s1 waits in out.y until y3 needs it
+    }
+    ZKP_SCHED_FENCE();
+    const UB2<P, 2> pp = {ub_mul(ub_add(pd.c0, pd.c1), ub_sub(pd.c0, pd.c1)), ub_mul(ub_dbl(pd.c0), pd.c1)};   // complex squaring: 8*8, 8*4
+    const auto ppp = ub2_mul(pd, pp);
+    {
+      const UB2<P, 2> zzp = ld2(out, 2);
+      const auto zz3 = ub2_mul(zzp, pp);
+      st2(out, 2, zz3.c0.f, zz3.c1.f);
+      const UB2<P, 2> zzzp = ld2(out, 3);
+      const auto zzz3 = ub2_mul(zzzp, ppp);
+      st2(out, 3, zzz3.c0.f, zzz3.c1.f);
+    }
+    ZKP_SCHED_FENCE();
+    const auto q = ub2_mul(u1, pp);
+    const UB2<P, 2> rr = {ub_mul(ub_add(rd.c0, rd.c1), ub_sub(rd.c0, rd.c1)), ub_mul(ub_dbl(rd.c0), rd.c1)};
+    const UB2<P, 4> x3 = {UB<P, 4>{U::template csub<4>(ub_sub_sub2(rr.c0, ppp.c0, q.c0).f)},
+                          UB<P, 4>{U::template csub<4>(ub_sub_sub2(rr.c1, ppp.c1, q.c1).f)}};
+    st2(out, 0, x3.c0.f, x3.c1.f);
+    ZKP_SCHED_FENCE();
+    const auto t = ub2_sub(q, x3);                         // (0, 6p)
+    static_assert(4 * 6 + 4 * 7 + 2 * 2 * 2 <= UBLimits<P>::MULCAP, "y3 exceeds the slack");
+    const auto nppp0 = ub_neg<2>(ppp.c0);
+    const UB2<P, 2> s1b = ld2(out, 1);
+    const Fu<P> y30 = U::mul_add4(rd.c0.f, t.c0.f, rd.c1.f, ub_neg_lazy(t.c1).f, s1b.c0.f, nppp0.f, s1b.c1.f, ppp.c1.f);
+    const Fu<P> y31 = U::mul_add4(rd.c0.f, t.c1.f, rd.c1.f, t.c0.f, s1b.c0.f, ub_neg_lazy(ppp.c1).f, s1b.c1.f, nppp0.f);
+    st2(out, 1, y30, y31);
+  }
   ZKP_DEV BkPoint dbl() const {
     if (v.inf) return *this;
     const auto u = ub2_dbl(v.y);                           // < 4p
@@ -285,6 +418,11 @@ struct BkPoint<Fp2<P>> {
 template <class F>
 __device__ __noinline__ void bk_same_x(BkPoint<F>& a, bool same_y) {
   a = same_y ? a.dbl() : BkPoint<F>::inf();
+}
+template <class F>
+__device__ __noinline__ void bk_same_x_mem(const char* a, char* out, bool same_y) {
+  if (same_y) BkPoint<F>::dbl_mem(a, out);
+  else BkPoint<F>::inf().store(out);
 }
 
 }  // namespace zkp

@@ -62,9 +62,8 @@ __global__ __launch_bounds__(256) void pair_kernel(const char* __restrict__ in, 
   __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= count) return;
-  BkPoint<F> a = BkPoint<F>::load(in + (size_t)(2 * k) * BkPoint<F>::BYTES);
-  a.add(BkPoint<F>::load(in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES));
-  a.store(out + (size_t)k * BkPoint<F>::BYTES);
+  BkPoint<F>::add_mem(in + (size_t)(2 * k) * BkPoint<F>::BYTES, in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES,
+                      out + (size_t)k * BkPoint<F>::BYTES);
 }
 
 // The top of the pyramid in ONE launch: the level with `cnt` <= PAIR_TOP_MAX entries at `base`, every further level
@@ -78,11 +77,9 @@ __global__ __launch_bounds__(PAIR_TOP_THREADS) void pair_top_kernel(char* __rest
   char* in = base;
   for (; cnt > 1; cnt >>= 1) {
     char* out = in + (size_t)cnt * BkPoint<F>::BYTES;
-    for (uint32_t k = threadIdx.x; k < cnt / 2; k += PAIR_TOP_THREADS) {
-      BkPoint<F> a = BkPoint<F>::load(in + (size_t)(2 * k) * BkPoint<F>::BYTES);
-      a.add(BkPoint<F>::load(in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES));
-      a.store(out + (size_t)k * BkPoint<F>::BYTES);
-    }
+    for (uint32_t k = threadIdx.x; k < cnt / 2; k += PAIR_TOP_THREADS)
+      BkPoint<F>::add_mem(in + (size_t)(2 * k) * BkPoint<F>::BYTES, in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES,
+                          out + (size_t)k * BkPoint<F>::BYTES);
     __threadfence_block();
     __syncthreads();
     in = out;
@@ -100,6 +97,20 @@ __global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ ba
   uint32_t chunk = blockIdx.x - plan.first_block[l];
   uint32_t lo = chunk * plan.chunk;
   uint32_t hi = min(plan.count[l], lo + plan.chunk);
+  if constexpr (BkPoint<F>::MEM_ADD) {
+    // G2: the running sum lives in this thread's LDS slot and every addition streams its operands (BkPoint::add_mem)
+    char* my = smem + threadIdx.x * BkPoint<F>::BYTES;
+    BkPoint<F>::inf().store(my);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
+      BkPoint<F>::add_mem(my, base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * BkPoint<F>::BYTES, my);
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) BkPoint<F>::add_mem(my, smem + (threadIdx.x + s) * BkPoint<F>::BYTES, my);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) BkPoint<F>::copy_point(partial + (size_t)blockIdx.x * BkPoint<F>::BYTES, my);
+    return;
+  }
   BkPoint<F> acc = BkPoint<F>::inf();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
     acc.add(BkPoint<F>::load(base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * BkPoint<F>::BYTES));
