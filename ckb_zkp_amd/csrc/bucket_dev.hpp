@@ -110,13 +110,66 @@ struct BkPoint<Fp<P>> {
     if (v.inf) return XYZZ<F>::inf();
     return {v.x.f.to_sat(), v.y.f.to_sat(), v.zz.f.to_sat(), v.zzz.f.to_sat()};
   }
-  static constexpr bool MEM_ADD = false;                   // G1 additions keep both operands in registers (115-120 VGPRs)
+#if defined(ZKP_G1_REG_ADD)
+  static constexpr bool MEM_ADD = false;                   // round-2 form: both operands in registers (115-120 VGPRs + 168 B scratch)
   ZKP_DEV static void dbl_mem(const char* a, char* out) { load(a).dbl().store(out); }
   ZKP_DEV static void add_mem(const char* a, const char* b, char* out) {
     BkPoint pa = load(a);
     pa.add(load(b));
     pa.store(out);
   }
+#else
+  // streamed operands like the G2 form below (see BkPoint<Fp2>::add_mem for the scheme)
+  static constexpr bool MEM_ADD = true;
+  ZKP_DEV static void copy_point(char* out, const char* in) {
+    if (out == in) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) fu_store<P>(out + k * EB, fu_load<P>(in + k * EB));
+  }
+  ZKP_DEV static void dbl_mem(const char* a, char* out) {   // exceptional path only: through the out-of-line doubling (104 VGPRs)
+    BkPoint p = load(a);
+    bk_same_x<F>(p, true);
+    p.store(out);
+  }
+  ZKP_DEV static void add_mem(const char* a, const char* b, char* out) {
+    const UB<P, 2> zz1{fu_load<P>(a + 2 * EB)}, zz2{fu_load<P>(b + 2 * EB)};
+    if (fu_is_zero(zz2.f)) {
+      copy_point(out, a);
+      return;
+    }
+    if (fu_is_zero(zz1.f)) {
+      copy_point(out, b);
+      return;
+    }
+    const UB<P, 8> x1{fu_load<P>(a)};
+    const auto u1 = ub_mul(x1, zz2);
+    const UB<P, 8> x2{fu_load<P>(b)};
+    const auto pd = ub_sub(ub_mul(x2, zz1), u1);           // (0, 4p)
+    const bool same_x = pd.f.template maybe_multiple_of_p<4>() && pd.f.template is_multiple_of_p<4>();
+    if (!same_x) fu_store<P>(out + 2 * EB, ub_mul(zz1, zz2).f);     // zz1 zz2 parked in out.zz
+    __asm__ volatile("" ::: "memory");
+    const UB<P, 2> zzz1{fu_load<P>(a + 3 * EB)}, zzz2{fu_load<P>(b + 3 * EB)};
+    const UB<P, 4> y1{fu_load<P>(a + EB)};
+    const auto s1 = ub_mul(y1, zzz2);
+    const UB<P, 4> y2{fu_load<P>(b + EB)};
+    const auto rd = ub_sub(ub_mul(y2, zzz1), s1);          // (0, 4p)
+    if (same_x) {
+      bk_same_x_mem<F>(a, out, rd.f.template is_multiple_of_p<4>());
+      return;
+    }
+    fu_store<P>(out + 3 * EB, ub_mul(zzz1, zzz2).f);
+    __asm__ volatile("" ::: "memory");
+    const auto pp = ub_sqr(pd);
+    const auto ppp = ub_mul(pd, pp);
+    fu_store<P>(out + 2 * EB, ub_mul(UB<P, 2>{fu_load<P>(out + 2 * EB)}, pp).f);
+    fu_store<P>(out + 3 * EB, ub_mul(UB<P, 2>{fu_load<P>(out + 3 * EB)}, ppp).f);
+    const auto q = ub_mul(u1, pp);
+    const UB<P, 8> x3 = ub_sub_sub2(ub_sqr(rd), ppp, q);   // (0, 8p)
+    fu_store<P>(out, x3.f);
+    const UB<P, 2> y3 = ub_mul_add(rd, ub_sub_lazy(q, x3), s1, ub_neg_lazy(ppp));
+    fu_store<P>(out + EB, y3.f);
+  }
+#endif
   // this += o   (add-2008-s)
   ZKP_DEV void add(const BkPoint& o) {
     if (o.v.inf) return;

@@ -201,6 +201,26 @@ __global__ __launch_bounds__(64) void final_kernel(const char* __restrict__ O, i
   __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int t = threadIdx.x;
+  if constexpr (BkPoint<F>::MEM_ADD) {
+    // G2: the lane's point lives in its LDS slot, additions / doublings stream their operands (bucket_dev.hpp)
+    char* my = smem + t * BkPoint<F>::BYTES;
+    if (t < L) BkPoint<F>::copy_point(my, O + (size_t)t * BkPoint<F>::BYTES);
+    else if (t == L) BkPoint<F>::copy_point(my, root);
+    else BkPoint<F>::inf().store(my);
+    if (t < L && !BkPoint<F>::load(my).is_inf())
+      for (int k = 0; k < t; k++) BkPoint<F>::dbl_mem(my, my);
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+      if (t < s) BkPoint<F>::add_mem(my, smem + (t + s) * BkPoint<F>::BYTES, my);
+      __syncthreads();
+    }
+    if (t == 0) {
+      const XYZZ<F> res = BkPoint<F>::load(my).to_sat();
+      if (out_xyzz) res.store(out_xyzz);
+      if (out_jac) res.store_jacobian(out_jac);
+    }
+    return;
+  }
   BkPoint<F> acc = BkPoint<F>::inf();
   if (t < L) {
     acc = BkPoint<F>::load(O + (size_t)t * BkPoint<F>::BYTES);
