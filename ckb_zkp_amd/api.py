@@ -153,6 +153,37 @@ class Context:
         _lib.check(fn(self.h, c.cid, _ptr(_c64(xyz)), _ptr(xy), _ptr(inf)), "zkp_into_affine")
         return xy, bool(inf[0])
 
+    def decompress_points(self, curve, group: int, data: bytes):
+        """zkp_g1/g2_decompress: ark-serialize compressed points -> ((n, w) affine Montgomery, (n,) identity flags).  Raises
+        ValueError(index) on a malformed point."""
+        c = get_curve(curve)
+        pb = 8 * c.fq_limbs * (1 if group == 1 else 2)
+        assert len(data) % pb == 0
+        n = len(data) // pb
+        w = 2 * c.fq_limbs * (1 if group == 1 else 2)
+        xy = np.zeros((n, w), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        bad = C.c_size_t(0)
+        fn = self.lib.zkp_g1_decompress if group == 1 else self.lib.zkp_g2_decompress
+        rc = fn(self.h, c.cid, _ptr(buf) if n else None, n, _ptr(xy), _ptr(inf), C.byref(bad))
+        if rc == -1 and n:
+            raise ValueError(f"malformed compressed point at index {bad.value}")
+        _lib.check(rc, "zkp_decompress")
+        return xy, inf
+
+    def compress_points(self, curve, group: int, xy: np.ndarray, inf=None) -> bytes:
+        """zkp_g1/g2_compress: affine Montgomery points -> ark-serialize compressed bytes"""
+        c = get_curve(curve)
+        xy = _c64(xy)
+        n = xy.shape[0]
+        pb = 8 * c.fq_limbs * (1 if group == 1 else 2)
+        out = np.zeros(n * pb, dtype=np.uint8)
+        infa = None if inf is None else np.ascontiguousarray(inf, dtype=np.uint8)
+        fn = self.lib.zkp_g1_compress if group == 1 else self.lib.zkp_g2_compress
+        _lib.check(fn(self.h, c.cid, _ptr(xy), None if infa is None else _ptr(infa), n, _ptr(out)), "zkp_compress")
+        return out.tobytes()
+
     def fixed_base_mul(self, curve, group: int, base_xy: np.ndarray, scalars: np.ndarray):
         """k_i * P for canonical scalars (n,4) -> ((n, w) uint64 affine Montgomery, (n,) uint8 identity flags)."""
         c = get_curve(curve)

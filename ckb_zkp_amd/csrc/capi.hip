@@ -412,6 +412,32 @@ int32_t zkp_g2_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz,
   if (!xyz || !xy || !inf) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { point_into_affine(ctx, curve, 2, xyz, xy, inf); });
 }
+static int32_t decompress_any(zkp_ctx* ctx, zkp_curve_t curve, int group, const uint8_t* bytes, size_t n, uint64_t* xy,
+                              uint8_t* inf, size_t* bad) {
+  if (n && (!bytes || !xy || !inf)) return ZKP_ERR_BAD_ARG;
+  size_t st = 0;
+  const int32_t rc = guarded(ctx, [&] { st = points_decompress(ctx, curve, group, bytes, n, xy, inf); });
+  if (rc != ZKP_OK) return rc;
+  if (st) {
+    if (bad) *bad = st - 1;
+    return ZKP_ERR_BAD_ARG;
+  }
+  return ZKP_OK;
+}
+int32_t zkp_g1_decompress(zkp_ctx* ctx, zkp_curve_t curve, const uint8_t* bytes, size_t n, uint64_t* xy, uint8_t* inf, size_t* bad) {
+  return decompress_any(ctx, curve, 1, bytes, n, xy, inf, bad);
+}
+int32_t zkp_g2_decompress(zkp_ctx* ctx, zkp_curve_t curve, const uint8_t* bytes, size_t n, uint64_t* xy, uint8_t* inf, size_t* bad) {
+  return decompress_any(ctx, curve, 2, bytes, n, xy, inf, bad);
+}
+int32_t zkp_g1_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes) {
+  if (n && (!xy || !bytes)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { points_compress(ctx, curve, 1, xy, inf, n, bytes); });
+}
+int32_t zkp_g2_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes) {
+  if (n && (!xy || !bytes)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { points_compress(ctx, curve, 2, xy, inf, n, bytes); });
+}
 int32_t zkp_fixed_base_mul_g1(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* base, const uint64_t* scalars, size_t n,
                               uint64_t* out_xy, uint8_t* out_inf) {
   if (!base || (n && (!scalars || !out_xy || !out_inf))) return ZKP_ERR_BAD_ARG;

@@ -70,6 +70,8 @@ void msm_free_all(zkp_ctx* ctx);
 void bases_drop(zkp_ctx* ctx, uint64_t handle);
 void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, size_t k, uint64_t* out_xyz_host);
 void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, uint64_t* xy_out, uint8_t* inf_out);
+size_t points_decompress(zkp_ctx* ctx, int curve, int group, const uint8_t* bytes, size_t n, uint64_t* xy_out, uint8_t* inf_out);
+void points_compress(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes_out);
 // k Jacobian points a_i (+ b_i where has_b[i]) -> affine, one launch; host in / host out (slot strides: 3 fN / 2 fN words)
 void points_fold_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* a_xyz_host, const uint64_t* b_xyz_host,
                              const uint8_t* has_b, size_t k, uint64_t* xy_out, uint8_t* inf_out);

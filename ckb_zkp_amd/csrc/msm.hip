@@ -1272,6 +1272,48 @@ void points_fold_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t*
   for (size_t i = 0; i < k; i++) inf_out[i] = (uint8_t)hinf[i];
 }
 
+// ark-serialize compressed points (host bytes) -> affine Montgomery points (host), decompressed on the device.  Returns 0, or
+// 1 + the index of the first malformed point.
+size_t points_decompress(zkp_ctx* ctx, int curve, int group, const uint8_t* bytes, size_t n, uint64_t* xy_out, uint8_t* inf_out) {
+  if (n == 0) return 0;
+  const MsmVtbl* vt = msm_vtbl(curve, group);
+  const size_t pb = (size_t)vt->fN * 4 * (group == 2 ? 1 : 1), ab = vt->aff_bytes;     // compressed bytes per point = one coordinate
+  char* buf = reinterpret_cast<char*>(ctx->msm_misc.get(n * pb + n * ab + n + 256 + 64));
+  uint32_t* d_bytes = reinterpret_cast<uint32_t*>(buf);
+  char* d_xy = buf + ((n * pb + 63) & ~(size_t)63);
+  uint8_t* d_inf = reinterpret_cast<uint8_t*>(d_xy + n * ab);
+  uint32_t* d_b = reinterpret_cast<uint32_t*>(buf + ((n * pb + 63) & ~(size_t)63) + n * ab + ((n + 63) & ~(size_t)63));
+  uint32_t* d_status = d_b + 48;
+  hipStream_t st = ctx->cur->stream;
+  const uint32_t none = 0xffffffffu;
+  ZKP_HIP(hipMemcpyAsync(d_bytes, bytes, n * pb, hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipMemcpyAsync(d_status, &none, 4, hipMemcpyHostToDevice, st));
+  vt->decompress(st, d_bytes, n, d_b, d_xy, d_inf, d_status);
+  ZKP_HIP(hipGetLastError());
+  uint32_t status = 0;
+  ZKP_HIP(hipMemcpyAsync(xy_out, d_xy, n * ab, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(inf_out, d_inf, n, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipStreamSynchronize(st));
+  return status == none ? 0 : (size_t)status;
+}
+void points_compress(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes_out) {
+  if (n == 0) return;
+  const MsmVtbl* vt = msm_vtbl(curve, group);
+  const size_t pb = (size_t)vt->fN * 4, ab = vt->aff_bytes;
+  char* buf = reinterpret_cast<char*>(ctx->msm_misc.get(n * pb + n * ab + n + 256));
+  char* d_xy = buf;
+  uint32_t* d_bytes = reinterpret_cast<uint32_t*>(buf + n * ab);
+  uint8_t* d_inf = reinterpret_cast<uint8_t*>(buf + n * ab + n * pb);
+  hipStream_t st = ctx->cur->stream;
+  ZKP_HIP(hipMemcpyAsync(d_xy, xy, n * ab, hipMemcpyHostToDevice, st));
+  if (inf) ZKP_HIP(hipMemcpyAsync(d_inf, inf, n, hipMemcpyHostToDevice, st));
+  vt->compress(st, d_xy, inf ? d_inf : nullptr, n, d_bytes);
+  ZKP_HIP(hipGetLastError());
+  ZKP_HIP(hipMemcpyAsync(bytes_out, d_bytes, n * pb, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipStreamSynchronize(st));
+}
+
 void fixed_base_mul(zkp_ctx* ctx, int curve, int group, const uint64_t* base_xy, const uint64_t* scalars, size_t n,
                     uint64_t* out_xy, uint8_t* out_inf) {
   if (n == 0) return;

@@ -371,6 +371,173 @@ __global__ void from_jacobian_kernel(const uint32_t* jac, char* out) {
   jac_to_xyzz<F>(jac).store(out);
 }
 
+// ------------------------------------------------------------------------------------------- ark-serialize point codec
+// Compressed short-Weierstrass points of ark-serialize 0.2 (`Parameters::serialize` as cli/src/setup.rs:41-45 writes it,
+// `Proof::serialize` of cli/src/zkp_prove.rs:45-49): the canonical little-endian x (Fq2: c0 then c1) with two flags in the top
+// bits of the LAST byte — bit 7: y is the larger of {y, -y} (Fq: as integers; Fq2: c1 first, then c0), bit 6: the identity.
+// The same layout ckb_zkp_amd/serialize.py restates (parity unpinned: the reference holds no serialized fixture).
+// Decompression of a multi-million-point key is a square root per point: one lane per point.
+template <class P>
+__device__ __forceinline__ bool fp_sqrt(const Fp<P>& a, Fp<P>& out) {  // p = 3 (mod 4) for both base fields: a^((p + 1) / 4)
+  constexpr int N = P::N;
+  uint32_t e[N];
+  uint64_t c = 1;
+#pragma unroll
+  for (int i = 0; i < N; i++) {                                         // p + 1
+    c += (uint64_t)P::MOD[i];
+    e[i] = (uint32_t)c;
+    c >>= 32;
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) e[i] = (e[i] >> 2) | (i + 1 < N ? e[i + 1] << 30 : 0);
+  out = a.pow_limbs(e);
+  return out.sqr() == a;
+}
+template <class P>
+__device__ __forceinline__ bool fp_gt(const Fp<P>& a, const Fp<P>& b) {   // canonical integers, a > b
+  for (int i = P::N - 1; i >= 0; i--)
+    if (a.v[i] != b.v[i]) return a.v[i] > b.v[i];
+  return false;
+}
+template <class P>
+__device__ __forceinline__ bool fp_canonical_lt_mod(const Fp<P>& a) {  // a (plain words) < p
+  for (int i = P::N - 1; i >= 0; i--)
+    if (a.v[i] != P::MOD[i]) return a.v[i] < P::MOD[i];
+  return false;
+}
+// y "positive" = y > -y in ark's ordering
+template <class P>
+__device__ __forceinline__ bool y_positive(const Fp<P>& y) { return fp_gt(y.from_mont(), y.neg().from_mont()); }
+template <class P>
+__device__ __forceinline__ bool y_positive(const Fp2<P>& y) {
+  const Fp<P> a1 = y.c1.from_mont(), n1 = y.c1.neg().from_mont();
+  if (!(a1 == n1)) return fp_gt(a1, n1);
+  return fp_gt(y.c0.from_mont(), y.c0.neg().from_mont());
+}
+template <class P>
+__device__ __forceinline__ bool curve_sqrt(const Fp<P>& a, Fp<P>& out) { return fp_sqrt(a, out); }
+template <class P>
+__device__ __forceinline__ bool curve_sqrt(const Fp2<P>& a, Fp2<P>& out) {   // norm method, as serialize.py _sqrt_fq2
+  using B = Fp<P>;
+  if (a.c1.is_zero()) {
+    B s;
+    if (fp_sqrt(a.c0, s)) {
+      out = {s, B::zero()};
+      return true;
+    }
+    if (fp_sqrt(a.c0.neg(), s)) {
+      out = {B::zero(), s};
+      return true;
+    }
+    return false;
+  }
+  B n;
+  if (!fp_sqrt(a.c0.sqr() + a.c1.sqr(), n)) return false;
+  const B inv2 = (B::one() + B::one()).inv();
+  for (int sign = 0; sign < 2; sign++) {
+    const B x2 = (sign == 0 ? a.c0 + n : a.c0 - n) * inv2;
+    B x;
+    if (fp_sqrt(x2, x) && !x.is_zero()) {
+      const B y = a.c1 * (x + x).inv();
+      const Fp2<P> r{x, y};
+      if (r.sqr() == a) {
+        out = r;
+        return true;
+      }
+    }
+  }
+  return false;
+}
+template <class P>
+__device__ __forceinline__ bool coords_canonical(const Fp<P>& x) { return fp_canonical_lt_mod(x); }
+template <class P>
+__device__ __forceinline__ bool coords_canonical(const Fp2<P>& x) { return fp_canonical_lt_mod(x.c0) && fp_canonical_lt_mod(x.c1); }
+template <class P>
+__device__ __forceinline__ Fp<P> coords_to_mont(const Fp<P>& x) { return x.to_mont(); }
+template <class P>
+__device__ __forceinline__ Fp2<P> coords_to_mont(const Fp2<P>& x) { return {x.c0.to_mont(), x.c1.to_mont()}; }
+template <class P>
+__device__ __forceinline__ Fp<P> coords_from_mont(const Fp<P>& x) { return x.from_mont(); }
+template <class P>
+__device__ __forceinline__ Fp2<P> coords_from_mont(const Fp2<P>& x) { return {x.c0.from_mont(), x.c1.from_mont()}; }
+
+// the curve's b in Montgomery form: G1 3 / 4 (BN254 / BLS12-381), G2 twist 3 / (9 + u) = (27 - 3u) / 82 and 4 (1 + u)
+template <class F>
+__global__ void curve_b_kernel(uint32_t* out) {
+  if (threadIdx.x || blockIdx.x) return;
+  using B = Fp<CfgFq>;
+  auto small = [](uint32_t k) {
+    B x = B::zero();
+    x.v[0] = k;
+    return x.to_mont();
+  };
+#if ZKP_CFG_GROUP == 1
+  small(ZKP_CFG_CURVE == 0 ? 3 : 4).store(out);
+#else
+  if (ZKP_CFG_CURVE == 0) {
+    const B i82 = small(82).inv();
+    (small(27) * i82).store(out);
+    (small(3) * i82).neg().store(out + B::N);
+  } else {
+    small(4).store(out);
+    small(4).store(out + B::N);
+  }
+#endif
+}
+
+// bytes: n points of 4 * F::N bytes each -> xy (affine Montgomery, identity = (0, 0)), inf flags; status[0] = 1 + index of the first
+// malformed point (flags, x >= p, no square root), 0 if none
+template <class F>
+__global__ __launch_bounds__(64) void decompress_kernel(const uint32_t* __restrict__ bytes, size_t n, const uint32_t* __restrict__ bcoef,
+                                                        char* __restrict__ xy, uint8_t* __restrict__ inf, uint32_t* __restrict__ status) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  F x = F::load(bytes + i * F::N);
+  uint32_t* top = reinterpret_cast<uint32_t*>(&x) + (F::N - 1);
+  const uint32_t flags = *top >> 30;                                     // bit 1: positive y, bit 0: infinity
+  *top &= 0x3fffffffu;
+  auto fail = [&] { atomicMin(status, (uint32_t)(i + 1)); };
+  if (flags == 3) {
+    fail();
+    return;
+  }
+  if (flags & 1) {
+    Affine<F>::inf().store(xy + i * Affine<F>::BYTES);
+    inf[i] = 1;
+    return;
+  }
+  if (!coords_canonical(x)) {
+    fail();
+    return;
+  }
+  const F xm = coords_to_mont(x);
+  const F rhs = xm.sqr() * xm + F::load(bcoef);
+  F y;
+  if (!curve_sqrt(rhs, y)) {
+    fail();
+    return;
+  }
+  if (y_positive(y) != (bool)(flags >> 1)) y = y.neg();
+  Affine<F>{xm, y}.store(xy + i * Affine<F>::BYTES);
+  inf[i] = 0;
+}
+template <class F>
+__global__ __launch_bounds__(64) void compress_kernel(const char* __restrict__ xy, const uint8_t* __restrict__ inf, size_t n,
+                                                      uint32_t* __restrict__ bytes) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Affine<F> p = Affine<F>::load(xy + i * Affine<F>::BYTES);
+  F x = F::zero();
+  uint32_t flags = 1;                                                    // identity: x = 0 + the infinity flag
+  if (!(inf && inf[i]) && !p.is_inf()) {
+    x = coords_from_mont(p.x);
+    flags = y_positive(p.y) ? 2u : 0u;
+  }
+  uint32_t* top = reinterpret_cast<uint32_t*>(&x) + (F::N - 1);
+  *top |= flags << 30;
+  x.store(bytes + i * F::N);
+}
+
 // k_i * P, one lane per scalar (setup-side helper; double-and-add, MSB first)
 template <class F, int BITS>
 __global__ __launch_bounds__(128) void fixed_base_kernel(const uint32_t* base, const uint32_t* scalars, size_t n,
@@ -642,6 +809,13 @@ void l_fold_affine_batch(hipStream_t s, const uint32_t* ja, const uint32_t* jb, 
                          uint32_t* inf) {
   if (k > 0) hipLaunchKernelGGL(fold_affine_batch_kernel<F>, dim3((k + 63) / 64), dim3(64), 0, s, ja, jb, has_b, k, xy, inf);
 }
+void l_decompress(hipStream_t s, const uint32_t* bytes, size_t n, const uint32_t* bcoef, char* xy, uint8_t* inf, uint32_t* status) {
+  hipLaunchKernelGGL(curve_b_kernel<F>, dim3(1), dim3(64), 0, s, const_cast<uint32_t*>(bcoef));   // bcoef: F::N words of scratch
+  if (n) hipLaunchKernelGGL(decompress_kernel<F>, dim3((n + 63) / 64), dim3(64), 0, s, bytes, n, bcoef, xy, inf, status);
+}
+void l_compress(hipStream_t s, const char* xy, const uint8_t* inf, size_t n, uint32_t* bytes) {
+  if (n) hipLaunchKernelGGL(compress_kernel<F>, dim3((n + 63) / 64), dim3(64), 0, s, xy, inf, n, bytes);
+}
 void l_from_jacobian(hipStream_t s, const uint32_t* jac, char* out) {
   hipLaunchKernelGGL(from_jacobian_kernel<F>, dim3(1), dim3(64), 0, s, jac, out);
 }
@@ -669,7 +843,7 @@ const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
   static const MsmVtbl v = {
       F::N, Affine<F>::BYTES, XYZZ<F>::BYTES, BkPoint<F>::BYTES, CFG_BITS,
       l_ingest, l_precompute, ZKP_CFG_SYM(msm_accumulate_launch), l_combine, l_pair, l_segsum, l_final, l_identity, l_fold,
-      l_into_affine, l_fold_affine_batch, l_from_jacobian, l_fixed_base, l_segsum_desc, l_final_var, l_fold_slots,
+      l_into_affine, l_fold_affine_batch, l_decompress, l_compress, l_from_jacobian, l_fixed_base, l_segsum_desc, l_final_var, l_fold_slots,
 #if ZKP_CFG_GROUP == 1
       l_assemble_g1_p1, l_assemble_g1_p2, nullptr,
 #else

@@ -56,6 +56,9 @@ struct MsmVtbl {
   // commitments of a Marlin round share ONE launch instead of k single-lane inversions (0.3 ms each) one after the other
   void (*fold_affine_batch)(hipStream_t, const uint32_t* jac_a, const uint32_t* jac_b, const uint32_t* has_b, int k,
                             uint32_t* xy, uint32_t* inf);
+  // ark-serialize compressed points <-> affine Montgomery, one lane per point (msm_group.hip "point codec"); bcoef = the curve's b
+  void (*decompress)(hipStream_t, const uint32_t* bytes, size_t n, const uint32_t* bcoef, char* xy, uint8_t* inf, uint32_t* status);
+  void (*compress)(hipStream_t, const char* xy, const uint8_t* inf, size_t n, uint32_t* bytes);
   void (*from_jacobian)(hipStream_t, const uint32_t* jac, char* out_xyzz);
   void (*fixed_base)(hipStream_t, const uint32_t* base, const uint32_t* scalars, size_t n, char* out_xy,
                      uint8_t* out_inf);

@@ -480,3 +480,64 @@ def marlin_proof_from_bytes(b: bytes, curve, checked: bool = True):
     if r.o != len(b):
         raise SerializationError("InvalidData")
     return commitments, evaluations, proofs
+
+
+# ------------------------------------------------------------------ bulk codecs over the C ABI (device decompression)
+# `Parameters::serialize` / `deserialize_unchecked` of a multi-million-point key without a Python big-integer per point: the
+# container framing is parsed here, the point vectors go through zkp_g1/g2_compress / zkp_g1/g2_decompress (one lane per point
+# on the GPU: a square root each).  Same bytes as parameters_to_bytes / parameters_from_bytes above (tests/test_gpu_codec.py).
+def parameters_to_bytes_abi(ctx, params) -> bytes:
+    """groth16.Parameters (ABI arrays) -> the bytes of `Parameters::serialize` (cli/src/setup.rs:41-45)"""
+    import numpy as np
+    c = params.curve
+    one1 = lambda xy: ctx.compress_points(c, 1, np.ascontiguousarray(xy).reshape(1, -1))
+    one2 = lambda xy: ctx.compress_points(c, 2, np.ascontiguousarray(xy).reshape(1, -1))
+    vec = lambda g, q: struct.pack("<Q", q[0].shape[0]) + ctx.compress_points(c, g, q[0], q[1])
+    return (one1(params.alpha_g1) + one2(params.beta_g2) + one2(params.gamma_g2) + one2(params.delta_g2) + vec(1, params.gamma_abc_g1) +
+            one1(params.beta_g1) + one1(params.delta_g1) + vec(1, params.a_query) + vec(1, params.b_g1_query) +
+            vec(2, params.b_g2_query) + vec(1, params.h_query) + vec(1, params.l_query))
+
+
+def parameters_from_bytes_abi(ctx, b: bytes, curve, num_constraints: int):
+    """`Parameters::deserialize_unchecked` -> groth16.Parameters (ABI arrays), points decompressed on the device.
+    num_constraints is not part of the file (the reference re-synthesises the circuit): the caller supplies it."""
+    from .groth16 import Parameters
+    c = get_curve(curve)
+    n = _fq_bytes(c)
+    r = _Reader(b)
+
+    def pts(group, count):
+        try:
+            return ctx.decompress_points(c, group, r.take(count * n * group))
+        except ValueError as e:
+            raise SerializationError(f"InvalidData ({e})")
+
+    def single(group):
+        xy, inf = pts(group, 1)
+        if inf[0]:
+            raise SerializationError("InvalidData (identity in a key element)")
+        return xy[0]
+
+    alpha_g1, beta_g2, gamma_g2, delta_g2 = single(1), single(2), single(2), single(2)
+    gamma_abc = pts(1, r.u64())
+    beta_g1, delta_g1 = single(1), single(1)
+    a_q = pts(1, r.u64())
+    b1_q = pts(1, r.u64())
+    b2_q = pts(2, r.u64())
+    h_q = pts(1, r.u64())
+    l_q = pts(1, r.u64())
+    if r.o != len(b):
+        raise SerializationError("InvalidData")
+    return Parameters(curve=c, num_inputs=gamma_abc[0].shape[0], num_aux=l_q[0].shape[0], num_constraints=num_constraints,
+                      alpha_g1=alpha_g1, beta_g1=beta_g1, delta_g1=delta_g1, beta_g2=beta_g2, gamma_g2=gamma_g2, delta_g2=delta_g2,
+                      gamma_abc_g1=gamma_abc, a_query=a_q, b_g1_query=b1_q, b_g2_query=b2_q, h_query=h_q, l_query=l_q)
+
+
+def proof_to_bytes_abi(ctx, curve, proof_limbs, inf) -> bytes:
+    """the 3 affine Montgomery points zkp_groth16_prove returns (A | B | C) -> `Proof::serialize` bytes (cli/src/zkp_prove.rs:45-49)"""
+    import numpy as np
+    c = get_curve(curve)
+    w = 2 * c.fq_limbs
+    p = np.ascontiguousarray(proof_limbs, dtype=np.uint64).reshape(-1)
+    return (ctx.compress_points(c, 1, p[:w].reshape(1, -1), [inf[0]]) + ctx.compress_points(c, 2, p[w:3 * w].reshape(1, -1), [inf[1]]) +
+            ctx.compress_points(c, 1, p[3 * w:4 * w].reshape(1, -1), [inf[2]]))

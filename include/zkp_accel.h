@@ -164,6 +164,21 @@ int32_t zkp_g1_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_
                            uint8_t* inf_out);
 int32_t zkp_g2_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_host, uint64_t* xy_out,
                            uint8_t* inf_out);
+/* ark-serialize 0.2 COMPRESSED short-Weierstrass points <-> the affine Montgomery arrays of zkp_groth16_pk_desc /
+ * zkp_bases_upload_*: what `Parameters::serialize` writes into a .pk file (cli/src/setup.rs:41-45) and `Proof::serialize` into
+ * a proof (cli/src/zkp_prove.rs:45-49).  A point is its canonical little-endian x (G2: c0 then c1; 32 / 64 bytes on BN254,
+ * 48 / 96 on BLS12-381) with two flags in the top bits of the last byte: bit 7 = y is the larger of {y, -y} (Fq: as integers;
+ * Fq2: c1 first, then c0), bit 6 = the identity.  Decompression (a square root per point) runs on the device, one lane per point:
+ * a 2^20 key loads in tens of milliseconds.  On a malformed point (both flags, x >= p, x^3 + b not a square) the call returns
+ * ZKP_ERR_BAD_ARG and *bad_index (if not NULL) receives its index.  No subgroup check (= ark's `deserialize_unchecked` for the
+ * cofactor groups; BN254 G1 has cofactor 1).  The container framing (Vec length prefixes, field order of `Parameters`) stays with
+ * the caller: ckb_zkp_amd/serialize.py, rust/zkp-accel. */
+int32_t zkp_g1_decompress(zkp_ctx* ctx, zkp_curve_t curve, const uint8_t* bytes, size_t n, uint64_t* xy_out, uint8_t* inf_out,
+                          size_t* bad_index);
+int32_t zkp_g2_decompress(zkp_ctx* ctx, zkp_curve_t curve, const uint8_t* bytes, size_t n, uint64_t* xy_out, uint8_t* inf_out,
+                          size_t* bad_index);
+int32_t zkp_g1_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes_out);
+int32_t zkp_g2_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes_out);
 
 /* ---- fixed-base multiples k_i * P (setup side, generator.rs:205-256 `FixedBaseMSM`).
  * Used to build synthetic proving keys from a known trapdoor at 2^20+ scale.  scalars canonical. */

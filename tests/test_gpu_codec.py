@@ -1,0 +1,102 @@
+"""ark-serialize point codec behind the C ABI (zkp_g1/g2_compress / _decompress, csrc/msm_group.hip "point codec") against the
+Python restatement of the same layout (ckb_zkp_amd/serialize.py; both restate ark-serialize 0.2 — the reference holds no
+serialized fixture, so byte parity with a real .pk stays unpinned) and through a full Parameters round trip:
+key -> `Parameters::serialize` bytes -> device decompression -> proving key -> the same proof."""
+import random
+
+import numpy as np
+import pytest
+
+from ckb_zkp_amd import codec, groth16, serialize
+from ckb_zkp_amd.circuits import mimc_chain_instance
+from ckb_zkp_amd.params import get_curve
+from tests.util import OC
+
+TOXIC = dict(alpha=0x1234567890ABCDEF1, beta=0xFEDCBA09876543211, gamma=0x1111111111111111111, delta=0x2222222222222222223, tau=0x3333333333333333335)
+
+pytestmark = pytest.mark.gpu
+
+
+def _points(curve, group, n, seed):
+    from oracle.pyref.curves import Group
+    G = Group(OC[curve], group)
+    rnd = random.Random(seed)
+    pts = [G.mul(G.gen, rnd.randrange(1, G.order)) for _ in range(n)]
+    pts[n // 2] = None                                           # the identity
+    return pts
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("group", [1, 2])
+def test_compress_decompress_match_python_restatement(ctx, curve, group):
+    c = get_curve(curve)
+    pts = _points(curve, group, 40, 11 * group + len(curve))
+    to_b = serialize.g1_to_bytes if group == 1 else serialize.g2_to_bytes
+    to_m = codec.g1_to_mont if group == 1 else codec.g2_to_mont
+    want = b"".join(to_b(p, c) for p in pts)
+    xy, inf = to_m(pts, c)
+    assert ctx.compress_points(c, group, xy, inf) == want
+    xy2, inf2 = ctx.decompress_points(c, group, want)
+    assert np.array_equal(xy2, xy) and list(inf2) == list(inf)
+    # also the negated points (the other y flag)
+    from oracle.pyref.curves import Group
+    G = Group(OC[curve], group)
+    neg = [G.neg(p) for p in pts]
+    want_n = b"".join(to_b(p, c) for p in neg)
+    xy_n, inf_n = to_m(neg, c)
+    assert ctx.compress_points(c, group, xy_n, inf_n) == want_n
+    assert np.array_equal(ctx.decompress_points(c, group, want_n)[0], xy_n)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_malformed_points_are_rejected_with_their_index(ctx, curve):
+    c = get_curve(curve)
+    n = 8 * c.fq_limbs
+    good = serialize.g1_to_bytes(_points(curve, 1, 3, 5)[0], c)
+    # (a) both flags set, (b) x >= p, (c) x^3 + b is not a square
+    both = bytearray(good)
+    both[-1] |= 0xC0
+    big = bytearray((c.q + 1).to_bytes(n, "little"))
+    x = 1
+    while pow((x * x * x + (3 if curve == "bn254" else 4)) % c.q, (c.q - 1) // 2, c.q) == 1:
+        x += 1
+    nonres = x.to_bytes(n, "little")
+    for k, bad in enumerate((bytes(both), bytes(big), nonres)):
+        data = good * (k + 1) + bad + good
+        with pytest.raises(ValueError) as e:
+            ctx.decompress_points(c, 1, data)
+        assert f"index {k + 1}" in str(e.value)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_parameters_bytes_roundtrip_proves_the_same(ctx, curve):
+    c = get_curve(curve)
+    inst = mimc_chain_instance(curve, 40)
+    params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    blob = serialize.parameters_to_bytes_abi(ctx, params)
+    # the Python restatement reads the same bytes to the same points
+    ref = serialize.parameters_from_bytes(blob, c, checked=False)
+    assert ref["a_query"] == codec.g1_from_mont(params.a_query[0], params.a_query[1], c)
+    assert ref["b_g2_query"] == codec.g2_from_mont(params.b_g2_query[0], params.b_g2_query[1], c)
+    assert ref["vk"]["gamma_abc_g1"] == codec.g1_from_mont(params.gamma_abc_g1[0], params.gamma_abc_g1[1], c)
+    assert serialize.parameters_to_bytes(ref, c) == blob
+    loaded = serialize.parameters_from_bytes_abi(ctx, blob, curve, inst.num_constraints())
+    for name in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query", "gamma_abc_g1"):
+        a, b = getattr(params, name), getattr(loaded, name)
+        assert np.array_equal(a[0], b[0]) and list(a[1]) == list(b[1]), name
+    for name in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "gamma_g2", "delta_g2"):
+        assert np.array_equal(getattr(params, name), getattr(loaded, name)), name
+    z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+    r, s = codec.fr_to_mont([0x1234567], c)[0], codec.fr_to_mont([0x7654321], c)[0]
+    pk1, pk2 = groth16.ProvingKey(ctx, params, inst), groth16.ProvingKey(ctx, loaded, inst)
+    p1, i1 = pk1.prove_raw(z, r, s)
+    p2, i2 = pk2.prove_raw(z, r, s)
+    assert np.array_equal(p1, p2) and list(i1) == list(i2)
+    # Proof::serialize: ABI path == Python restatement of the same proof
+    w = 2 * c.fq_limbs
+    pa = codec.g1_from_mont(p1[:w].reshape(1, -1), [i1[0]], c)[0]
+    pb = codec.g2_from_mont(p1[w:3 * w].reshape(1, -1), [i1[1]], c)[0]
+    pc = codec.g1_from_mont(p1[3 * w:].reshape(1, -1), [i1[2]], c)[0]
+    assert serialize.proof_to_bytes_abi(ctx, curve, p1, i1) == serialize.proof_to_bytes(groth16.Proof(pa, pb, pc), c)
+    pk1.free()
+    pk2.free()
