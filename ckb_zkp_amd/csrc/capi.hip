@@ -81,6 +81,7 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
         ZKP_HIP(hipEventCreateWithFlags(&L.ws[i].done, hipEventDisableTiming));
         ZKP_HIP(hipEventCreateWithFlags(&L.ws[i].sorted, hipEventDisableTiming));
         ZKP_HIP(hipEventCreateWithFlags(&L.ws[i].l1_done, hipEventDisableTiming));
+        ZKP_HIP(hipEventCreateWithFlags(&L.ws[i].acc_done, hipEventDisableTiming));
         if (i > 0) {
           ZKP_HIP(hipStreamCreateWithFlags(&L.ws[i].stream, hipStreamNonBlocking));
           L.ws[i].own_stream = true;
@@ -163,6 +164,7 @@ int32_t zkp_ctx_destroy(zkp_ctx* ctx) {
       if (L.ws[i].done) (void)hipEventDestroy(L.ws[i].done);
       if (L.ws[i].sorted) (void)hipEventDestroy(L.ws[i].sorted);
       if (L.ws[i].l1_done) (void)hipEventDestroy(L.ws[i].l1_done);
+      if (L.ws[i].acc_done) (void)hipEventDestroy(L.ws[i].acc_done);
       if (L.ws[i].own_stream && L.ws[i].stream) (void)hipStreamDestroy(L.ws[i].stream);
     }
     if (L.own_stream && L.stream) (void)hipStreamDestroy(L.stream);

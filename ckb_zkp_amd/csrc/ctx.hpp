@@ -96,6 +96,9 @@ struct MsmWorkspace {
   hipEvent_t done = nullptr;
   hipEvent_t sorted = nullptr;     // recorded when the bucket sort + task schedule of the current MSM are complete
   hipEvent_t l1_done = nullptr;    // recorded when the level-1 pass (entries scattered into bins) of the current MSM is complete
+  uint32_t chain_nb = 0;           // != 0: `buckets` holds the complete, unreduced buckets (chain_nb of them, chain_xb bytes each) of a deferred MSM
+  size_t chain_xb = 0;
+  hipEvent_t acc_done = nullptr;   // recorded when the buckets of an MSM whose reduction was deferred are complete (msm_defer_reduce)
   DevBuf keys, vals, keys2, vals2, sort_tmp, offsets, buckets, tmp, out, sched, scan_tmp, scan_tmp2, partial, redo;
 };
 struct Groth16Timing {
@@ -130,6 +133,11 @@ struct zkp_ctx {
   hipEvent_t ev2 = nullptr, ev3 = nullptr;   // internal per-kernel timing
   bool profiling = false;
   size_t table_bytes = 0;      // resident window tables of this context (ZKP_TABLE_BUDGET_GB accounting)
+  // Bucket chaining (round 3): two MSMs whose results are only ever ADDED (Groth16: L and H, C = ... + l' + h_acc) share ONE bucket array
+  // and ONE reduction.  msm_defer_reduce: the next MSM stops after its buckets are complete (output = the identity); msm_acc_into >= 0:
+  // the next MSM accumulates on top of the buckets workspace `msm_acc_into` holds and reduces the sum.  Both reset by msm_run.
+  bool msm_defer_reduce = false;
+  int msm_acc_into = -1;
   bool dbg_skip_k8 = false;    // ABLATION ONLY (ZKP_DEBUG_SKIP_K8_MASK): the next MSM skips its bucket reduction — wrong results, timing experiments
   bool batch_mode = false;     // inside zkp_groth16_prove_batch*: kernels are tuned for throughput of many proofs in flight, not latency
   std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)

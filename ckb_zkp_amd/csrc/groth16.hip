@@ -51,6 +51,7 @@ struct zkp_groth16_pk {
   DevCsr m[3];
   uint64_t hA = 0, hB1 = 0, hB2 = 0, hH = 0, hL = 0;
   bool share_b_sort = false;     // b_g1_query / b_g2_query: same length, window configuration and identity pattern
+  bool chain_lh = false;         // H accumulates into L's buckets: one bucket reduction for l' + h_acc (bucket chaining, ctx.hpp)
   bool share_al_sort = false;    // L (stored index-aligned with z) reuses A's bucket sort: same scalars, same identity pattern
   bool share_l1 = false;         // A, L and (b_in_l1) B2 (+B1) share ONE level-1 sort pass over z (each filters its identities at level 2)
   bool b_in_l1 = false;          // the B queries have A's window configuration and take part in the shared pass
@@ -333,6 +334,15 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
         pk->share_l1 = true;
         pk->b_in_l1 = with_b;
       }
+      {
+        // C only ever needs l' + h_acc (prover.rs:189-196): with equal bucket ranges and no window groups H's accumulate kernel
+        // continues from L's finished buckets and ONE reduction yields the sum; L's own result is the identity (ZKP_CHAIN_LH=0: off)
+        static const bool on_chain = !(getenv("ZKP_CHAIN_LH") && atoi(getenv("ZKP_CHAIN_LH")) == 0);
+        uint64_t iL[5], iH[5];
+        bases_info(ctx, pk->hL, iL);
+        bases_info(ctx, pk->hH, iH);
+        pk->chain_lh = on_chain && iL[0] == iH[0] && iL[2] == 1 && iH[2] == 1 && pk->q_n[3] > 0 && pk->q_n[4] > 0;
+      }
       if (getenv("ZKP_DEBUG_MSM"))
         fprintf(stderr, "[groth16] A/L sort sharing: %d (flags differ at %zu of %zu bases), B1/B2: %d, shared level 1: %d\n",
                 (int)pk->share_al_sort, differ, fA.size(), (int)pk->share_b_sort, (int)pk->share_l1);
@@ -490,7 +500,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   const size_t slot = v2->xyzz_bytes;                  // uniform slot size
   char* res = reinterpret_cast<char*>(PL.results.get(6 * slot));
   const uint64_t* Sd = reinterpret_cast<const uint64_t*>(S);
-  bool l_done_in_fan = false, g2_done_in_fan = false;
+  bool l_done_in_fan = false, g2_done_in_fan = false, chained = false;
   float acc_ms = 0.f, scan_ms = 0.f;
   uint64_t ent = 0, scan_bytes = 0, scan_runs = 0;
   // Schedule.  profiling: everything on the main stream, one MSM at a time, with per-phase events.
@@ -551,6 +561,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
         g2_done_in_fan = true;
       }
       run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 3, pk->share_b_sort ? 2 : -1);
+      ctx->msm_defer_reduce = chained = pk->chain_lh;
       run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 1, pk->share_al_sort ? 1 : -1, l1);   // A's sort / level-1 pass, still in this workspace
       if (!partial_out) {
         ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_a, 0));
@@ -582,6 +593,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     run(1, pk->hB1, Sd + 4 * pk->q_lo[1], pk->q_n[1], 0);
     run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 0);
   }
+  if (chained) ctx->msm_acc_into = 1;                 // on top of L's buckets (workspace 1): result slot 3 = h_acc + l', slot 4 = identity
   run(3, pk->hH, reinterpret_cast<const uint64_t*>(h) + 4 * pk->q_lo[3], pk->q_n[3], 0);  // :186-187 (min(len) truncation in q_n)
   if (!(fan && l_done_in_fan)) run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 0);                                 // :189-190
   if (fan) {

@@ -864,6 +864,12 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
                           uint64_t* n_entries, int ws_idx, int sort_src, float* ms_scan, int l1_src) {
   const MsmVtbl* vt = be->vt;
   MsmWorkspace& ws = ctx->cur->ws[ws_idx];
+  // bucket chaining (ctx.hpp): one-shot requests, consumed by this MSM
+  const bool defer = ctx->msm_defer_reduce;
+  const int into = ctx->msm_acc_into;
+  ctx->msm_defer_reduce = false;
+  ctx->msm_acc_into = -1;
+  ZKP_REQUIRE(!(defer || into >= 0) || (n > 0 && !be->var && !(defer && into >= 0)), ZKP_ERR_BAD_ARG);
   // sort_src: workspace whose sorted entries + task schedule this MSM reuses (same scalars, window configuration and identity
   // pattern); sort_src == ws_idx = the MSM that ran on this workspace just before (A -> L on one stream)
   const bool reuse = sort_src >= 0;
@@ -994,15 +1000,23 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     }
     // level l of the reduction pyramid lives at element offset lvl_off[l] of `buckets` (level 0 = buckets);
     // all-zero bytes are a valid identity (zz == 0), so empty buckets need no kernel
-    char* buckets = reinterpret_cast<char*>(ws.buckets.get((size_t)2 * nb * XB + XB));
+    // (into >= 0: the bucket array of workspace `into`, which holds the finished buckets of an MSM over the same bucket range;
+    //  its accumulate + combine must be complete before this one's start)
+    MsmWorkspace& bws = into >= 0 ? ctx->cur->ws[into] : ws;
+    char* buckets = reinterpret_cast<char*>(bws.buckets.get((size_t)2 * nb * XB + XB));
     char* task_partial = reinterpret_cast<char*>(ws.partial.get((size_t)max_tasks * XB));
     static const bool zero_all = getenv("ZKP_MEMSET_BUCKETS") && atoi(getenv("ZKP_MEMSET_BUCKETS")) != 0;   // A/B: round-2 behaviour
-    if (zero_all) ZKP_HIP(hipMemsetAsync(buckets, 0, (size_t)nb * XB, st));
+    const uint32_t init = into >= 0 ? 1u : 0u;
+    if (init) {
+      ZKP_REQUIRE(bws.chain_nb == nb && bws.chain_xb == XB, ZKP_ERR_BAD_ARG);
+      if (into != ws_idx) ZKP_HIP(hipStreamWaitEvent(st, bws.acc_done, 0));
+    } else if (zero_all) ZKP_HIP(hipMemsetAsync(buckets, 0, (size_t)nb * XB, st));
     else hipLaunchKernelGGL(zero_empty_buckets_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, start, end, nb, buckets, (uint32_t)XB);
+    bws.chain_nb = 0;
     const bool timed = ms_accumulate && ctx->profiling;
     if (timed) ZKP_HIP(hipEventRecord(ctx->ev2, st));
     vt->accumulate(st, be->table, sorted_vals, desc, toff + nb, max_tasks, buckets, task_partial,
-                   ws.redo.as<uint32_t>((size_t)max_tasks + 1));
+                   ws.redo.as<uint32_t>((size_t)max_tasks + 1), init);
     if (timed) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
       ZKP_HIP(hipEventSynchronize(ctx->ev3));
@@ -1021,7 +1035,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
              be->group, n, nb, max_tasks, h[0], h[1], h[2], h[3], h[4], h[5]);
       fflush(stdout);
     }
-    if (dbg != 2) vt->combine(st, long_list, tmeta + TM_NLONG, toff, task_partial, buckets);
+    if (dbg != 2) vt->combine(st, long_list, tmeta + TM_NLONG, toff, task_partial, buckets, init);
     if (dbg) {
       hipError_t e = hipStreamSynchronize(st);
       printf("[msm] combine: %s\n", hipGetErrorString(e));
@@ -1057,6 +1071,17 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
         ZKP_HIP(hipMemcpyAsync(out_xyz_host, out_jac, jac_words * 4, hipMemcpyDeviceToHost, st));
         ZKP_HIP(hipStreamSynchronize(st));
       }
+      return;
+    }
+    if (defer) {
+      // the buckets stay as they are for the MSM that reduces them together with its own (msm_acc_into); this one contributes
+      // the identity to whatever sums the results
+      ws.chain_nb = nb;
+      ws.chain_xb = XB;
+      ZKP_HIP(hipEventRecord(ws.acc_done, st));
+      vt->write_identity(st, (char*)out_dev_xyzz, out_jac);
+      ZKP_HIP(hipGetLastError());
+      ZKP_REQUIRE(!out_xyz_host, ZKP_ERR_BAD_ARG);
       return;
     }
     if (ctx->dbg_skip_k8) return;                  // ablation experiments only (wrong result)

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
                                                          const uint4* __restrict__ desc,
                                                          const uint32_t* __restrict__ n_tasks_dev,
                                                          char* __restrict__ buckets, char* __restrict__ partial, uint32_t idx_mask,
-                                                         uint32_t* __restrict__ redo) {
+                                                         uint32_t* __restrict__ redo, uint32_t init) {
   using F = CfgF;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *n_tasks_dev) return;
@@ -83,6 +83,10 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   // G1: accumulate on unsaturated limbs (unsat_dev.hpp); the window table and the buckets keep the saturated layout
   XYZZu<CfgFq> acc;
   acc.inf = true;
+  if (init && !(d >> 31)) {                             // bucket chaining: continue from the bucket another MSM left here
+    const BkPoint<F> b0 = BkPoint<F>::load(out);
+    if (!b0.is_inf()) acc = b0.v;
+  }
 #if defined(ZKP_ACC_PREFETCH)
   // software pipeline: the gather of entry e + 1 is in flight while entry e is added (A/B switch; + 16 VGPRs -> 3 waves/SIMD)
   uint32_t v_next = vq.get(e0, e0);
@@ -117,6 +121,10 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   // G2 (BN254): Fq2 accumulator on unsaturated limbs, schoolbook products with lazily reduced sums (unsat_dev.hpp)
   XYZZu2<CfgFq> acc;
   acc.inf = true;
+  if (init && !(d >> 31)) {
+    const BkPoint<F> b0 = BkPoint<F>::load(out);
+    if (!b0.is_inf()) acc = b0.v;
+  }
   for (uint32_t e = e0; e < e1; e++) {
     uint32_t v = vq.get(e, e0);
     Affine<F> p = Affine<F>::ZKP_GATHER(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   r.v = acc;
   r.store(out);
 #else
-  XYZZ<F> acc = XYZZ<F>::inf();
+  XYZZ<F> acc = (init && !(d >> 31)) ? BkPoint<F>::load(out).to_sat() : XYZZ<F>::inf();
   // (a software-pipelined gather of entry e+1 was tried twice — G1: +20 VGPRs -> spills; G2 after the redo split:
   //  276 VGPRs -> 1 wave/SIMD, or 256 with launch bounds — no gain either time: the gather latency is covered)
   for (uint32_t e = e0; e < e1; e++) {
@@ -151,20 +159,21 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
 __global__ __launch_bounds__(64) void accumulate_redo_kernel(const char* __restrict__ table, const uint32_t* __restrict__ vals,
                                                             const uint4* __restrict__ desc, char* __restrict__ buckets,
                                                             char* __restrict__ partial, uint32_t idx_mask,
-                                                            const uint32_t* __restrict__ redo) {
+                                                            const uint32_t* __restrict__ redo, uint32_t init) {
   using F = CfgF;
   const uint32_t count = redo[0];
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
     const uint4 td = desc[redo[1 + k]];
     const uint32_t e0 = td.x, e1 = e0 + td.y;
-    XYZZ<F> acc = XYZZ<F>::inf();
+    const uint32_t d = td.z;
+    // (the fast kernel did not store anything for this task: with bucket chaining the bucket still holds the other MSM's value)
+    XYZZ<F> acc = (init && !(d >> 31)) ? BkPoint<F>::load(buckets + (size_t)d * BkPoint<F>::BYTES).to_sat() : XYZZ<F>::inf();
     for (uint32_t e = e0; e < e1; e++) {
       uint32_t v = vals[e];
       Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
       if (v >> 31) p.y = p.y.neg();
       acc.madd(p);
     }
-    const uint32_t d = td.z;
     BkPoint<F>::from_sat(acc).store((d >> 31) ? partial + (size_t)(d & 0x7fffffffu) * BkPoint<F>::BYTES
                                               : buckets + (size_t)d * BkPoint<F>::BYTES);
   }
@@ -183,7 +192,7 @@ static uint32_t dbg_mask() {
 }
 void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint4* desc,
                                         const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial,
-                                        uint32_t* redo) {
+                                        uint32_t* redo, uint32_t init) {
   // G2: 1 wave/SIMD (VGPRs + AGPRs as spill space, default) vs 2 waves/SIMD (256 VGPRs + 704 B scratch): the latter makes
   // the kernel itself 7 % faster but the whole proof 8 % slower (it starves the concurrent streams) — ZKP_G2_ACC_OCC=1|2
   static const unsigned lds = [] { const char* e = getenv("ZKP_ACC_LDS_BYTES"); return e ? (unsigned)atoi(e) : 0u; }();
@@ -197,34 +206,35 @@ void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const 
     const uint4* desc;
     char *buckets, *partial;
     uint32_t* redo;
+    uint32_t init;
     ~Redo() {
       hipLaunchKernelGGL(accumulate_redo_kernel, dim3(64), dim3(64), 0, s, table, vals, desc, buckets, partial,
-                         dbg_mask(), redo);
+                         dbg_mask(), redo, init);
     }
-  } redo_after{s, table, vals, desc, buckets, partial, redo};
+  } redo_after{s, table, vals, desc, buckets, partial, redo, init};
 #if ZKP_CFG_GROUP == 1 && defined(ZKP_ACC_UNSAT)
   // BLS12-381 G1: 169 VGPRs = one register over three waves per SIMD; ZKP_G1_ACC_WAVES=3 compiles for three (A/B switch)
   static const int g1w = [] { const char* e = getenv("ZKP_G1_ACC_WAVES"); return e ? atoi(e) : 0; }();
   if (g1w == 3)
     hipLaunchKernelGGL(accumulate_kernel<3>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
-                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo, init);
   else
     hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
-                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo, init);
   return;
 #endif
   if (ZKP_CFG_GROUP == 1 && occ1 == 4)
     hipLaunchKernelGGL(accumulate_kernel<4>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
-                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo, init);
   else if (ZKP_CFG_GROUP == 2 && occ == 3)
     hipLaunchKernelGGL(accumulate_kernel<3>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
-                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo, init);
   else if (ZKP_CFG_GROUP == 2 && occ == 2)
     hipLaunchKernelGGL(accumulate_kernel<2>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
-                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo, init);
   else
     hipLaunchKernelGGL(accumulate_kernel<1>, dim3((max_tasks + 255) / 256), dim3(256), lds, s, table, vals, desc,
-                       n_tasks_dev, buckets, partial, dbg_mask(), redo);
+                       n_tasks_dev, buckets, partial, dbg_mask(), redo, init);
 }
 
 }  // namespace zkp

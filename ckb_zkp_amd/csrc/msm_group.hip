@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void combine_small_kernel(const uint32_t* __re
                                                             const uint32_t* __restrict__ n_long_dev,
                                                             const uint32_t* __restrict__ toff,
                                                             const char* __restrict__ partial,
-                                                            char* __restrict__ buckets) {
+                                                            char* __restrict__ buckets, uint32_t init) {
   __builtin_amdgcn_s_setprio(3);
   const uint32_t n_long = *n_long_dev;
   for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_long; w += gridDim.x * blockDim.x) {
@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void combine_small_kernel(const uint32_t* __re
     if (p1 - p0 > COMBINE_SMALL) continue;
     BkPoint<F> acc = BkPoint<F>::load(partial + (size_t)p0 * BkPoint<F>::BYTES);
     for (uint32_t i = p0 + 1; i < p1; i++) acc.add(BkPoint<F>::load(partial + (size_t)i * BkPoint<F>::BYTES));
+    if (init) acc.add(BkPoint<F>::load(buckets + (size_t)b * BkPoint<F>::BYTES));      // bucket chaining
     acc.store(buckets + (size_t)b * BkPoint<F>::BYTES);
   }
 }
@@ -163,7 +164,7 @@ template <class F>
 __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict__ long_list,
                                                       const uint32_t* __restrict__ n_long_dev,
                                                       const uint32_t* __restrict__ toff,
-                                                      const char* __restrict__ partial, char* __restrict__ buckets) {
+                                                      const char* __restrict__ partial, char* __restrict__ buckets, uint32_t init) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
@@ -188,7 +189,10 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (lane == 0) acc.store(buckets + (size_t)b * BkPoint<F>::BYTES);
+    if (lane == 0) {
+      if (init) acc.add(BkPoint<F>::load(buckets + (size_t)b * BkPoint<F>::BYTES));    // bucket chaining
+      acc.store(buckets + (size_t)b * BkPoint<F>::BYTES);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -757,7 +761,7 @@ __global__ __launch_bounds__(64) void assemble_g2_kernel(const char* __restrict_
 
 // ------------------------------------------------------------------------------------------- launch table
 void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t, const char*, const uint32_t*, const uint4*, const uint32_t*, uint32_t,
-                                        char*, char*, uint32_t*);   // msm_acc.hip
+                                        char*, char*, uint32_t*, uint32_t);   // msm_acc.hip
 
 namespace {
 using F = CfgF;
@@ -770,9 +774,9 @@ void l_precompute(hipStream_t s, char* table, size_t n, int c, int W, int wide) 
   hipLaunchKernelGGL(precompute_kernel<F>, dim3((n + 127) / 128), dim3(128), 0, s, table, n, c, W, wide);
 }
 void l_combine(hipStream_t s, const uint32_t* long_list, const uint32_t* n_long_dev, const uint32_t* toff,
-               const char* partial, char* buckets) {
-  hipLaunchKernelGGL(combine_small_kernel<F>, dim3(256), dim3(256), 0, s, long_list, n_long_dev, toff, partial, buckets);
-  hipLaunchKernelGGL(combine_kernel<F>, dim3(512), dim3(256), 256 * BB, s, long_list, n_long_dev, toff, partial, buckets);
+               const char* partial, char* buckets, uint32_t init) {
+  hipLaunchKernelGGL(combine_small_kernel<F>, dim3(256), dim3(256), 0, s, long_list, n_long_dev, toff, partial, buckets, init);
+  hipLaunchKernelGGL(combine_kernel<F>, dim3(512), dim3(256), 256 * BB, s, long_list, n_long_dev, toff, partial, buckets, init);
 }
 void l_pair(hipStream_t s, const char* in, char* out, uint32_t count) {
   hipLaunchKernelGGL(pair_kernel<F>, dim3((count + 255) / 256), dim3(256), 0, s, in, out, count);

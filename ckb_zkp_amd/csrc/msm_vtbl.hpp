@@ -39,13 +39,15 @@ struct MsmVtbl {
   // dst < 0x80000000: bucket index (single-task bucket), else partial slot (dst & 0x7fffffff)
   // desc[t] = {first entry, length, dst, -} of the t-th task IN SCHEDULE ORDER (task_order_kernel): one coalesced 16-B load per
   // lane instead of four dependent random ones
+  // init != 0: the bucket array already holds the buckets of another MSM (bucket chaining, ctx.hpp): a single-task bucket starts
+  // from its stored value instead of the identity
   void (*accumulate)(hipStream_t, const char* table, const uint32_t* vals, const uint4* desc,
-                     const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial, uint32_t* redo);
+                     const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial, uint32_t* redo, uint32_t init);
   // redo: max_tasks + 1 words of scratch ([0] = count, zeroed by the launcher): tasks the fast path abandoned because an
   // operand might equal +-accumulator are listed there and redone by an exact second kernel
   // one wave per multi-task bucket: buckets[b] = sum of its partials
   void (*combine)(hipStream_t, const uint32_t* long_list, const uint32_t* n_long_dev, const uint32_t* toff,
-                  const char* partial, char* buckets);
+                  const char* partial, char* buckets, uint32_t init);   // init: add the bucket's stored value too
   void (*pair)(hipStream_t, const char* in, char* out, uint32_t count);
   void (*segsum)(hipStream_t, const char* base, const SegPlan* plan, char* partial, uint32_t blocks);
   void (*final)(hipStream_t, const char* O, int L, const char* root, char* out_xyzz, uint32_t* out_jac);
