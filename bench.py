@@ -475,7 +475,7 @@ def main():
                         "per_pass": {"passes": passes, "ms": round(t_ntt / passes, 4),
                                      "achieved": round(ach * passes, 1), "frac": round(ach * passes / 8000.0, 4),
                                      "note": "one pass reads and writes the vector once (64*N bytes)"},
-                        "valu": {"mulmods_per_element": round(0.5 * args.log_n + 1.5, 1),
+                        "valu": {"mulmods_per_element": round(0.5 * args.log_n + 0.25 * -(-args.log_n // 7), 2),   # per pass: S/2 - 3/4 in the tile (DIT: trivial twiddles in the first stages) + 1 at the store
                                  "gmulmod_per_s": round((0.5 * args.log_n + 1.5) * N / (t_ntt * 1e-3) / 1e9, 1)}}
         # (ii) MSM scalar scan (digit extraction fused into the level-1 histogram + scatter passes of the bucket sort)
         if phases and phases.get("ms_msm_scan", 0) > 0:
@@ -507,7 +507,9 @@ def main():
                                            "multiplier": "unsaturated limbs, schoolbook Fq2 with lazily reduced sums (unsat_dev.hpp)"},
                          "ntt": {"achieved": roofline_ntt["valu"]["gmulmod_per_s"], "ceiling": round(ceil_fr, 1),
                                  "frac": round(roofline_ntt["valu"]["gmulmod_per_s"] / ceil_fr, 3),
-                                 "multiplier": "unsaturated Fr products, saturated carry-chain add / sub (ntt.hip)"},
+                                 "multiplier": "tile unsaturated in LDS (decimation in time, no reductions between stages; ntt.hip ntt_pass2_kernel); "
+                                               "a stand-alone transform is bound by its 1024-workgroup grid on 768 slots and the load / store "
+                                               "phases, not by this roof — under the pipelined prover its VALU instruction count is what matters"},
                          "saturated_fq_ceiling": round(ceil_s, 1),
                          "note": "ceilings = zkp_bench_mulmod (better of 2 and 4 independent product chains per lane, 8 workgroups per CU), "
                                  "measured in this process; the accumulate / NTT kernels are bound by this roof, not by HBM"}

@@ -177,7 +177,7 @@ struct NttPassArgs {
 template <class P>
 __global__ __launch_bounds__(256) void ntt_full_table_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ lo,
                                                              const uint32_t* __restrict__ hi, int h, uint32_t n,
-                                                             int S, int logB, int twiddle) {
+                                                             int S, int logB, int twiddle, int rp) {
   using F = Fp<P>;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -187,7 +187,12 @@ __global__ __launch_bounds__(256) void ntt_full_table_kernel(uint32_t* __restric
     uint32_t bj = (i >> (logB + S)) << logB;
     e = bj * k1;
   }
-  (F::load(hi + (size_t)(e >> h) * 8) * F::load(lo + (size_t)(e & ((1u << h) - 1)) * 8)).store(out + (size_t)i * 8);
+  F r = F::load(hi + (size_t)(e >> h) * 8) * F::load(lo + (size_t)(e & ((1u << h) - 1)) * 8);
+  // rp: the entry as a canonical R'-form factor (t * 2^(L*B) mod p instead of t * 2^(32N)): SHIFT modular doublings.  A pass of
+  // the unsaturated kernel below repacks it into limbs and has a factor < p, not < 2^SHIFT * p
+  if (rp)
+    for (int k = 0; k < Fu<P>::SHIFT; k++) r = r + r;
+  r.store(out + (size_t)i * 8);
 }
 
 // Round 3: the products of a pass run on the UNSATURATED multiplier (unsat_dev.hpp: 9 x 29-bit limbs, one v_mad_u64_u32 per
@@ -371,6 +376,201 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3, second half: the pass with the tile UNSATURATED in LDS (ZKP_NTT_V2=0 restores the kernel above).
+//
+// The kernel above converts at every product (repack in, repack + conditional subtraction out: ~80 of the ~285 VALU
+// instructions of a butterfly's product) and adds / subtracts on carry chains with a conditional subtraction.  Here an element
+// enters the tile once as 9 x 29-bit limbs and stays that way through all S stages; the in-tile transform is decimation in TIME
+// (rows placed bit-reversed at the load, natural order at the store):   a' = a + w b,  b' = a + 2p - w b   with w b < 2p from the
+// multiplier, so the value bound grows by 2p per stage — LINEARLY (<= (2S + 1) p = 15p after seven stages; decimation in
+// frequency doubles the bound of the never-multiplied sum path per stage) — and no stage reduces anything: a butterfly is one
+// product (205 instructions) + a normalising add + a normalising subtract (27 each).  Twiddles of the tile are brought below 2p
+// once per workgroup (data bound x twiddle bound = 30 <= floor(R' / r) = 64 for the 255-bit BLS12-381 scalar field too); the
+// per-element tables (inter-pass twiddles, coset factors) are generated in canonical R' form (ntt_full_table_kernel, rp), so
+// the product that applies them also brings the element back below 2p, and one repack + conditional subtraction per element
+// and pass returns the canonical words HBM holds between passes.  DIT also makes the trivial twiddles fall in the FIRST stages:
+// 2.75 products per element in a 7-stage tile instead of 3.
+// LDS: limb planes of PLANE = TILE + TILE/8 words (8 pad words per 64: the four rows a lane touches in the early stages are
+// 4h rows apart, which would otherwise land in the same banks).
+// (an XOR swizzle without padding — 39 KB, four workgroups per CU instead of three — measured the same: 142.7 vs 142.9 proofs/s)
+#define NTT2_PLANE(tile) ((tile) + ((tile) >> 3))
+ZKP_DEV int ntt2_pad(int a) { return a + ((a >> 6) << 3); }
+template <class P>
+ZKP_DEV Fu<P> ntt2_lds_load(const uint32_t* lds, int plane, int pos) {
+  Fu<P> r;
+#pragma unroll
+  for (int l = 0; l < Fu<P>::L; l++) r.v[l] = lds[l * plane + pos];
+  return r;
+}
+template <class P>
+ZKP_DEV void ntt2_lds_store(uint32_t* lds, int plane, int pos, const Fu<P>& x) {
+#pragma unroll
+  for (int l = 0; l < Fu<P>::L; l++) lds[l * plane + pos] = x.v[l];
+}
+template <class P>
+ZKP_DEV Fu<P> ntt2_tw(const uint32_t* tw_l, int e) {
+  Fu<P> r;
+#pragma unroll
+  for (int l = 0; l < Fu<P>::L; l++) r.v[l] = tw_l[e * Fu<P>::L + l];
+  return r;
+}
+// a table entry in canonical R' form (< p)
+template <class P>
+ZKP_DEV Fu<P> ntt2_factor(const uint32_t* p) {
+  const Fp<P> t = Fp<P>::load(p);
+  return Fu<P>::from_words(t.v, 0);
+}
+
+template <class P>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass2_kernel(NttPassArgs a) {
+  using F = Fp<P>;
+  using U = Fu<P>;
+  constexpr int UL = U::L;
+  const uint32_t* __restrict__ in = a.in[blockIdx.y];
+  uint32_t* __restrict__ out = a.out[blockIdx.y];
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int S = a.S, logC = a.logC;
+  const int R = 1 << S, C = 1 << logC;
+  const int TILE = R << logC;
+  const int PLANE = NTT2_PLANE(TILE);
+  uint32_t* tw_l = lds + UL * PLANE;               // R/2 twiddles, < 2p, AoS (broadcast reads)
+  const uint32_t ncols = 1u << (a.log_n - S);
+  const uint32_t c0 = blockIdx.x << logC;
+  const int tid = threadIdx.x;
+  const uint32_t hmask = (1u << a.h) - 1;
+  {
+    const int shift = a.sub_log - S;               // w_R^k = w_Rsub^(k << shift)
+    for (int e = tid; e < (R >> 1); e += NTT_THREADS) {
+      const U t = U::from_sat_reduced(F::load(a.tw_sub + ((size_t)(e << shift)) * 8));
+#pragma unroll
+      for (int l = 0; l < UL; l++) tw_l[e * UL + l] = t.v[l];
+    }
+  }
+  // load (coalesced runs of C elements); the optional pointwise step / coset pre-scale works on canonical values as above
+  for (int e = tid; e < TILE; e += NTT_THREADS) {
+    uint32_t j1 = e >> logC, cc = e & (C - 1);
+    uint32_t gidx = j1 * ncols + c0 + cc;
+    F x = F::load(in + (size_t)gidx * 8);
+    if (a.fuse_b)
+      x = ntt_mul(ntt_mul(x, ntt_factor<P>(a.fuse_b + (size_t)gidx * 8)) - F::load(a.fuse_c + (size_t)gidx * 8), ntt_factor<P>(a.fuse_k));
+    if (a.pre_full) {
+      x = ntt_mul(x, ntt2_factor<P>(a.pre_full + (size_t)gidx * 8));
+    } else if (a.pre_lo) {
+      F sc = ntt_mul(F::load(a.pre_hi + (size_t)(gidx >> a.h) * 8), ntt_factor<P>(a.pre_lo + (size_t)(gidx & hmask) * 8));
+      x = ntt_mul(x, U::from_sat(sc));
+    }
+    const uint32_t row = S ? (__brev(j1) >> (32 - S)) : 0;
+    ntt2_lds_store<P>(lds, PLANE, ntt2_pad((int)((row << logC) + cc)), U::from_words(x.v, 0));
+  }
+  // S radix-2 DIT stages over rows, two per LDS round trip: a lane holds rows {b, b + h, b + 2h, b + 3h} (h = 2^s)
+  int s = 0;
+  for (; s + 1 < S; s += 2) {
+    __syncthreads();
+    const int h = 1 << s;
+    for (int qd = tid; qd < (TILE >> 2); qd += NTT_THREADS) {
+      const int cc = qd & (C - 1);
+      const int u = qd >> logC;
+      const int pos = u & (h - 1);
+      const int b = ((u >> s) << (s + 2)) + pos;
+      const int p0 = ntt2_pad((b << logC) + cc), p1 = ntt2_pad(((b + h) << logC) + cc);
+      const int p2 = ntt2_pad(((b + 2 * h) << logC) + cc), p3 = ntt2_pad(((b + 3 * h) << logC) + cc);
+      U r0 = ntt2_lds_load<P>(lds, PLANE, p0), r1 = ntt2_lds_load<P>(lds, PLANE, p1);
+      U r2 = ntt2_lds_load<P>(lds, PLANE, p2), r3 = ntt2_lds_load<P>(lds, PLANE, p3);
+      if (s > 0) {                                         // stage s: w_{2h}^pos for both pairs (w^0 in the first stage)
+        const U ta = ntt2_tw<P>(tw_l, pos << (S - 1 - s));
+        r1 = U::mul(r1, ta);
+        r3 = U::mul(r3, ta);
+      }
+      const U y0 = U::add(r0, r1), y1 = U::template sub<2>(r0, r1);
+      U y2 = U::add(r2, r3), y3 = U::template sub<2>(r2, r3);
+      if (s > 0) y2 = U::mul(y2, ntt2_tw<P>(tw_l, pos << (S - 2 - s)));           // stage s + 1: w_{4h}^pos ...
+      y3 = U::mul(y3, ntt2_tw<P>(tw_l, (pos + h) << (S - 2 - s)));                // ... and w_{4h}^(pos + h)
+      ntt2_lds_store<P>(lds, PLANE, p0, U::add(y0, y2));
+      ntt2_lds_store<P>(lds, PLANE, p2, U::template sub<2>(y0, y2));
+      ntt2_lds_store<P>(lds, PLANE, p1, U::add(y1, y3));
+      ntt2_lds_store<P>(lds, PLANE, p3, U::template sub<2>(y1, y3));
+    }
+  }
+  for (; s < S; s++) {
+    __syncthreads();
+    const int h = 1 << s;
+    for (int bf = tid; bf < (TILE >> 1); bf += NTT_THREADS) {
+      const int cc = bf & (C - 1);
+      const int u = bf >> logC;
+      const int pos = u & (h - 1);
+      const int b = ((u >> s) << (s + 1)) + pos;
+      const int p0 = ntt2_pad((b << logC) + cc), p1 = ntt2_pad(((b + h) << logC) + cc);
+      const U r0 = ntt2_lds_load<P>(lds, PLANE, p0);
+      U r1 = ntt2_lds_load<P>(lds, PLANE, p1);
+      if (s > 0) r1 = U::mul(r1, ntt2_tw<P>(tw_l, pos << (S - 1 - s)));
+      ntt2_lds_store<P>(lds, PLANE, p0, U::add(r0, r1));
+      ntt2_lds_store<P>(lds, PLANE, p1, U::template sub<2>(r0, r1));
+    }
+  }
+  __syncthreads();
+  // store: rows are in natural order; enumerate outputs in global-address order.  Values < (2S + 1) p leave through a product
+  // (inter-pass twiddle / coset factor / 1/N, or R' mod p when the pass has none), a repack and one conditional subtraction
+  const int logB = a.logB;
+  const int logBc = logB < logC ? logB : logC;
+  U pc = U::zero();
+  if (a.post_const) pc = U::from_sat_reduced(F::load(a.post_const));
+  for (int o = tid; o < TILE; o += NTT_THREADS) {
+    uint32_t bb = o & ((1u << logBc) - 1);
+    uint32_t k1 = (o >> logBc) & (R - 1);
+    uint32_t jj = o >> (logBc + S);
+    uint32_t cc = bb + (jj << logBc);
+    uint32_t c = c0 + cc;
+    uint32_t b = c & ((1u << logB) - 1);
+    uint32_t bj = c - b;                              // B * j'
+    uint32_t oidx = b + (k1 << logB) + (bj << S);
+    U x = ntt2_lds_load<P>(lds, PLANE, ntt2_pad((int)((k1 << logC) + cc)));
+    bool reduced = false;
+    if (!a.last) {
+      if (a.tw_full) {
+        x = U::mul(x, ntt2_factor<P>(a.tw_full + (size_t)oidx * 8));
+        reduced = true;
+      } else {
+        uint32_t e = bj * k1;                           // < N
+        if (e) {
+          F t = ntt_mul(F::load(a.tw_hi + (size_t)(e >> a.h) * 8), ntt_factor<P>(a.tw_lo + (size_t)(e & hmask) * 8));
+          x = U::mul(x, U::from_sat_reduced(t));
+          reduced = true;
+        }
+      }
+    }
+    if (a.post_full) {
+      x = U::mul(x, ntt2_factor<P>(a.post_full + (size_t)oidx * 8));
+      reduced = true;
+    } else if (a.post_lo) {
+      F t = ntt_mul(F::load(a.post_hi + (size_t)(oidx >> a.h) * 8), ntt_factor<P>(a.post_lo + (size_t)(oidx & hmask) * 8));
+      x = U::mul(x, U::from_sat_reduced(t));
+      reduced = true;
+    } else if (a.post_const) {
+      x = U::mul(x, pc);
+      reduced = true;
+    }
+    if (!reduced) x = U::mul(x, U::one());
+    F r;
+    x.to_words(r.v);
+    F::reduce_once(r).store(out + (size_t)oidx * 8);
+  }
+}
+static bool ntt_v2() {
+  static const bool on = !(getenv("ZKP_NTT_V2") && atoi(getenv("ZKP_NTT_V2")) == 0);
+  return on;
+}
+// one pass: the kernel and the LDS size that goes with it
+template <class P>
+static void ntt_launch(hipStream_t st, const NttPassArgs& a, uint32_t grid, int count) {
+  const size_t tile = (size_t)1 << (a.S + a.logC);
+  const size_t tw_bytes = ((size_t)1 << a.S) / 2 * 4 * Fu<P>::L + 32;
+  if (ntt_v2())
+    hipLaunchKernelGGL(ntt_pass2_kernel<P>, dim3(grid, count), dim3(NTT_THREADS), NTT2_PLANE(tile) * 4 * Fu<P>::L + tw_bytes, st, a);
+  else
+    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid, count), dim3(NTT_THREADS), tile * 32 + tw_bytes, st, a);
+}
+
 static void ntt_plan(int log_n, int* S, int* P) {
   if (log_n == 0) {
     *P = 0;
@@ -394,7 +594,7 @@ static uint32_t* full_table(zkp_ctx* ctx, NttTables& t, uint32_t** slot, const u
   if (hipMalloc(&blk, N * 32) != hipSuccess) return nullptr;        // fall back to the two-level lookup
   hipStream_t s = ctx->cur->stream;
   hipLaunchKernelGGL(ntt_full_table_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, s, blk, lo, hi, t.h, (uint32_t)N, S,
-                     logB, twiddle);
+                     logB, twiddle, ntt_v2() ? 1 : 0);
   ZKP_HIP(hipGetLastError());
   ZKP_HIP(hipStreamSynchronize(s));       // shared by every lane / stream afterwards
   t.extra.push_back(blk);
@@ -455,10 +655,7 @@ void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* const* data, int count, int lo
         a.post_const = t.n_inv;
       }
     }
-    const int tile = 1 << (S[p] + logC);
-    const size_t lds_bytes = (size_t)tile * 32 + ((size_t)1 << S[p]) / 2 * 4 * Fu<P>::L + 32;
-    const uint32_t grid = (uint32_t)(N >> (S[p] + logC));
-    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid, count), dim3(NTT_THREADS), lds_bytes, ctx->cur->stream, a);
+    ntt_launch<P>(ctx->cur->stream, a, (uint32_t)(N >> (S[p] + logC)), count);
     in_scratch = to_scratch;
     logB += S[p];
   }
@@ -486,10 +683,7 @@ static void launch_pass(zkp_ctx* ctx, NttTables& t, int log_n, const int* S, int
   a.tw_lo = inverse ? t.wi_lo : t.w_lo;
   a.tw_hi = inverse ? t.wi_hi : t.w_hi;
   if (!a.last) a.tw_full = full_table<P>(ctx, t, inverse ? &t.full_inv[p] : &t.full_fwd[p], a.tw_lo, a.tw_hi, S[p], logB, 1);
-  const int tile = 1 << (S[p] + logC);
-  const size_t lds_bytes = (size_t)tile * 32 + ((size_t)1 << S[p]) / 2 * 4 * Fu<P>::L + 32;
-  const uint32_t grid = (uint32_t)(((size_t)1 << log_n) >> (S[p] + logC));
-  hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid, 1), dim3(NTT_THREADS), lds_bytes, ctx->cur->stream, a);
+  ntt_launch<P>(ctx->cur->stream, a, (uint32_t)(((size_t)1 << log_n) >> (S[p] + logC)), 1);
 }
 
 // Witness map, first half (r1cs_to_qap.rs:144-148,161-162): ifft_in_place followed by coset_fft_in_place of the same vector

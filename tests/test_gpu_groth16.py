@@ -196,9 +196,6 @@ def test_full_size_proof_trapdoor_and_pipeline(ctx, curve, k):
 def test_graph_replay_equals_eager():
     """ZKP_GRAPH=1: the third and later proofs on a lane replay a captured hipGraph; they must equal the eager proofs
     (own process: the switch is read once per process)."""
-    import os
-    import subprocess
-    import sys
     code = r'''
 import numpy as np, random
 from ckb_zkp_amd import codec, groth16
@@ -219,14 +216,53 @@ ss = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(n)], c)
 outs, infs = pk.prove_batch_raw([zd] * n, rs, ss)
 print("PROOFS", outs.tobytes().hex(), infs.tobytes().hex())
 '''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for g in ("0", "1"):
-        env = dict(os.environ, ZKP_GRAPH=g, ZKP_LANES="2", PYTHONPATH=root)
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
-        assert out.returncode == 0, out.stderr[-2000:]
-        res[g] = [l for l in out.stdout.splitlines() if l.startswith("PROOFS")][0]
+    res = {g: _proofs_in_subprocess(code, ZKP_GRAPH=g, ZKP_LANES="2") for g in ("0", "1")}
     assert res["0"] == res["1"]
+
+
+def _proofs_in_subprocess(code, **env_extra):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, **env_extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [l for l in out.stdout.splitlines() if l.startswith("PROOFS")][0]
+
+
+_SWITCH_CODE = r'''
+import numpy as np, random
+from ckb_zkp_amd import codec, groth16
+from ckb_zkp_amd.api import Context
+from ckb_zkp_amd.circuits import mimc_chain_instance, samples_for_domain
+TOXIC = dict(alpha=11, beta=13, gamma=17, delta=19, tau=23)
+ctx = Context(0)
+inst = mimc_chain_instance("bn254", samples_for_domain(12))
+params = groth16.generate_parameters(ctx, "bn254", inst, **TOXIC)
+pk = groth16.ProvingKey(ctx, params, inst)
+c = params.curve
+z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+zd = ctx.to_device(z)
+rnd = random.Random(9)
+n = 3
+rs = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(n)], c)
+ss = codec.fr_to_mont([rnd.randrange(c.r) for _ in range(n)], c)
+outs, infs = pk.prove_batch_raw([zd] * n, rs, ss)
+one, inf1 = pk.prove_raw(z, rs[0], ss[0])
+assert np.array_equal(one, outs[0]) and np.array_equal(inf1, infs[0])
+print("PROOFS", outs.tobytes().hex(), infs.tobytes().hex())
+'''
+
+
+def test_schedule_switches_do_not_change_the_proof():
+    """Every scheduling shortcut of the prover — bucket chaining (H accumulates into L's buckets, one reduction for l' + h_acc),
+    the shared level-1 pass, shared sorts, the staged scatter, the three-stream plan — is an optimisation only: proofs are
+    byte-identical with each one switched off (own processes: the switches are read once per process)."""
+    base = _proofs_in_subprocess(_SWITCH_CODE)
+    for sw in ({"ZKP_CHAIN_LH": "0"}, {"ZKP_SHARE_L1": "0"}, {"ZKP_SHARE_B_SORT": "0", "ZKP_SHARE_AL_SORT": "0"},
+               {"ZKP_SORT_STAGED": "0"}, {"ZKP_SINGLE_STREAM": "1"}, {"ZKP_LATENCY_PLAN": "0"}, {"ZKP_TABLE_K": "2"}):
+        assert _proofs_in_subprocess(_SWITCH_CODE, **sw) == base, sw
 
 
 
