@@ -129,6 +129,8 @@ SIGNATURES = {
     "zkp_g2_decompress": (C.c_int32, [vp, C.c_int, vp, C.c_size_t, vp, vp, C.POINTER(C.c_size_t)]),
     "zkp_g1_compress": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, vp]),
     "zkp_g2_compress": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, vp]),
+    "zkp_g1_subgroup_check": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "zkp_g2_subgroup_check": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "zkp_g2_into_affine": (C.c_int32, [vp, C.c_int, vp, vp, vp]),
     "zkp_fixed_base_mul_g1": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, vp, vp]),
     "zkp_fixed_base_mul_g2": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, vp, vp]),

@@ -184,6 +184,20 @@ class Context:
         _lib.check(fn(self.h, c.cid, _ptr(xy), None if infa is None else _ptr(infa), n, _ptr(out)), "zkp_compress")
         return out.tobytes()
 
+    def subgroup_check(self, curve, group: int, xy: np.ndarray, inf=None) -> None:
+        """zkp_g1/g2_subgroup_check: every point on the curve and in the prime-order subgroup ([r]P = O), else ValueError(index) —
+        the checked half of ark's `deserialize`."""
+        c = get_curve(curve)
+        xy = _c64(xy)
+        n = xy.shape[0]
+        infa = None if inf is None else np.ascontiguousarray(inf, dtype=np.uint8)
+        bad = C.c_size_t(0)
+        fn = self.lib.zkp_g1_subgroup_check if group == 1 else self.lib.zkp_g2_subgroup_check
+        rc = fn(self.h, c.cid, _ptr(xy) if n else None, None if infa is None else _ptr(infa), n, C.byref(bad))
+        if rc == -1 and n:
+            raise ValueError(f"point {bad.value} is not in the prime-order subgroup (or not on the curve)")
+        _lib.check(rc, "zkp_subgroup_check")
+
     def fixed_base_mul(self, curve, group: int, base_xy: np.ndarray, scalars: np.ndarray):
         """k_i * P for canonical scalars (n,4) -> ((n, w) uint64 affine Montgomery, (n,) uint8 identity flags)."""
         c = get_curve(curve)

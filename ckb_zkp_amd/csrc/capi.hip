@@ -440,6 +440,23 @@ int32_t zkp_g2_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, con
   if (n && (!xy || !bytes)) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { points_compress(ctx, curve, 2, xy, inf, n, bytes); });
 }
+static int32_t subgroup_any(zkp_ctx* ctx, zkp_curve_t curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n, size_t* bad) {
+  if (n && !xy) return ZKP_ERR_BAD_ARG;
+  size_t st = 0;
+  const int32_t rc = guarded(ctx, [&] { st = points_subgroup_check(ctx, curve, group, xy, inf, n); });
+  if (rc != ZKP_OK) return rc;
+  if (st) {
+    if (bad) *bad = st - 1;
+    return ZKP_ERR_BAD_ARG;
+  }
+  return ZKP_OK;
+}
+int32_t zkp_g1_subgroup_check(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, size_t* bad) {
+  return subgroup_any(ctx, curve, 1, xy, inf, n, bad);
+}
+int32_t zkp_g2_subgroup_check(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, size_t* bad) {
+  return subgroup_any(ctx, curve, 2, xy, inf, n, bad);
+}
 int32_t zkp_fixed_base_mul_g1(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* base, const uint64_t* scalars, size_t n,
                               uint64_t* out_xy, uint8_t* out_inf) {
   if (!base || (n && (!scalars || !out_xy || !out_inf))) return ZKP_ERR_BAD_ARG;

@@ -72,6 +72,7 @@ void point_fold(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, si
 void point_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* xyz_host, uint64_t* xy_out, uint8_t* inf_out);
 size_t points_decompress(zkp_ctx* ctx, int curve, int group, const uint8_t* bytes, size_t n, uint64_t* xy_out, uint8_t* inf_out);
 void points_compress(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes_out);
+size_t points_subgroup_check(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n);
 // k Jacobian points a_i (+ b_i where has_b[i]) -> affine, one launch; host in / host out (slot strides: 3 fN / 2 fN words)
 void points_fold_into_affine(zkp_ctx* ctx, int curve, int group, const uint64_t* a_xyz_host, const uint64_t* b_xyz_host,
                              const uint8_t* has_b, size_t k, uint64_t* xy_out, uint8_t* inf_out);

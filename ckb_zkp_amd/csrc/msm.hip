@@ -1322,6 +1322,28 @@ size_t points_decompress(zkp_ctx* ctx, int curve, int group, const uint8_t* byte
   ZKP_HIP(hipStreamSynchronize(st));
   return status == none ? 0 : (size_t)status;
 }
+// 0 = every point is on the curve and in the prime-order subgroup, else 1 + index of the first that is not
+size_t points_subgroup_check(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n) {
+  if (n == 0) return 0;
+  const MsmVtbl* vt = msm_vtbl(curve, group);
+  const size_t ab = vt->aff_bytes;
+  char* buf = reinterpret_cast<char*>(ctx->msm_misc.get(n * ab + n + 512));
+  char* d_xy = buf;
+  uint8_t* d_inf = reinterpret_cast<uint8_t*>(buf + n * ab);
+  uint32_t* d_b = reinterpret_cast<uint32_t*>(buf + n * ab + ((n + 63) & ~(size_t)63));
+  uint32_t* d_status = d_b + 48;
+  hipStream_t st = ctx->cur->stream;
+  const uint32_t none = 0xffffffffu;
+  ZKP_HIP(hipMemcpyAsync(d_xy, xy, n * ab, hipMemcpyHostToDevice, st));
+  if (inf) ZKP_HIP(hipMemcpyAsync(d_inf, inf, n, hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipMemcpyAsync(d_status, &none, 4, hipMemcpyHostToDevice, st));
+  vt->subgroup_check(st, d_xy, inf ? d_inf : nullptr, n, d_b, d_status);
+  ZKP_HIP(hipGetLastError());
+  uint32_t status = 0;
+  ZKP_HIP(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipStreamSynchronize(st));
+  return status == none ? 0 : (size_t)status;
+}
 void points_compress(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes_out) {
   if (n == 0) return;
   const MsmVtbl* vt = msm_vtbl(curve, group);

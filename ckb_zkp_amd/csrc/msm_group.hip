@@ -525,6 +525,31 @@ __global__ __launch_bounds__(64) void decompress_kernel(const uint32_t* __restri
   Affine<F>{xm, y}.store(xy + i * Affine<F>::BYTES);
   inf[i] = 0;
 }
+// ark-ec 0.2 `GroupAffine::is_in_correct_subgroup_assuming_on_curve` ([r]P = O by double-and-add over the bits of the group
+// order) plus the curve equation — what the CHECKED `deserialize` of a key or proof element runs per point
+// (/root/reference/groth16/src/lib.rs `Parameters::deserialize` -> ark-serialize derive -> GroupAffine::deserialize).  One lane per
+// point; status = 1 + index of the first point that is off the curve or outside the prime-order subgroup (atomicMin).
+template <class F>
+__global__ __launch_bounds__(64) void subgroup_check_kernel(const char* __restrict__ xy, const uint8_t* __restrict__ inf, size_t n,
+                                                           const uint32_t* __restrict__ bcoef, uint32_t* __restrict__ status) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (inf && inf[i]) return;
+  const Affine<F> p = Affine<F>::load(xy + i * Affine<F>::BYTES);
+  if (p.is_inf()) return;
+  bool ok = (p.y.sqr() - (p.x.sqr() * p.x + F::load(bcoef))).is_zero();
+  if (ok) {
+    XYZZ<F> acc = XYZZ<F>::from_affine(p);
+    int top = 32 * CfgFr::N - 1;
+    while (!((CfgFr::MOD[top >> 5] >> (top & 31)) & 1u)) top--;
+    for (int b = top - 1; b >= 0; b--) {
+      acc = acc.dbl();
+      if ((CfgFr::MOD[b >> 5] >> (b & 31)) & 1u) acc.madd(p);
+    }
+    ok = acc.is_inf();
+  }
+  if (!ok) atomicMin(status, (uint32_t)(i + 1));
+}
 template <class F>
 __global__ __launch_bounds__(64) void compress_kernel(const char* __restrict__ xy, const uint8_t* __restrict__ inf, size_t n,
                                                       uint32_t* __restrict__ bytes) {
@@ -820,6 +845,10 @@ void l_decompress(hipStream_t s, const uint32_t* bytes, size_t n, const uint32_t
 void l_compress(hipStream_t s, const char* xy, const uint8_t* inf, size_t n, uint32_t* bytes) {
   if (n) hipLaunchKernelGGL(compress_kernel<F>, dim3((n + 63) / 64), dim3(64), 0, s, xy, inf, n, bytes);
 }
+void l_subgroup_check(hipStream_t s, const char* xy, const uint8_t* inf, size_t n, const uint32_t* bcoef, uint32_t* status) {
+  hipLaunchKernelGGL(curve_b_kernel<F>, dim3(1), dim3(64), 0, s, const_cast<uint32_t*>(bcoef));
+  if (n) hipLaunchKernelGGL(subgroup_check_kernel<F>, dim3((n + 63) / 64), dim3(64), 0, s, xy, inf, n, bcoef, status);
+}
 void l_from_jacobian(hipStream_t s, const uint32_t* jac, char* out) {
   hipLaunchKernelGGL(from_jacobian_kernel<F>, dim3(1), dim3(64), 0, s, jac, out);
 }
@@ -847,7 +876,7 @@ const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
   static const MsmVtbl v = {
       F::N, Affine<F>::BYTES, XYZZ<F>::BYTES, BkPoint<F>::BYTES, CFG_BITS,
       l_ingest, l_precompute, ZKP_CFG_SYM(msm_accumulate_launch), l_combine, l_pair, l_segsum, l_final, l_identity, l_fold,
-      l_into_affine, l_fold_affine_batch, l_decompress, l_compress, l_from_jacobian, l_fixed_base, l_segsum_desc, l_final_var, l_fold_slots,
+      l_into_affine, l_fold_affine_batch, l_decompress, l_compress, l_subgroup_check, l_from_jacobian, l_fixed_base, l_segsum_desc, l_final_var, l_fold_slots,
 #if ZKP_CFG_GROUP == 1
       l_assemble_g1_p1, l_assemble_g1_p2, nullptr,
 #else

@@ -61,6 +61,8 @@ struct MsmVtbl {
   // ark-serialize compressed points <-> affine Montgomery, one lane per point (msm_group.hip "point codec"); bcoef = the curve's b
   void (*decompress)(hipStream_t, const uint32_t* bytes, size_t n, const uint32_t* bcoef, char* xy, uint8_t* inf, uint32_t* status);
   void (*compress)(hipStream_t, const char* xy, const uint8_t* inf, size_t n, uint32_t* bytes);
+  // on the curve and [r]P = O, one lane per point; status: 1 + index of the first failing point (atomicMin)
+  void (*subgroup_check)(hipStream_t, const char* xy, const uint8_t* inf, size_t n, const uint32_t* bcoef, uint32_t* status);
   void (*from_jacobian)(hipStream_t, const uint32_t* jac, char* out_xyzz);
   void (*fixed_base)(hipStream_t, const uint32_t* base, const uint32_t* scalars, size_t n, char* out_xy,
                      uint8_t* out_inf);

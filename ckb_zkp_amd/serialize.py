@@ -498,8 +498,11 @@ def parameters_to_bytes_abi(ctx, params) -> bytes:
             vec(2, params.b_g2_query) + vec(1, params.h_query) + vec(1, params.l_query))
 
 
-def parameters_from_bytes_abi(ctx, b: bytes, curve, num_constraints: int):
-    """`Parameters::deserialize_unchecked` -> groth16.Parameters (ABI arrays), points decompressed on the device.
+def parameters_from_bytes_abi(ctx, b: bytes, curve, num_constraints: int, checked: bool = True):
+    """`Parameters::deserialize` (checked=True: every point on the curve and in the prime-order subgroup, like ark-ec 0.2's
+    `GroupAffine::deserialize`; False = `deserialize_unchecked`) -> groth16.Parameters (ABI arrays).  Decompression and the subgroup
+    check run on the device (zkp_g*_decompress / zkp_g*_subgroup_check): a 2^20 key loads checked in well under a second where the
+    pure-Python `parameters_from_bytes` needs hours.
     num_constraints is not part of the file (the reference re-synthesises the circuit): the caller supplies it."""
     from .groth16 import Parameters
     c = get_curve(curve)
@@ -508,7 +511,10 @@ def parameters_from_bytes_abi(ctx, b: bytes, curve, num_constraints: int):
 
     def pts(group, count):
         try:
-            return ctx.decompress_points(c, group, r.take(count * n * group))
+            xy, inf = ctx.decompress_points(c, group, r.take(count * n * group))
+            if checked and not (group == 1 and c.name == "bn254"):       # BN254 G1 has cofactor 1
+                ctx.subgroup_check(c, group, xy, inf)
+            return xy, inf
         except ValueError as e:
             raise SerializationError(f"InvalidData ({e})")
 

@@ -179,6 +179,14 @@ int32_t zkp_g2_decompress(zkp_ctx* ctx, zkp_curve_t curve, const uint8_t* bytes,
                           size_t* bad_index);
 int32_t zkp_g1_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes_out);
 int32_t zkp_g2_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes_out);
+/* The CHECKED half of ark-serialize's `deserialize` for curve points (ark-ec 0.2 `GroupAffine::deserialize`: on the curve and
+ * `is_in_correct_subgroup_assuming_on_curve`, i.e. [r]P = O; what `Parameters::deserialize` / `Proof::deserialize` /
+ * `VerifyKey::deserialize` run per element — /root/reference/cli/src/zkp_prove.rs, zkp_verify.rs).  xy: n affine Montgomery points
+ * (the layout zkp_g*_decompress writes), inf: optional identity flags (identities pass).  One lane per point, a double-and-add over
+ * the group order: ~0.2 s for a 2^20-element G2 query.  ZKP_OK if every point passes; otherwise ZKP_ERR_BAD_ARG and *bad_index
+ * (if not NULL) = index of the first point that is off the curve or outside the prime-order subgroup. */
+int32_t zkp_g1_subgroup_check(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, size_t* bad_index);
+int32_t zkp_g2_subgroup_check(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, size_t* bad_index);
 
 /* ---- fixed-base multiples k_i * P (setup side, generator.rs:205-256 `FixedBaseMSM`).
  * Used to build synthetic proving keys from a known trapdoor at 2^20+ scale.  scalars canonical. */

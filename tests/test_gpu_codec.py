@@ -100,3 +100,71 @@ def test_parameters_bytes_roundtrip_proves_the_same(ctx, curve):
     assert serialize.proof_to_bytes_abi(ctx, curve, p1, i1) == serialize.proof_to_bytes(groth16.Proof(pa, pb, pc), c)
     pk1.free()
     pk2.free()
+
+
+# ------------------------------------------------------------------------------------------- checked deserialize (subgroup)
+def _curve_point_outside_subgroup(curve, group):
+    """a point ON the curve whose order does not divide r (cofactor groups only): decompress small x values until one works"""
+    from oracle.pyref.curves import Group
+    c = get_curve(curve)
+    n = 8 * c.fq_limbs
+    G = Group(OC[curve], group)
+    x = 1
+    while True:
+        data = x.to_bytes(n, "little") + (b"" if group == 1 else (1).to_bytes(n, "little"))
+        x += 1
+        try:
+            P = (serialize.g1_from_bytes if group == 1 else serialize.g2_from_bytes)(data, c, checked=False)
+        except serialize.SerializationError:
+            continue
+        if P is not None and G.on_curve(P) and not serialize.in_prime_order_subgroup(P, c, group):
+            return P
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("group", [1, 2])
+def test_subgroup_check_accepts_subgroup_points_and_rejects_off_curve(ctx, curve, group):
+    c = get_curve(curve)
+    pts = _points(curve, group, 24, 3 * group + len(curve))
+    to_m = codec.g1_to_mont if group == 1 else codec.g2_to_mont
+    xy, inf = to_m(pts, c)
+    ctx.subgroup_check(c, group, xy, inf)                         # incl. the identity at index 12
+    ctx.subgroup_check(c, group, xy[:0], inf[:0])                 # empty
+    bad = xy.copy()
+    bad[7, -1] ^= 1                                               # y (G2: its c1) off by one Montgomery unit: not on the curve
+    with pytest.raises(ValueError) as e:
+        ctx.subgroup_check(c, group, bad, inf)
+    assert "point 7 " in str(e.value)
+
+
+@pytest.mark.parametrize("curve,group", [("bls12_381", 1), ("bls12_381", 2), ("bn254", 2)])
+def test_subgroup_check_rejects_curve_points_outside_the_subgroup(ctx, curve, group):
+    c = get_curve(curve)
+    P = _curve_point_outside_subgroup(curve, group)
+    pts = _points(curve, group, 12, 17)
+    pts[9] = P
+    pts[10] = P                                                   # the FIRST failing index is reported
+    to_m = codec.g1_to_mont if group == 1 else codec.g2_to_mont
+    xy, inf = to_m(pts, c)
+    with pytest.raises(ValueError) as e:
+        ctx.subgroup_check(c, group, xy, inf)
+    assert "point 9 " in str(e.value)
+    # the same verdict as the Python restatement of ark's check
+    assert not serialize.in_prime_order_subgroup(P, c, group)
+    assert serialize.in_prime_order_subgroup(pts[0], c, group)
+
+
+def test_checked_parameters_load_rejects_a_small_subgroup_element(ctx):
+    curve = "bls12_381"
+    c = get_curve(curve)
+    inst = mimc_chain_instance(curve, 12)
+    params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    blob = serialize.parameters_to_bytes_abi(ctx, params)
+    serialize.parameters_from_bytes_abi(ctx, blob, curve, inst.num_constraints())                 # checked: passes
+    ref = serialize.parameters_from_bytes(blob, c, checked=False)
+    ref["b_g2_query"][3] = _curve_point_outside_subgroup(curve, 2)
+    blob2 = serialize.parameters_to_bytes(ref, c)
+    with pytest.raises(serialize.SerializationError):
+        serialize.parameters_from_bytes_abi(ctx, blob2, curve, inst.num_constraints())
+    loaded = serialize.parameters_from_bytes_abi(ctx, blob2, curve, inst.num_constraints(), checked=False)
+    assert loaded.b_g2_query[0].shape == params.b_g2_query[0].shape
