@@ -181,7 +181,7 @@ int32_t zkp_g1_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, con
 int32_t zkp_g2_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* bytes_out);
 /* The CHECKED half of ark-serialize's `deserialize` for curve points (ark-ec 0.2 `GroupAffine::deserialize`: on the curve and
  * `is_in_correct_subgroup_assuming_on_curve`, i.e. [r]P = O; what `Parameters::deserialize` / `Proof::deserialize` /
- * `VerifyKey::deserialize` run per element — /root/reference/cli/src/zkp_prove.rs, zkp_verify.rs).  xy: n affine Montgomery points
+ * `VerifyKey::deserialize` run per element — /root/reference/cli/src/zkp_prove.rs:45, zkp_verify.rs:61-62).  xy: n affine Montgomery points
  * (the layout zkp_g*_decompress writes), inf: optional identity flags (identities pass).  One lane per point, a double-and-add over
  * the group order: ~0.2 s for a 2^20-element G2 query.  ZKP_OK if every point passes; otherwise ZKP_ERR_BAD_ARG and *bad_index
  * (if not NULL) = index of the first point that is off the curve or outside the prime-order subgroup. */

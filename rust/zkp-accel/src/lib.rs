@@ -410,3 +410,92 @@ pub fn ntt_in_place<F: AbiScalar>(ctx: &Ctx, curve: c_int, v: &mut [F], op: NttO
     let log_n = v.len().trailing_zeros();
     check(unsafe { ffi::zkp_ntt(ctx.0, curve, scalars_mut_ptr(v), log_n, op as i32) })
 }
+
+// ------------------------------------------------------------------------------------------------ point codec
+/// Error of the codec / checked-deserialize calls: the library reports the index of the first offending point.
+#[derive(Debug)]
+pub enum PointError {
+    /// malformed compressed point (both flags set, x >= p, x^3 + b not a square) / point off the curve or outside the
+    /// prime-order subgroup, at this index
+    Invalid(usize),
+    Accel(Error),
+}
+
+/// `n` ark-serialize 0.2 COMPRESSED points (what `Parameters::serialize` writes for a query) -> `Vec<GroupAffine<P>>`,
+/// decompressed on the device (`zkp_g*_decompress`: one square root per lane).  `checked = true` adds ark's
+/// `is_in_correct_subgroup_assuming_on_curve` for every point (`zkp_g*_subgroup_check`), i.e. the semantics of
+/// `CanonicalDeserialize::deserialize`; `false` = `deserialize_unchecked`.
+pub fn decompress_points<P: AccelGroup>(ctx: &Ctx, bytes: &[u8], checked: bool) -> Result<Vec<GroupAffine<P>>, PointError>
+where
+    P::BaseField: AbiField,
+{
+    let l = <P::BaseField as AbiField>::LIMBS;
+    let pb = 8 * l; // one coordinate per point
+    assert_eq!(bytes.len() % pb, 0, "a whole number of compressed points");
+    let n = bytes.len() / pb;
+    let mut xy = vec![0u64; n * 2 * l];
+    let mut inf = vec![0u8; n];
+    let mut bad: usize = 0;
+    let st = unsafe {
+        if P::GROUP == 1 {
+            ffi::zkp_g1_decompress(ctx.0, P::CURVE, bytes.as_ptr(), n, xy.as_mut_ptr(), inf.as_mut_ptr(), &mut bad)
+        } else {
+            ffi::zkp_g2_decompress(ctx.0, P::CURVE, bytes.as_ptr(), n, xy.as_mut_ptr(), inf.as_mut_ptr(), &mut bad)
+        }
+    };
+    if st == ffi::ZKP_ERR_BAD_ARG && n > 0 {
+        return Err(PointError::Invalid(bad));
+    }
+    check(st).map_err(PointError::Accel)?;
+    if checked {
+        subgroup_check_limbs::<P>(ctx, &xy, &inf)?;
+    }
+    Ok((0..n).map(|i| unmarshal_affine::<P>(&xy[i * 2 * l..(i + 1) * 2 * l], inf[i] != 0)).collect())
+}
+
+/// `&[GroupAffine<P>]` -> ark-serialize compressed bytes (`zkp_g*_compress`), e.g. the three points of a `Proof`.
+pub fn compress_points<P: AccelGroup>(ctx: &Ctx, pts: &[GroupAffine<P>]) -> Result<Vec<u8>, Error>
+where
+    P::BaseField: AbiField,
+{
+    let l = <P::BaseField as AbiField>::LIMBS;
+    let (xy, inf) = marshal_points(pts);
+    let mut out = vec![0u8; pts.len() * 8 * l];
+    let st = unsafe {
+        if P::GROUP == 1 {
+            ffi::zkp_g1_compress(ctx.0, P::CURVE, xy.as_ptr(), inf.as_ptr(), pts.len(), out.as_mut_ptr())
+        } else {
+            ffi::zkp_g2_compress(ctx.0, P::CURVE, xy.as_ptr(), inf.as_ptr(), pts.len(), out.as_mut_ptr())
+        }
+    };
+    check(st)?;
+    Ok(out)
+}
+
+fn subgroup_check_limbs<P: AccelGroup>(ctx: &Ctx, xy: &[u64], inf: &[u8]) -> Result<(), PointError>
+where
+    P::BaseField: AbiField,
+{
+    let mut bad: usize = 0;
+    let n = inf.len();
+    let st = unsafe {
+        if P::GROUP == 1 {
+            ffi::zkp_g1_subgroup_check(ctx.0, P::CURVE, xy.as_ptr(), inf.as_ptr(), n, &mut bad)
+        } else {
+            ffi::zkp_g2_subgroup_check(ctx.0, P::CURVE, xy.as_ptr(), inf.as_ptr(), n, &mut bad)
+        }
+    };
+    if st == ffi::ZKP_ERR_BAD_ARG && n > 0 {
+        return Err(PointError::Invalid(bad));
+    }
+    check(st).map_err(PointError::Accel)
+}
+
+/// ark-ec 0.2 `is_in_correct_subgroup_assuming_on_curve` (plus the curve equation) for a whole query at once.
+pub fn subgroup_check<P: AccelGroup>(ctx: &Ctx, pts: &[GroupAffine<P>]) -> Result<(), PointError>
+where
+    P::BaseField: AbiField,
+{
+    let (xy, inf) = marshal_points(pts);
+    subgroup_check_limbs::<P>(ctx, &xy, &inf)
+}

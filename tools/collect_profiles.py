@@ -22,7 +22,7 @@ def row(path, kern):
 
 
 f, w = src + "pmc_FETCH_SIZE.txt", src + "pmc_WRITE_SIZE.txt"
-A1, A2, NT = "_ZN3zkp7cfg_c0117accumulate_kernel", "_ZN3zkp7cfg_c0217accumulate_kernel", "_ZN3zkp15ntt_pass_kernel"
+A1, A2, NT = "_ZN3zkp7cfg_c0117accumulate_kernel", "_ZN3zkp7cfg_c0217accumulate_kernel", "_ZN3zkp16ntt_pass2_kernel"
 fg1, n1, t1 = row(f, A1)
 fg2, n2, t2 = row(f, A2)
 wg1, _, _ = row(w, A1)
@@ -40,7 +40,7 @@ json.dump({
     "write_kib_per_launch": {"g1": round(w1, 2), "g2": round(w2, 2)},
     "avg_launch_us_in_pmc_run": {"g1": t1, "g2": t2},
     "gfx950_fetch_correction": 2.0,
-    "calibration": f"ntt_pass_kernel in the same run: FETCH_SIZE raw {fn / nn / 1024:.2f} MiB/launch (x2 = {2 * fn / nn / 1024:.1f} MiB) for a "
+    "calibration": f"ntt_pass2_kernel in the same run: FETCH_SIZE raw {fn / nn / 1024:.2f} MiB/launch (x2 = {2 * fn / nn / 1024:.1f} MiB) for a "
                    f"32 MiB vector + twiddle table minus cache hits, WRITE_SIZE {wn / nn / 1024:.2f} MiB/launch for a 32 MiB vector -> reads "
                    "need the x2 of MI355X_MICROARCH.md, writes are exact",
     "traffic_bytes_per_launch": traffic,
