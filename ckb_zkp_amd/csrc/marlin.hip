@@ -378,9 +378,11 @@ struct zkp_marlin_index {
   int32_t *w_idx = nullptr, *x_idx = nullptr;
   std::vector<void*> owned;
   Pool pool;           // scratch of the provers that use this index
+  uint64_t* early_pinned = nullptr;     // pinned landing zone of the early commitment MSMs (marlin_prove: commit_early)
   ~zkp_marlin_index() {
     pool.trim();
     for (void* p : owned) (void)hipFree(p);
+    if (early_pinned) (void)hipHostFree(early_pinned);
   }
 };
 
@@ -663,6 +665,49 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   }
   DVec z_a_ev = be.spmv(ix->csr[0].rp, ix->csr[0].col, ix->csr[0].cf, z, ix->n);
   DVec z_b_ev = be.spmv(ix->csr[1].rp, ix->csr[1].col, ix->csr[1].cf, z, ix->n);
+  // the mask polynomial is an input: prepared first so that its commitment (the largest MSM of the round) runs under the
+  // interpolations below
+  const size_t mask_len = 3 * hs + 2 * 1 - 2;
+  DVec mask = be.alloc(mask_len);
+  ZKP_HIP(hipMemcpyAsync(mask.p, rnd->mask, mask_len * 32, rnd->mask_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  {
+    DVec mrem = be.fold(mask, hs).second;
+    be.add_at(mask, 0, F.neg(be.element(mrem, 0)));   // mask - sigma_H(mask)/|H| ... exactly prover.rs:202-205
+  }
+  // label order used everywhere below: first round w, z_a, z_b, mask; second t, g_1, h_1; third g_2, h_2
+  enum { W_, ZA_, ZB_, MASK_, T_, G1_, H1_, G2_, H2_, NLAB };
+  DVec poly[NLAB];
+  poly[MASK_] = mask;
+  const bool bounded[NLAB] = {false, false, false, false, false, true, false, true, false};
+  // Early commitments (round 3): a polynomial that is final long before its round ends (the mask polynomial — an input — and t(X)
+  // of the second round) starts its commitment MSM at once on an MSM workspace stream of this lane, under the NTTs / pointwise
+  // kernels that compute the rest of the round (which otherwise run alone: 12.6 + 4.9 ms per proof in a kernel trace);
+  // commit_round collects the result instead of launching the MSM.  ZKP_MARLIN_EARLY=0: every MSM inside commit_round.
+  static const bool early_on = !(getenv("ZKP_MARLIN_EARLY") && atoi(getenv("ZKP_MARLIN_EARLY")) == 0);
+  constexpr int EARLY_MAX = 4;
+  if (!ix->early_pinned) ZKP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->early_pinned), EARLY_MAX * 24 * 8));
+  struct Early {
+    int label, ws;
+  };
+  std::vector<Early> early;
+  // -> index into `early` (-1: not started, the caller runs the MSM itself later)
+  auto start_early = [&](int label, const DVec& v) -> int {
+    if (!early_on || (int)early.size() >= EARLY_MAX || v.n == 0) return -1;
+    zkp_lane* L = ctx->cur;
+    const int w = 1 + (int)(early.size() % (zkp_lane::N_WS - 1));
+    hipStream_t ws_st = L->ws[w].stream;
+    ZKP_HIP(hipEventRecord(L->ev_fork, st));                         // v is complete on the prover's stream
+    ZKP_HIP(hipStreamWaitEvent(ws_st, L->ev_fork, 0));
+    const size_t n = std::min(v.n, bases_len(ctx, powers_g));        // ark min(len) truncation, as msm_run_multi
+    msm_run(ctx, powers_g, 0, v.p, n, true, nullptr, nullptr, nullptr, nullptr, w);
+    ZKP_HIP(hipMemcpyAsync(ix->early_pinned + early.size() * 24, L->ws[w].out.p, jw64 * 8, hipMemcpyDeviceToHost, ws_st));
+    ZKP_HIP(hipEventRecord(L->ws[w].done, ws_st));
+    early.push_back({label, w});
+    return (int)early.size() - 1;
+  };
+  auto commit_early = [&](int l) { (void)start_early(l, poly[l]); };
+
+  commit_early(MASK_);
   // ---- first round (prover.rs:150-222)
   DVec x_poly = be.ifft(z.view(0, ni), xs);
   DVec x_on_h = be.fft(x_poly, hs);
@@ -676,22 +721,10 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   };
   DVec w_poly = be.fold(masked(w_on_h, fr_of(rnd->w)), xs).first;
   DVec z_a = masked(z_a_ev, fr_of(rnd->z_a)), z_b = masked(z_b_ev, fr_of(rnd->z_b));
-  const size_t mask_len = 3 * hs + 2 * 1 - 2;
-  DVec mask = be.alloc(mask_len);
-  ZKP_HIP(hipMemcpyAsync(mask.p, rnd->mask, mask_len * 32, rnd->mask_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-  {
-    DVec mrem = be.fold(mask, hs).second;
-    be.add_at(mask, 0, F.neg(be.element(mrem, 0)));   // mask - sigma_H(mask)/|H| ... exactly prover.rs:202-205
-  }
-  // label order used everywhere below: first round w, z_a, z_b, mask; second t, g_1, h_1; third g_2, h_2
-  enum { W_, ZA_, ZB_, MASK_, T_, G1_, H1_, G2_, H2_, NLAB };
-  DVec poly[NLAB];
   poly[W_] = w_poly;
   poly[ZA_] = z_a;
   poly[ZB_] = z_b;
-  poly[MASK_] = mask;
   const bool hide[NLAB] = {true, true, true, false, false, true, false, false, false};
-  const bool bounded[NLAB] = {false, false, false, false, false, true, false, true, false};
   const size_t bound[NLAB] = {0, 0, 0, 0, 0, hs - 2, 0, ks - 2, 0};
   const uint64_t* blind_host[NLAB] = {rnd->blind_w, rnd->blind_z_a, rnd->blind_z_b, nullptr, nullptr, rnd->blind_g_1,
                                       nullptr,      nullptr,        nullptr};
@@ -706,7 +739,15 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     std::vector<size_t> offs, ns;
     std::vector<const uint64_t*> ptrs;
     std::vector<std::pair<int, bool>> slot;
+    std::vector<std::pair<int, size_t>> early_slot;                 // (label, index into `early`) of the polynomials already under way
     for (int l : labels) {
+      size_t e = 0;
+      while (e < early.size() && early[e].label != l) e++;
+      if (e < early.size() && !bounded[l]) {
+        tm.commit_points += poly[l].n;
+        early_slot.push_back({l, e});
+        continue;
+      }
       offs.push_back(0);
       ns.push_back(poly[l].n);
       ptrs.push_back(poly[l].p);
@@ -719,8 +760,16 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
       }
     }
     for (size_t nn : ns) tm.commit_points += nn;
-    std::vector<uint64_t> jac(slot.size() * jw64);
+    std::vector<uint64_t> jac((slot.size() + early_slot.size()) * jw64);
     msm_run_batch(ctx, powers_g, slot.size(), offs.data(), ptrs.data(), ns.data(), true, jac.data());
+    if (!early_slot.empty()) {
+      for (auto& es : early_slot) ZKP_HIP(hipStreamWaitEvent(st, ctx->cur->ws[early[es.second].ws].done, 0));
+      ZKP_HIP(hipStreamSynchronize(st));
+      for (auto& es : early_slot) {
+        memcpy(jac.data() + slot.size() * jw64, ix->early_pinned + es.second * 24, jw64 * 8);
+        slot.push_back({es.first, false});
+      }
+    }
     std::vector<size_t> boffs, bns;
     std::vector<const uint64_t*> bptrs;
     std::vector<size_t> bslot(slot.size(), (size_t)-1);
@@ -780,6 +829,8 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   for (int m = 0; m < 3; m++)
     be.axpy_into(t_on_h, be.spmv(ix->csr_t[m].rp, ix->csr_t[m].col, ix->csr_t[m].cf, r_alpha_on_h, hs), etas[m]);
   DVec t_poly = be.ifft(t_on_h, hs);
+  poly[T_] = t_poly;
+  commit_early(T_);                                                        // under the product FFTs below
   DVec z_poly = be.axpy(be.sub(be.shift(w_poly, xs), w_poly), x_poly, one);          // w * v_X + x
   {
     const size_t size = next_pow2(std::max({mask.n, r_alpha.n + m_poly.n, t_poly.n + z_poly.n}));
@@ -863,6 +914,7 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   const int npts = order == 0 ? 1 : 2;
   const FrE xi2 = F.mul(xi, xi);
   std::vector<DVec> wq(npts);
+  std::vector<int> wq_early(npts, -1);
   std::vector<std::array<FrE, 2>> rbs(npts);
   for (int k = 0; k < npts; k++) {
     DVec p = be.zeros(D + 1);
@@ -886,14 +938,31 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     poly_div_linear(ctx, curve, p.p, D + 1, reinterpret_cast<const uint64_t*>(pts[k].data()), qv.p, nullptr);
     wq[k] = qv;
     rbs[k] = rb;
+    if (k + 1 < npts) wq_early[k] = start_early(-1, qv);            // under the next point's combination + division
   }
   {
-    std::vector<size_t> offs(npts, 0), ns(npts, D);
+    std::vector<size_t> offs, ns;
     std::vector<const uint64_t*> ptrs;
-    for (int k = 0; k < npts; k++) ptrs.push_back(wq[k].p);
-    std::vector<uint64_t> wjac(npts * jw64);
+    std::vector<int> at(npts, -1);
+    for (int k = 0; k < npts; k++)
+      if (wq_early[k] < 0) {
+        at[k] = (int)ptrs.size();
+        offs.push_back(0);
+        ns.push_back(D);
+        ptrs.push_back(wq[k].p);
+      }
+    std::vector<uint64_t> wjac(npts * jw64), part(std::max<size_t>(ptrs.size(), 1) * jw64);
     tm.open_points += (uint64_t)npts * D;
-    msm_run_batch(ctx, powers_g, npts, offs.data(), ptrs.data(), ns.data(), true, wjac.data());
+    msm_run_batch(ctx, powers_g, ptrs.size(), offs.data(), ptrs.data(), ns.data(), true, part.data());
+    for (int k = 0; k < npts; k++) {
+      if (wq_early[k] >= 0) {
+        ZKP_HIP(hipStreamWaitEvent(st, ctx->cur->ws[early[wq_early[k]].ws].done, 0));
+        ZKP_HIP(hipStreamSynchronize(st));
+        memcpy(wjac.data() + k * jw64, ix->early_pinned + (size_t)wq_early[k] * 24, jw64 * 8);
+      } else {
+        memcpy(wjac.data() + k * jw64, part.data() + (size_t)at[k] * jw64, jw64 * 8);
+      }
+    }
     out->num_opening_proofs = (uint32_t)npts;
     for (int k = 0; k < npts; k++) {
       std::vector<uint64_t> pt(wjac.begin() + k * jw64, wjac.begin() + (k + 1) * jw64);
