@@ -869,7 +869,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
   const int into = ctx->msm_acc_into;
   ctx->msm_defer_reduce = false;
   ctx->msm_acc_into = -1;
-  ZKP_REQUIRE(!(defer || into >= 0) || (n > 0 && !be->var && !(defer && into >= 0)), ZKP_ERR_BAD_ARG);
+  ZKP_REQUIRE(!(defer || into >= 0) || (n > 0 && !be->var && be->group == 1 && !(defer && into >= 0)), ZKP_ERR_BAD_ARG);   // G1 only (msm_acc.hip)
   // sort_src: workspace whose sorted entries + task schedule this MSM reuses (same scalars, window configuration and identity
   // pattern); sort_src == ws_idx = the MSM that ran on this workspace just before (A -> L on one stream)
   const bool reuse = sort_src >= 0;

@@ -119,12 +119,11 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   r.store(out);
 #elif ZKP_CFG_GROUP == 2 && defined(ZKP_ACC_UNSAT_G2)
   // G2 (BN254): Fq2 accumulator on unsaturated limbs, schoolbook products with lazily reduced sums (unsat_dev.hpp)
+  // (no bucket chaining for G2 — msm.hip refuses it: loading a stored bucket in this prologue took the kernel from 213 to 256 VGPRs,
+  //  2 -> 1 waves per SIMD, 1.24 -> 1.39 ms per B-query, for a path no caller uses)
   XYZZu2<CfgFq> acc;
   acc.inf = true;
-  if (init && !(d >> 31)) {
-    const BkPoint<F> b0 = BkPoint<F>::load(out);
-    if (!b0.is_inf()) acc = b0.v;
-  }
+  (void)init;
   for (uint32_t e = e0; e < e1; e++) {
     uint32_t v = vq.get(e, e0);
     Affine<F> p = Affine<F>::ZKP_GATHER(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   r.v = acc;
   r.store(out);
 #else
-  XYZZ<F> acc = (init && !(d >> 31)) ? BkPoint<F>::load(out).to_sat() : XYZZ<F>::inf();
+  XYZZ<F> acc = (ZKP_CFG_GROUP == 1 && init && !(d >> 31)) ? BkPoint<F>::load(out).to_sat() : XYZZ<F>::inf();
   // (a software-pipelined gather of entry e+1 was tried twice — G1: +20 VGPRs -> spills; G2 after the redo split:
   //  276 VGPRs -> 1 wave/SIMD, or 256 with launch bounds — no gain either time: the gather latency is covered)
   for (uint32_t e = e0; e < e1; e++) {
