@@ -274,7 +274,9 @@ int32_t zkp_groth16_assemble(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* su
  *                                   plus the circuit matrices;
  *   zkp_groth16_prove_partials_dev  witness map (replicated) + the five partial MSMs of this rank; r, s (host, Montgomery)
  *                                   must be the same on every rank.  partials_dev (DEVICE, zkp_groth16_partials_bytes()
- *                                   bytes: 5 XYZZ slots A|B1|B2|H|L) is complete when the call returns;
+ *                                   bytes: 5 XYZZ slots A|B1|B2|H|L) is complete when the call returns; only the slot-wise
+ *                                   SUMS over the ranks are specified — since round 3 the H MSM reduces L's buckets
+ *                                   together with its own (slot H = h_acc + l', slot L = the identity; C uses their sum);
  *   -- ncclAllGather(partials_dev -> gathered_dev, world x partials bytes) over RCCL, by the caller --
  *   zkp_groth16_fold_assemble_dev   slot-wise sum over the ranks (EC addition is not an RCCL reduction op) + assembly of
  *                                   prover.rs:192-210 -> proof_out (host).
