@@ -813,6 +813,13 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
 void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scalars_dev, size_t n, bool montgomery,
              uint64_t* out_xyz_host, void* out_dev_xyzz, float* ms_accumulate, uint64_t* n_entries, int ws_idx,
              int sort_src, float* ms_scan, int l1_src) {
+  struct ChainReset {                // one-shot requests: never leak into a later MSM, whatever this call throws (bad handle, ...)
+    zkp_ctx* c;
+    ~ChainReset() {
+      c->msm_defer_reduce = false;
+      c->msm_acc_into = -1;
+    }
+  } chain_reset{ctx};
   auto be = get_bases(ctx, handle);
   msm_run_entry(ctx, be.get(), offset, scalars_dev, n, montgomery, out_xyz_host, out_dev_xyzz, ms_accumulate, n_entries,
                 ws_idx, sort_src, ms_scan, l1_src);

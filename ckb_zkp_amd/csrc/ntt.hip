@@ -31,8 +31,17 @@
 namespace zkp {
 
 constexpr int NTT_SMAX = 7;            // max radix bits per pass
-constexpr int NTT_TILE_LOG = 10;       // elements per LDS tile (1024 * 32 B = 32 KiB)
-constexpr int NTT_THREADS = 256;
+#ifndef ZKP_NTT_TILE_LOG
+#define ZKP_NTT_TILE_LOG 10
+#endif
+#ifndef ZKP_NTT_THREADS
+#define ZKP_NTT_THREADS 256
+#endif
+// (round 3, stand-alone fft at 2^20 / 2^22 / 2^23 — tools/ntt_time.py: 1024 elements x 256 threads 0.164 / 0.640 / 1.225 ms; 512 x 128:
+//  0.195 / 0.668 / 1.250; 512 x 256: 0.175 / 0.688 / 1.314; 1024 x 512: 0.165 / 0.657 / 1.259; 2048 x 512: 0.181 / 0.770 / 1.497.
+//  At 2^23 a pass runs at 74 % of its VALU-instruction bound, at 2^20 at 50 %: per-launch ramp, not the tile shape, is what is left.)
+constexpr int NTT_TILE_LOG = ZKP_NTT_TILE_LOG;       // elements per LDS tile (1024 * 32 B = 32 KiB)
+constexpr int NTT_THREADS = ZKP_NTT_THREADS;
 constexpr int NTT_SUB_LOG = 7;         // sub-FFT twiddle table covers R <= 2^7
 constexpr int NTT_FULL_MAX_LOG = 24;   // full-size twiddle / coset tables up to this domain size (32 B * N each)
 constexpr int NTT_MAX_BATCH = 4;       // independent transforms per launch (blockIdx.y)
