@@ -201,6 +201,10 @@ class DeviceShardedGroth16Prover:
             dev = device if device is not None else torch.device("cuda", ctx.device)
             self._torch_bufs = (torch.zeros(self.pb, dtype=torch.uint8, device=dev),
                                 torch.zeros(self.pb * world, dtype=torch.uint8, device=dev))
+            # torch fills them on ITS stream, the library writes them on its own: without this the zero fill of a fresh process
+            # (torch's first kernel, late) could land on top of the first proof's partial sums — seen as a wrong FIRST proof in
+            # 4 of 10 runs of tests/dist_worker_gpu.py with three ranks on one GPU
+            torch.cuda.current_stream(dev).synchronize()
         else:
             self._raw = ctx.dev_alloc(self.pb)
 
