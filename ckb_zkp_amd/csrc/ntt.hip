@@ -431,7 +431,9 @@ ZKP_DEV Fu<P> ntt2_factor(const uint32_t* p) {
   return Fu<P>::from_words(t.v, 0);
 }
 
-template <class P>
+// TILE_C: the tile size as a compile-time constant (every domain >= 2^NTT_TILE_LOG has full tiles) so that the limb-plane offsets
+// l * PLANE fold into the ds_read / ds_write offset fields instead of one v_add per limb and access; 0 = read it from the arguments
+template <class P, int TILE_C>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass2_kernel(NttPassArgs a) {
   using F = Fp<P>;
   using U = Fu<P>;
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass2_kernel(NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int S = a.S, logC = a.logC;
   const int R = 1 << S, C = 1 << logC;
-  const int TILE = R << logC;
+  const int TILE = TILE_C ? TILE_C : (R << logC);
   const int PLANE = NTT2_PLANE(TILE);
   uint32_t* tw_l = lds + UL * PLANE;               // R/2 twiddles, < 2p, AoS (broadcast reads)
   const uint32_t ncols = 1u << (a.log_n - S);
@@ -574,8 +576,11 @@ template <class P>
 static void ntt_launch(hipStream_t st, const NttPassArgs& a, uint32_t grid, int count) {
   const size_t tile = (size_t)1 << (a.S + a.logC);
   const size_t tw_bytes = ((size_t)1 << a.S) / 2 * 4 * Fu<P>::L + 32;
-  if (ntt_v2())
-    hipLaunchKernelGGL(ntt_pass2_kernel<P>, dim3(grid, count), dim3(NTT_THREADS), NTT2_PLANE(tile) * 4 * Fu<P>::L + tw_bytes, st, a);
+  if (ntt_v2() && tile == ((size_t)1 << NTT_TILE_LOG))
+    hipLaunchKernelGGL((ntt_pass2_kernel<P, (1 << NTT_TILE_LOG)>), dim3(grid, count), dim3(NTT_THREADS),
+                       NTT2_PLANE(tile) * 4 * Fu<P>::L + tw_bytes, st, a);
+  else if (ntt_v2())
+    hipLaunchKernelGGL((ntt_pass2_kernel<P, 0>), dim3(grid, count), dim3(NTT_THREADS), NTT2_PLANE(tile) * 4 * Fu<P>::L + tw_bytes, st, a);
   else
     hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(grid, count), dim3(NTT_THREADS), tile * 32 + tw_bytes, st, a);
 }
