@@ -344,8 +344,10 @@ def parameters_to_bytes(p: dict, curve) -> bytes:
 
 
 def parameters_from_bytes(b: bytes, curve, checked: bool = True) -> dict:
-    """`Parameters::deserialize`; checked=False = `deserialize_unchecked` (a trusted multi-million-point key: the
-    subgroup test costs one 255-bit scalar multiplication per point)"""
+    """`Parameters::deserialize`; checked=False = `deserialize_unchecked`.  This is the pure-Python restatement (a big-integer
+    square root and, when checked, a 255-step affine double-and-add PER POINT): the reference for small keys and tests.  A real key
+    goes through `parameters_from_bytes_abi`, which decompresses and subgroup-checks on the device (zkp_g*_decompress,
+    zkp_g*_subgroup_check): 2^20-point queries in well under a second, checked."""
     c = get_curve(curve)
     n = _fq_bytes(c)
     r = _Reader(b)
