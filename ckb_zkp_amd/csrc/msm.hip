@@ -1022,8 +1022,9 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     bws.chain_nb = 0;
     const bool timed = ms_accumulate && ctx->profiling;
     if (timed) ZKP_HIP(hipEventRecord(ctx->ev2, st));
+    static const uint32_t force_redo = getenv("ZKP_DEBUG_FORCE_REDO") && atoi(getenv("ZKP_DEBUG_FORCE_REDO")) != 0 ? 2u : 0u;   // tests
     vt->accumulate(st, be->table, sorted_vals, desc, toff + nb, max_tasks, buckets, task_partial,
-                   ws.redo.as<uint32_t>((size_t)max_tasks + 1), init);
+                   ws.redo.as<uint32_t>((size_t)max_tasks + 1), init | force_redo);
     if (timed) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
       ZKP_HIP(hipEventSynchronize(ctx->ev3));

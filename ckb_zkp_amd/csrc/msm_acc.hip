@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   // G1: accumulate on unsaturated limbs (unsat_dev.hpp); the window table and the buckets keep the saturated layout
   XYZZu<CfgFq> acc;
   acc.inf = true;
-  if (init && !(d >> 31)) {                             // bucket chaining: continue from the bucket another MSM left here
+  if ((init & 1u) && !(d >> 31)) {                      // bucket chaining: continue from the bucket another MSM left here
     const BkPoint<F> b0 = BkPoint<F>::load(out);
     if (!b0.is_inf()) acc = b0.v;
   }
@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
     const Fu<CfgFq> ux = Fu<CfgFq>::from_sat(p.x), uy = Fu<CfgFq>::from_sat(p.y);
     xyzz_madd_u<CfgFq>(acc, ux, uy, 0u - (v >> 31));   // the digit's sign goes into the formulas (R = +-S2 - Y1)
   }
-  if (xyzz_u_degenerate<CfgFq>(acc)) {
+  // (init bit 1, ZKP_DEBUG_FORCE_REDO: every eighth task takes the exact path as well — the tests exercise the redo kernel, with
+  //  and without chaining, on ordinary inputs)
+  if (xyzz_u_degenerate<CfgFq>(acc) || ((init & 2u) && (t & 7u) == 0)) {
     // some operand equalled +-accumulator (doubling / cancellation; zz == 0 from then on): the whole task goes to the exact
     // kernel below instead of carrying the exceptional formulas — or a test per addition — through the hot loop
     redo[1 + atomicAdd(redo, 1u)] = id;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
     using U = Fu<CfgFq>;
     xyzz_madd_u2<CfgFq>(acc, U::from_sat(p.x.c0), U::from_sat(p.x.c1), U::from_sat(p.y.c0), U::from_sat(p.y.c1), 0u - (v >> 31));
   }
-  if (xyzz_u2_degenerate<CfgFq>(acc)) {
+  if (xyzz_u2_degenerate<CfgFq>(acc) || ((init & 2u) && (t & 7u) == 0)) {
     redo[1 + atomicAdd(redo, 1u)] = id;
     return;
   }
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, MINW) void accumulate_kernel(const char* __res
   r.v = acc;
   r.store(out);
 #else
-  XYZZ<F> acc = (ZKP_CFG_GROUP == 1 && init && !(d >> 31)) ? BkPoint<F>::load(out).to_sat() : XYZZ<F>::inf();
+  XYZZ<F> acc = (ZKP_CFG_GROUP == 1 && (init & 1u) && !(d >> 31)) ? BkPoint<F>::load(out).to_sat() : XYZZ<F>::inf();
   // (a software-pipelined gather of entry e+1 was tried twice — G1: +20 VGPRs -> spills; G2 after the redo split:
   //  276 VGPRs -> 1 wave/SIMD, or 256 with launch bounds — no gain either time: the gather latency is covered)
   for (uint32_t e = e0; e < e1; e++) {
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(64) void accumulate_redo_kernel(const char* __restr
     const uint32_t e0 = td.x, e1 = e0 + td.y;
     const uint32_t d = td.z;
     // (the fast kernel did not store anything for this task: with bucket chaining the bucket still holds the other MSM's value)
-    XYZZ<F> acc = (init && !(d >> 31)) ? BkPoint<F>::load(buckets + (size_t)d * BkPoint<F>::BYTES).to_sat() : XYZZ<F>::inf();
+    XYZZ<F> acc = ((init & 1u) && !(d >> 31)) ? BkPoint<F>::load(buckets + (size_t)d * BkPoint<F>::BYTES).to_sat() : XYZZ<F>::inf();
     for (uint32_t e = e0; e < e1; e++) {
       uint32_t v = vals[e];
       Affine<F> p = Affine<F>::load(table + (size_t)(v & idx_mask) * Affine<F>::BYTES);

@@ -263,7 +263,9 @@ def test_schedule_switches_do_not_change_the_proof():
     base = _proofs_in_subprocess(_SWITCH_CODE)
     for sw in ({"ZKP_CHAIN_LH": "0"}, {"ZKP_SHARE_L1": "0"}, {"ZKP_SHARE_B_SORT": "0", "ZKP_SHARE_AL_SORT": "0"},
                {"ZKP_SORT_STAGED": "0"}, {"ZKP_SINGLE_STREAM": "1"}, {"ZKP_LATENCY_PLAN": "0"}, {"ZKP_TABLE_K": "2"},
-               {"ZKP_NTT_V2": "0"}, {"ZKP_NTT_FULL": "0"}, {"ZKP_NTT_FUSE": "0"}):
+               {"ZKP_NTT_V2": "0"}, {"ZKP_NTT_FULL": "0"}, {"ZKP_NTT_FUSE": "0"},
+               # every eighth accumulate task through the exact (redo) kernel: on top of chained buckets, and without chaining
+               {"ZKP_DEBUG_FORCE_REDO": "1"}, {"ZKP_DEBUG_FORCE_REDO": "1", "ZKP_CHAIN_LH": "0"}):
         assert _proofs_in_subprocess(_SWITCH_CODE, **sw) == base, sw
 
 
