@@ -26,6 +26,36 @@ def test_constants_rederived():
         [3, 5, 15, 15, 16, 17, 18]                      # BASELINE.md §2 / SURVEY §2.2
 
 
+def test_public_known_answers_pin_the_curve_arithmetic():
+    """Values published OUTSIDE this repository and the reference (the reference's tests hold no vectors for this path): the
+    alt_bn128 / BN254 moduli, generators and 2*G1 of EIP-196 / EIP-197, the BLS12-381 moduli and G1 generator of the IETF
+    pairing-friendly-curves draft.  They pin the oracle's field and group arithmetic; everything else is checked against it."""
+    from oracle.pyref.curves import Group
+    bn, bls = OC["bn254"], OC["bls12_381"]
+    assert bn.q == 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    assert bn.r == 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    assert tuple(bn.g1_gen) == (1, 2)
+    g1 = Group(bn, 1)
+    two_g = g1.add(g1.gen, g1.gen)                                   # EIP-196 test vector (ecAdd of the generator with itself)
+    assert two_g == (0x030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3,
+                     0x15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4)
+    assert g1.mul(g1.gen, 2) == two_g and g1.mul(g1.gen, bn.r) is None and g1.mul(g1.gen, bn.r + 2) == two_g
+    assert (tuple(bn.g2_gen[0]), tuple(bn.g2_gen[1])) == (                                               # EIP-197
+        (10857046999023057135944570762232829481370756359578518086990519993285655852781,
+         11559732032986387107991004021392285783925812861821192530917403151452391805634),
+        (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+         4082367875863433681332203403145435568316851327593401208105741076214120093531))
+    g2 = Group(bn, 2)
+    assert g2.on_curve(g2.gen) and g2.mul(g2.gen, bn.r) is None
+    assert bls.q == 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    assert bls.r == 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    assert tuple(bls.g1_gen) == (
+        0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
+        0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
+    for grp in (Group(bls, 1), Group(bls, 2)):
+        assert grp.on_curve(grp.gen) and grp.mul(grp.gen, bls.r) is None
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_ntt_golden(curve):
     c = get_curve(curve)
