@@ -13,8 +13,13 @@ collective); `value` = proofs of all ranks / max-over-ranks time.
 
 The JSON line also carries
   roofline      the dominant kernel (MSM bucket accumulation): algorithmic HBM bytes per launch / HIP-event time
-  cpu_baseline  the C++ restatement of the reference algorithm (oracle/cpu, "port") on the host cores,
-                on a bounded smaller instance, scaled linearly to the 2^20 instance (rank 0, N=1 only).
+  cpu_baseline  the C++ restatement of the reference algorithm (oracle/cpu, "port") on the host cores: the full 2^20 instance
+                when the host proves it in seconds (the GPU box: 256 threads, 2.8 s), else a 2^16 sample scaled linearly
+                (rank 0, N=1 only); the device proof and witness map of the same (r, s) are compared with the port's.
+  hbm_peak_measured  an on-box streaming copy kernel (zkp_bench_hbm_copy) next to the nominal 8 TB/s
+and, at N=1 on the default BN254 2^20 line, one block per further BASELINE config, each with its own value, roofline, valu_roof,
+cpu_baseline and full-instance parity_check:  marlin_config4 (configs[3]), bls12_381_2p22 (configs[2]),
+bn254_2p24_single_gpu (configs[4] on one GPU), bn254_2p20_skewed_witness (50 % of aux in {0,1}).
 """
 from __future__ import annotations
 
@@ -287,6 +292,231 @@ def bench_marlin(ctx, curve="bn254", samples=87381, reps=3, verify=True, cpu=Fal
                     "polynomial, blinders) sampled before it"}
 
 
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def make_rand_fr(c, seed):
+    from ckb_zkp_amd import codec
+    rng = np.random.default_rng(seed)
+
+    def rand_fr():
+        v = int.from_bytes(rng.bytes(32), "little") % c.r
+        return codec.fr_to_mont([v], c)[0]
+    return rand_fr
+
+
+def hbm_peak_block(ctx):
+    """the on-box streaming-copy bandwidth next to the nominal 8 TB/s (zkp_bench_hbm_copy, 2 x 2 GiB buffers)."""
+    g = ctx.bench_hbm_copy(2 << 30)
+    return {"value": round(g, 1), "unit": "GB/s", "nominal": 8000.0, "frac_of_nominal": round(g / 8000.0, 4),
+            "note": "zkp_bench_hbm_copy: grid-stride dwordx4 copy kernel between two 2 GiB buffers (read + written bytes / HIP-event "
+                    "time, best of three grids), measured in this process; every roofline block quotes its fraction of BOTH peaks"}
+
+
+def with_measured(block, hbm_meas):
+    """adds the fraction of the MEASURED copy peak next to `frac` (of the nominal 8 TB/s)"""
+    if block and hbm_meas and block.get("achieved") is not None:
+        block["peak_measured"] = hbm_meas["value"]
+        block["frac_of_measured_peak"] = round(block["achieved"] / hbm_meas["value"], 5)
+    return block
+
+
+def accumulate_roofline(ctx, pk, c, inst, step, hbm_meas, traffic=None, traffic_src=None):
+    """dominant kernel (bucket accumulation): algorithmic HBM bytes per launch / HIP-event time, measured live on the library's
+    streams (zkp_set_profiling).  -> (roofline dict, last profiled phase timings)"""
+    ctx.set_profiling(True)
+    acc_ms, launches, tm_last = 0.0, 0, None
+    for _ in range(2):
+        step()
+        tm_last = pk.last_timing()
+        acc_ms += tm_last["ms_msm_accumulate"]
+        launches += tm_last["msm_accumulate_launches"]
+    ctx.set_profiling(False)
+    fq = c.fq_limbs * 8
+    nz = inst.num_inputs + inst.num_aux
+    # algorithmic bytes (BASELINE.md §3): scalars read once (32 B) + affine bases read once, per MSM
+    msm_bytes = [(nz + 4) * (32 + 2 * fq), (nz + 4) * (32 + 2 * fq), (nz + 4) * (32 + 4 * fq),
+                 (pk.domain_size - 1) * (32 + 2 * fq), (inst.num_aux + 4) * (32 + 2 * fq)]
+    bytes_per_launch = sum(msm_bytes) / max(tm_last["msm_accumulate_launches"], 1)
+    avg_ms = acc_ms / max(launches, 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "accumulate_kernel (MSM bucket accumulation, 5 launches/proof)",
+                "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                "traffic": traffic, "traffic_kind": "recorded" if traffic is not None else None, "traffic_source": traffic_src,
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "note": "integer-VALU bound (DESIGN.md).  traffic is RECORDED, not measured by this run: PMC counters cannot be read "
+                        "from inside the process, the figure is FETCH_SIZE*2 + WRITE_SIZE per launch from the separate rocprofv3 "
+                        "--pmc passes of this same command committed under profiles/ (the window-table design gathers each base "
+                        "W=13 times at 128-B fabric granularity)"}
+    return with_measured(roofline, hbm_meas), tm_last
+
+
+def valu_roof_block(ctx, c, phases, ntt_gmul=None):
+    """the binding roof: integer VALU.  Montgomery products/s sustained by the accumulate kernels vs the rate of the same
+    multipliers in a pure multiply loop on every CU (zkp_bench_mulmod, measured now)"""
+    ceil_u = ctx.bench_mulmod(c, 1, True)
+    ceil_s = ctx.bench_mulmod(c, 1, False)
+    ceil_fr = ctx.bench_mulmod(c, 0, True)                # the NTT products run on the unsaturated multiplier since round 3
+    g1 = [0, 1, 3, 4]
+    t_g1 = sum(phases["ms_msm_acc"][i] for i in g1)
+    e_g1 = sum(phases["msm_entries"][i] for i in g1)
+    t_g2, e_g2 = phases["ms_msm_acc"][2], phases["msm_entries"][2]
+    # product-equivalents of multiplier work (L*L partial products + L*L reduction products = one Montgomery product):
+    # G1 madd-2008-s with y3 as one lazily reduced sum of two products: 9.5; G2 with schoolbook Fq2 products as
+    # lazily reduced sums (two reductions per Fq2 product, one per component of y3): 27.6  (DESIGN.md, MSM section)
+    a1 = 9.5 * e_g1 / (t_g1 * 1e-3) / 1e9 if t_g1 > 0 else 0.0
+    a2 = 27.6 * e_g2 / (t_g2 * 1e-3) / 1e9 if t_g2 > 0 else 0.0
+    out = {"unit": "1e9 Montgomery products/s",
+           "g1_accumulate": {"achieved": round(a1, 1), "ceiling": round(ceil_u, 1), "frac": round(a1 / ceil_u, 3),
+                             "multiplier": "unsaturated 29/28-bit limbs (unsat_dev.hpp)"},
+           "g2_accumulate": {"achieved": round(a2, 1), "ceiling": round(ceil_u, 1), "frac": round(a2 / ceil_u, 3),
+                             "multiplier": "unsaturated limbs, schoolbook Fq2 with lazily reduced sums (unsat_dev.hpp)"},
+           "saturated_fq_ceiling": round(ceil_s, 1), "fr_ceiling": round(ceil_fr, 1),
+           "note": "ceilings = zkp_bench_mulmod (better of 2 and 4 independent product chains per lane, 8 workgroups per CU), "
+                   "measured in this process; the accumulate / NTT kernels are bound by this roof, not by HBM"}
+    if ntt_gmul is not None:
+        out["ntt"] = {"achieved": ntt_gmul, "ceiling": round(ceil_fr, 1), "frac": round(ntt_gmul / ceil_fr, 3),
+                      "multiplier": "tile unsaturated in LDS (decimation in time, no reductions between stages; ntt.hip)"}
+    return out
+
+
+def ntt_roofline(ctx, c, log_n, hbm_meas):
+    """NTT butterfly passes: 64*N algorithmic bytes per transform (read + write once); every pass moves 64*N too"""
+    from ckb_zkp_amd.api import NTT_FFT, NTT_COSET_IFFT
+    N = 1 << log_n
+    buf = ctx.to_device(np.frombuffer(np.random.default_rng(3).bytes(32 * N), dtype=np.uint64).reshape(-1, 4) >> np.uint64(3))
+    res = {}
+    for name, op in (("fft", NTT_FFT), ("coset_ifft", NTT_COSET_IFFT)):
+        for _ in range(3):
+            ctx.ntt_dev(c, buf, log_n, op)
+        reps = 30
+        ctx.timer_start()
+        for _ in range(reps):
+            ctx.ntt_dev(c, buf, log_n, op)
+        res[name] = ctx.timer_stop_ms() / reps
+    ctx.dev_free(buf)
+    passes = -(-log_n // 7)                                # LDS tiles of <= 2^7 points per pass (ntt.hip)
+    t_ntt = res["fft"]
+    ach = 64.0 * N / (t_ntt * 1e-3) / 1e9
+    mm = 0.5 * log_n + 0.25 * passes      # per pass: S/2 - 3/4 products in the tile (DIT: trivial twiddles fall in the first stages) + 1 at the store
+    out = {"bound": "hbm", "kernel": f"NTT pass kernels x{passes} (Stockham passes of one 2^{log_n} transform)",
+           "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+           "ms_per_transform": round(t_ntt, 4), "ms_coset_ifft": round(res["coset_ifft"], 4), "algorithmic_bytes": 64 * N,
+           "per_pass": {"passes": passes, "ms": round(t_ntt / passes, 4), "achieved": round(ach * passes, 1),
+                        "frac": round(ach * passes / 8000.0, 4),
+                        "frac_of_measured_peak": round(ach * passes / hbm_meas["value"], 4) if hbm_meas else None,
+                        "note": "one pass reads and writes the vector once (64*N bytes)"},
+           "valu": {"mulmods_per_element": round(mm, 2), "gmulmod_per_s": round(mm * N / (t_ntt * 1e-3) / 1e9, 1)}}
+    return with_measured(out, hbm_meas)
+
+
+def scan_roofline(phases, hbm_meas):
+    """MSM scalar scan (digit extraction fused into the level-1 histogram + scatter passes of the bucket sort)"""
+    if not phases or phases.get("ms_msm_scan", 0) <= 0:
+        return None
+    ach = phases["msm_scan_bytes"] / (phases["ms_msm_scan"] * 1e-3) / 1e9
+    return with_measured({"bound": "hbm", "kernel": "sort_hist_kernel + count scan + sort_scatter_kernel (MSM scalar scan)",
+                          "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                          "ms": round(phases["ms_msm_scan"] / phases["msm_scan_launches"], 4),
+                          "algorithmic_bytes": int(phases["msm_scan_bytes"] / phases["msm_scan_launches"]),
+                          "note": "per MSM: scalars read by the level-1 histogram + scatter passes (32 B each) + 8 B per "
+                                  "(bucket, point) entry written"}, hbm_meas)
+
+
+def cpu_port_block(pk, params, inst, z, c, cores, runs, what, rand_fr):
+    """the C++ restatement (oracle/cpu) on the FULL instance: `runs` timed proofs on all host threads, and the device proof +
+    witness map of the same (r, s) compared with the port's limb for limb.  -> (cpu_baseline, parity_check)"""
+    from oracle import cpu_oracle
+    import statistics
+    r_fix, s_fix = rand_fr(), rand_fr()
+    d_out, d_inf = pk.prove_raw(z, r_fix, s_fix)
+    ts, c_out, c_inf, ph = [], None, None, None
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        c_out, c_inf, ph = cpu_oracle.groth16_prove(params, inst, z, r_fix, s_fix, threads=cores)
+        ts.append(time.perf_counter() - t0)
+    h_eq = bool(np.array_equal(pk.witness_map(z), cpu_oracle.witness_map(params, inst, z, threads=cores)))
+    parity = {"device_eq_cpu_port": bool(np.array_equal(d_out, c_out) and np.array_equal(d_inf, c_inf)),
+              "witness_map_eq_cpu_port": h_eq, "instance": what,
+              "note": "same (r, s): zkp_groth16_prove vs oracle/cpu groth16_prove, proof limbs + identity flags; "
+                      "zkp_groth16_witness_map vs the port's witness_map, all N coefficients"}
+    t_all = statistics.median(ts)
+    sample = (f"{what} ({inst.num_constraints()} constraints), median of {runs} run(s) {[round(x, 2) for x in ts]} s on {cores} "
+              "threads (no extrapolation)")
+    base = {"value": round(1.0 / t_all, 6), "unit": "proofs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+            "s_per_proof": round(t_all, 3),
+            "sample": sample + "; oracle/cpu = C++ restatement of ark-ec/ark-poly 0.2 (Pippenger with the arkworks window rule "
+                      "c = ln(n)+2, one thread per window like ark's rayon path: an MSM uses <= ceil(254/c)+1 ~ 17 threads however "
+                      "many cores the host has; radix-2 NTT), not the Rust binary",
+            "phase_ms": [round(x, 1) for x in ph.tolist()]}
+    return base, parity
+
+
+def config_block(ctx, curve, log_n, steps, warmup, hbm_meas, skewed=False, cpu_runs=1):
+    """One further BASELINE config (or the skewed-witness variant) measured like the primary line, on its own key: value,
+    ms_per_step, roofline, valu_roof, cpu_baseline and parity_check on the FULL instance.  The key is freed on return."""
+    from ckb_zkp_amd import codec, groth16
+    from ckb_zkp_amd.circuits import boolean_mimc_instance, mimc_chain_instance, samples_for_domain
+    from ckb_zkp_amd.params import get_curve
+    from oracle import cpu_oracle
+    c = get_curve(curve)
+    t_setup = time.time()
+    inst = boolean_mimc_instance(c, log_n) if skewed else mimc_chain_instance(c, samples_for_domain(log_n))
+    params = groth16.generate_parameters(ctx, c, inst, **TOXIC)
+    pk = groth16.ProvingKey(ctx, params, inst)
+    z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+    z_dev = ctx.to_device(z)
+    t_setup = time.time() - t_setup
+    log(f"[{curve} 2^{log_n}{' skewed' if skewed else ''}] instance + key + upload: {t_setup:.1f}s")
+    rand_fr = make_rand_fr(c, 4321 + log_n)
+    try:
+        def batch(k):
+            rs = np.stack([rand_fr() for _ in range(k)]), np.stack([rand_fr() for _ in range(k)])
+            return lambda: pk.prove_batch_raw([z_dev] * k, rs[0], rs[1])
+        batch(warmup)()
+        ctx.sync()
+        run = batch(steps)
+        t0 = time.perf_counter()
+        run()
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        step = lambda: pk.prove_raw(z_dev, rand_fr(), rand_fr(), z_on_device=True)
+        step()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        lat = (time.perf_counter() - t0) / 3
+        roofline, phases = accumulate_roofline(ctx, pk, c, inst, step, hbm_meas)
+        valu = valu_roof_block(ctx, c, phases)
+        cores = cpu_oracle.hardware_threads()
+        what = f"full 2^{log_n}-domain {'boolean-heavy (50 % of aux in {0,1}) ' if skewed else ''}instance"
+        cpu_baseline, parity = cpu_port_block(pk, params, inst, z, c, cores, cpu_runs, what, rand_fr)
+        out = {"workload": f"Groth16 prove, {'MiMC chain + booleans' if skewed else 'MiMC-chain'} R1CS, {inst.num_constraints()} "
+                           f"constraints (domain 2^{log_n}), {inst.num_aux} aux, {c.name}, 1xMI355X",
+               "value": round(steps / dt, 4), "unit": "proofs/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": round(dt / steps * 1e3, 3), "latency_ms": round(lat * 1e3, 3),
+               "table_plan": pk.table_plan(), "roofline": roofline, "roofline_scan": scan_roofline(phases, hbm_meas),
+               "valu_roof": valu, "cpu_baseline": cpu_baseline, "parity_check": parity,
+               "vs_cpu_port": round(steps / dt / cpu_baseline["value"], 1), "setup_s": round(t_setup, 1)}
+        if skewed:
+            out["witness"] = {"aux": inst.num_aux, "boolean_aux": inst.num_boolean,
+                              "frac_aux_in_0_1": round(inst.num_boolean / inst.num_aux, 4),
+                              "msm_entries": phases["msm_entries"],
+                              "note": "SURVEY §8(d) skewed variant: (1 - b) * b = 0 rows (gadgets/src/algebra/boolean.rs:83-90); zero scalars "
+                                      "drop out of the digit scan, the ones all land in bucket 1 of the first window"}
+        return out
+    finally:
+        ctx.dev_free(z_dev)
+        pk.free()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,16 +524,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log-n", type=int, default=20, help="QAP domain 2^k (k=20 is the BASELINE metric config)")
     ap.add_argument("--curve", default="bn254")
-    ap.add_argument("--cpu-log-n", type=int, default=16, help="size of the bounded cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one blocking zkp_groth16_prove_dev call per step")
     ap.add_argument("--mode", choices=["throughput", "shard"], default="throughput",
                     help="throughput (default, the BASELINE metric): independent proofs per GPU.  shard: ONE proof per step, every "
                          "query base-sharded over the ranks, partial sums all-gathered (RCCL) and folded — BASELINE configs[4]")
     ap.add_argument("--workload", choices=["groth16", "marlin"], default="groth16",
-                    help="groth16 (default, the BASELINE metric; its line also carries a short Marlin config-4 measurement "
-                         "unless --no-marlin) or marlin: BASELINE configs[3] only")
+                    help="groth16 (default, the BASELINE metric; its line also carries the other BASELINE configs as blocks "
+                         "unless --no-extra-configs / --no-marlin) or marlin: BASELINE configs[3] only")
     ap.add_argument("--no-marlin", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the blocks for BASELINE configs[2] (BLS12-381 2^22), configs[4] on one GPU (BN254 2^24) and the "
+                         "skewed-witness variant that the default N=1 BN254 2^20 line carries")
+    ap.add_argument("--extra", default="skewed,bls22,bn24", help="which extra blocks to run (comma-separated)")
+    ap.add_argument("--budget-s", type=float, default=1400.0,
+                    help="wall-clock budget of the whole run: an extra block is skipped (and says so) when the time already "
+                         "spent plus its estimate exceeds this")
     ap.add_argument("--devices", default="",
                     help="single-process multi-GPU only: comma-separated device ids for zkp_ctx_create_multi (default 0..gpus-1; "
                          "ids may repeat, e.g. 0,0,0 exercises the 3-rank path on a one-GPU box — not a multi-GPU measurement)")
@@ -311,6 +547,7 @@ def main():
                     help="TEST ONLY: every rank uses cuda:0 and the collectives run over gloo (exercises the N>1 code path "
                          "on a one-GPU box; the number it prints is not a multi-GPU measurement)")
     args = ap.parse_args()
+    t_start = time.time()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -362,11 +599,7 @@ def main():
     log(f"key upload + window-table precompute: {time.time()-t0:.1f}s ; domain=2^{pk.domain_size.bit_length()-1}")
     z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
     z_dev = ctx.to_device(z)                                    # inputs resident in HBM before the timed region
-    rng = np.random.default_rng(1234 + rank)
-
-    def rand_fr():
-        v = int.from_bytes(rng.bytes(32), "little") % c.r
-        return codec.fr_to_mont([v], c)[0]
+    rand_fr = make_rand_fr(c, 1234 + rank)
 
     def step():
         return pk.prove_raw(z_dev, rand_fr(), rand_fr(), z_on_device=True)
@@ -394,6 +627,20 @@ def main():
             return
         pk.prove_batch_raw([z_dev] * k, rs[0], rs[1])
 
+    # ---- N > 1: every rank proves the SAME (r, s) once before the timed region; the proofs must agree with rank 0's
+    scale_parity = None
+    if world > 1:
+        import torch.distributed as dist
+        fix = make_rand_fr(c, 99)
+        p_out, p_inf = pk.prove_raw(z_dev, fix(), fix(), z_on_device=True)
+        mine = torch.from_numpy(np.concatenate([p_out.view(np.int64), p_inf.astype(np.int64)]))
+        if not args.single_device_test:
+            mine = mine.cuda()
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        scale_parity = {"all_ranks_eq_rank0": bool(all(torch.equal(a, allp[0]) for a in allp)), "ranks": world,
+                        "note": "one proof with a fixed (r, s) per rank before the timed region, all-gathered and compared"}
+
     rs_warm, rs_timed = blinders(args.warmup), blinders(args.steps)
     steps(args.warmup, rs_warm)
     barrier()
@@ -407,6 +654,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    primary = args.log_n == 20 and c.name == "bn254"
+    solo = rank == 0 and world == 1
     # ---- single-proof latency: blocking zkp_groth16_prove_dev calls, one proof in flight (the latency-oriented stream plan)
     latency = None
     if rank == 0:
@@ -418,110 +667,26 @@ def main():
         latency = {"ms_per_proof": round((time.perf_counter() - t0) / 10 * 1e3, 3),
                    "note": "one proof in flight: zkp_groth16_prove_dev blocking calls (witness resident), host time incl. the read-back"}
 
-    # ---- roofline of the dominant kernel (bucket accumulation), measured live with HIP events on the ctx stream
-    roofline = None
-    phases = None
+    hbm_meas = roofline = phases = roofline_ntt = roofline_scan = valu_roof = with_h2d = None
     if rank == 0:
-        ctx.set_profiling(True)
-        acc_ms, launches, tm_last = 0.0, 0, None
-        for _ in range(2):
-            step()
-            tm_last = pk.last_timing()
-            acc_ms += tm_last["ms_msm_accumulate"]
-            launches += tm_last["msm_accumulate_launches"]
-        ctx.set_profiling(False)
-        phases = tm_last
-        fq = c.fq_limbs * 8
-        nz = inst.num_inputs + inst.num_aux
-        # algorithmic bytes: scalars read once (32 B) + affine bases read once, per MSM
-        msm_bytes = [(nz + 4) * (32 + 2 * fq), (nz + 4) * (32 + 2 * fq), (nz + 4) * (32 + 4 * fq),
-                     (pk.domain_size - 1) * (32 + 2 * fq), (inst.num_aux + 4) * (32 + 2 * fq)]
-        bytes_per_launch = sum(msm_bytes) / max(tm_last["msm_accumulate_launches"], 1)
-        avg_ms = acc_ms / max(launches, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        try:
+            hbm_meas = hbm_peak_block(ctx)
+        except Exception as e:
+            log("hbm copy peak failed:", repr(e))
         # HBM bytes per launch: PMC counters cannot be read from inside the process; they come from the separate
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command recorded under profiles/
         traffic, traffic_src = None, None
         here = os.path.dirname(os.path.abspath(__file__))
-        for name in ("r03_pmc_accumulate.json", "r02_pmc_accumulate.json", "r01_pmc_accumulate.json"):
+        for name in ("r04_pmc_accumulate.json", "r03_pmc_accumulate.json", "r02_pmc_accumulate.json", "r01_pmc_accumulate.json"):
             pmc = os.path.join(here, "profiles", name)
-            if args.log_n == 20 and c.name == "bn254" and os.path.exists(pmc):
+            if primary and os.path.exists(pmc):
                 traffic, traffic_src = json.load(open(pmc))["traffic_bytes_per_launch"], "profiles/" + name
                 break
-        roofline = {"bound": "hbm", "kernel": "accumulate_kernel (MSM bucket accumulation, 5 launches/proof)",
-                    "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4),
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "note": "integer-VALU bound (DESIGN.md); traffic = FETCH_SIZE*2 + WRITE_SIZE per launch (rocprofv3 PMC, profiles/): "
-                            "the window-table design gathers each base W=13 times at 128-B fabric granularity"}
-
-    # ---- north_star / SURVEY §8(d) items, measured live in this run (rank 0)
-    roofline_ntt = roofline_scan = valu_roof = with_h2d = None
-    if rank == 0:
-        from ckb_zkp_amd.api import NTT_FFT, NTT_COSET_IFFT
-        N = pk.domain_size
-        # (i) NTT butterfly passes: 64*N algorithmic bytes per transform (read + write once); every pass moves 64*N too
-        buf = ctx.to_device(np.frombuffer(np.random.default_rng(3).bytes(32 * N), dtype=np.uint64).reshape(-1, 4) >> np.uint64(3))
-        res_ntt = {}
-        for name, op in (("fft", NTT_FFT), ("coset_ifft", NTT_COSET_IFFT)):
-            for _ in range(3):
-                ctx.ntt_dev(c, buf, args.log_n, op)
-            reps = 30
-            ctx.timer_start()
-            for _ in range(reps):
-                ctx.ntt_dev(c, buf, args.log_n, op)
-            res_ntt[name] = ctx.timer_stop_ms() / reps
-        ctx.dev_free(buf)
-        passes = -(-args.log_n // 7)                           # LDS tiles of <= 2^7 points per pass (ntt.hip)
-        t_ntt = res_ntt["fft"]
-        ach = 64.0 * N / (t_ntt * 1e-3) / 1e9
-        roofline_ntt = {"bound": "hbm", "kernel": f"ntt_pass2_kernel x{passes} (Stockham passes of one 2^{args.log_n} transform)",
-                        "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                        "ms_per_transform": round(t_ntt, 4), "ms_coset_ifft": round(res_ntt["coset_ifft"], 4),
-                        "algorithmic_bytes": 64 * N,
-                        "per_pass": {"passes": passes, "ms": round(t_ntt / passes, 4),
-                                     "achieved": round(ach * passes, 1), "frac": round(ach * passes / 8000.0, 4),
-                                     "note": "one pass reads and writes the vector once (64*N bytes)"},
-                        # per pass: S/2 - 3/4 products in the tile (DIT: the trivial twiddles fall in the first stages) + 1 at the store
-                        "valu": {"mulmods_per_element": round(0.5 * args.log_n + 0.25 * passes, 2),
-                                 "gmulmod_per_s": round((0.5 * args.log_n + 0.25 * passes) * N / (t_ntt * 1e-3) / 1e9, 1)}}
-        # (ii) MSM scalar scan (digit extraction fused into the level-1 histogram + scatter passes of the bucket sort)
-        if phases and phases.get("ms_msm_scan", 0) > 0:
-            ach = phases["msm_scan_bytes"] / (phases["ms_msm_scan"] * 1e-3) / 1e9
-            roofline_scan = {"bound": "hbm", "kernel": "sort_hist_kernel + count scan + sort_scatter_kernel (MSM scalar scan)",
-                             "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                             "ms": round(phases["ms_msm_scan"] / phases["msm_scan_launches"], 4),
-                             "algorithmic_bytes": int(phases["msm_scan_bytes"] / phases["msm_scan_launches"]),
-                             "note": "per MSM: 2 x 32 B per scalar read (histogram pass + scatter pass) + 8 B per (bucket, point) entry written"}
-        # (iii) the binding roof: integer VALU.  Montgomery products/s sustained by the accumulate kernels vs the rate of
-        # the same multipliers in a pure multiply loop on every CU (zkp_bench_mulmod, measured now)
-        if phases:
-            ceil_u = ctx.bench_mulmod(c, 1, True)
-            ceil_s = ctx.bench_mulmod(c, 1, False)
-            ceil_fr = ctx.bench_mulmod(c, 0, True)                # the NTT products run on the unsaturated multiplier since round 3
-            g1 = [i for i in (0, 1, 3, 4)]
-            t_g1 = sum(phases["ms_msm_acc"][i] for i in g1)
-            e_g1 = sum(phases["msm_entries"][i] for i in g1)
-            t_g2, e_g2 = phases["ms_msm_acc"][2], phases["msm_entries"][2]
-            # product-equivalents of multiplier work (L*L partial products + L*L reduction products = one Montgomery product):
-            # G1 madd-2008-s with y3 as one lazily reduced sum of two products: 9.5; G2 with schoolbook Fq2 products as
-            # lazily reduced sums (two reductions per Fq2 product, one per component of y3): 27.6  (MSM section)
-            a1 = 9.5 * e_g1 / (t_g1 * 1e-3) / 1e9 if t_g1 > 0 else 0.0
-            a2 = 27.6 * e_g2 / (t_g2 * 1e-3) / 1e9 if t_g2 > 0 else 0.0
-            valu_roof = {"unit": "1e9 Montgomery products/s",
-                         "g1_accumulate": {"achieved": round(a1, 1), "ceiling": round(ceil_u, 1), "frac": round(a1 / ceil_u, 3),
-                                           "multiplier": "unsaturated 29/28-bit limbs (unsat_dev.hpp)"},
-                         "g2_accumulate": {"achieved": round(a2, 1), "ceiling": round(ceil_u, 1), "frac": round(a2 / ceil_u, 3),
-                                           "multiplier": "unsaturated limbs, schoolbook Fq2 with lazily reduced sums (unsat_dev.hpp)"},
-                         "ntt": {"achieved": roofline_ntt["valu"]["gmulmod_per_s"], "ceiling": round(ceil_fr, 1),
-                                 "frac": round(roofline_ntt["valu"]["gmulmod_per_s"] / ceil_fr, 3),
-                                 "multiplier": "tile unsaturated in LDS (decimation in time, no reductions between stages; ntt.hip ntt_pass2_kernel); "
-                                               "a stand-alone transform is bound by its 1024-workgroup grid on 768 slots and the load / store "
-                                               "phases, not by this roof — under the pipelined prover its VALU instruction count is what matters"},
-                         "saturated_fq_ceiling": round(ceil_s, 1),
-                         "note": "ceilings = zkp_bench_mulmod (better of 2 and 4 independent product chains per lane, 8 workgroups per CU), "
-                                 "measured in this process; the accumulate / NTT kernels are bound by this roof, not by HBM"}
-        # (iv) with the witness on the HOST: each proof's assignment crosses PCIe in front of its proof (pinned buffer)
+        roofline, phases = accumulate_roofline(ctx, pk, c, inst, step, hbm_meas, traffic, traffic_src)
+        roofline_ntt = ntt_roofline(ctx, c, args.log_n, hbm_meas)
+        roofline_scan = scan_roofline(phases, hbm_meas)
+        valu_roof = valu_roof_block(ctx, c, phases, roofline_ntt["valu"]["gmulmod_per_s"])
+        # with the witness on the HOST: each proof's assignment crosses PCIe in front of its proof (pinned buffer)
         try:
             zp = torch.from_numpy(z.view(np.int64)).pin_memory()
             k = args.steps
@@ -542,7 +707,7 @@ def main():
 
     # ---- second half of BASELINE.json's metric: one G1 MSM (uniform scalars, the H-query shape) in Mop/s
     msm_g1 = None
-    if rank == 0 and world == 1:
+    if solo:
         hb = ctx.upload_bases(c, 1, *params.h_query)
         n_msm = hb.n
         sc = np.frombuffer(np.random.default_rng(7).bytes(32 * n_msm), dtype=np.uint64).reshape(-1, 4).copy()
@@ -568,91 +733,78 @@ def main():
         ctx.dev_free(sc_dev)
         hb.free()
 
-    # ---- CPU baseline (rank 0, N=1 only): oracle/cpu port of the reference algorithm on a bounded sample
-    cpu_baseline = None
-    parity_check = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- CPU baseline + parity (rank 0, N=1 only): oracle/cpu port of the reference algorithm
+    cpu_baseline = parity_check = None
+    if solo and not args.no_cpu_baseline:
         from oracle import cpu_oracle
         import statistics
         cores = cpu_oracle.hardware_threads()
-        cpu_model = "unknown"
-        try:
-            for line in open("/proc/cpuinfo"):
-                if line.startswith("model name"):
-                    cpu_model = line.split(":", 1)[1].strip()
-                    break
-        except OSError:
-            pass
-
-        def timed(p_, i_, z_, threads, runs):
-            ts, ph = [], None
-            for _ in range(runs):
-                t0 = time.perf_counter()
-                _, _, ph = cpu_oracle.groth16_prove(p_, i_, z_, rand_fr(), rand_fr(), threads=threads)
-                ts.append(time.perf_counter() - t0)
-            return statistics.median(ts), ts, ph
-
-        k = min(args.cpu_log_n, args.log_n)
+        # probe a 2^16 sample first: a slow host (this container: 8 cores) gets the bounded, scaled sample instead of the full instance
+        k = min(16, args.log_n)
         inst_s = mimc_chain_instance(c, samples_for_domain(k))
         params_s = groth16.generate_parameters(ctx, c, inst_s, **TOXIC)
         z_s = codec.fr_to_mont(inst_s.z, c).reshape(-1, 4)
         scale_s = float(1 << (args.log_n - k))
-        # all host threads: probe on the small sample, then time the FULL instance (3 runs, median) when that fits the budget
-        t_probe, _, ph = timed(params_s, inst_s, z_s, cores, 1)
-        if k < args.log_n and t_probe * scale_s <= 12.0:
-            t_all, runs_all, ph = timed(params, inst, z, cores, 3)
-            scale_all = 1.0
-            sample_all = (f"full 2^{args.log_n}-domain instance ({inst.num_constraints()} constraints), median of 3 runs "
-                          f"{[round(x, 2) for x in runs_all]} s on {cores} threads (no extrapolation)")
+        t0 = time.perf_counter()
+        cpu_oracle.groth16_prove(params_s, inst_s, z_s, rand_fr(), rand_fr(), threads=cores)
+        t_probe = time.perf_counter() - t0
+        if t_probe * scale_s <= 12.0 * (1 << max(args.log_n - 20, 0)):
+            cpu_baseline, parity_check = cpu_port_block(pk, params, inst, z, c, cores, 3, f"full 2^{args.log_n}-domain instance", rand_fr)
         else:
-            t_all, runs_all, ph = timed(params_s, inst_s, z_s, cores, 3)
-            scale_all = scale_s
-            sample_all = (f"2^{k}-domain MiMC chain ({inst_s.num_constraints()} constraints), median of 3 runs "
-                          f"{[round(x, 2) for x in runs_all]} s on {cores} threads, scaled x{int(scale_s)} linearly")
-        # parity of THIS run: one (r, s), the device proof and the CPU port's proof of the same instance
-        # — the full 2^20 instance when the host is fast enough for it, else the bounded sample — must agree limb for limb
-        r_fix, s_fix = rand_fr(), rand_fr()
-        if scale_all == 1.0:
-            p_pk, p_params, p_inst, p_z, p_what = pk, params, inst, z, f"full 2^{args.log_n} instance"
-        else:
-            p_pk = groth16.ProvingKey(ctx, params_s, inst_s)
-            p_params, p_inst, p_z, p_what = params_s, inst_s, z_s, f"2^{k} sample"
-        d_out, d_inf = p_pk.prove_raw(p_z, r_fix, s_fix)
-        c_out, c_inf, _ = cpu_oracle.groth16_prove(p_params, p_inst, p_z, r_fix, s_fix, threads=cores)
-        h_eq = bool(np.array_equal(p_pk.witness_map(p_z), cpu_oracle.witness_map(p_params, p_inst, p_z, threads=cores)))
-        parity_check = {"device_eq_cpu_port": bool(np.array_equal(d_out, c_out) and np.array_equal(d_inf, c_inf)),
-                        "witness_map_eq_cpu_port": h_eq, "instance": p_what,
-                        "note": "same (r, s): zkp_groth16_prove vs oracle/cpu groth16_prove, proof limbs + identity flags; "
-                                "zkp_groth16_witness_map vs the port's witness_map, all N coefficients"}
-        if p_pk is not pk:
-            p_pk.free()
-        # one thread: the bounded sample, 3 runs, median, scaled linearly
-        t_one, runs_one, _ = timed(params_s, inst_s, z_s, 1, 3)
-        cpu_baseline = {"value": round(1.0 / (t_all * scale_all), 6), "unit": "proofs/s", "cores": cores, "kind": "port",
-                        "cpu_model": cpu_model,
-                        "threads_all": {"threads": cores, "proofs_per_s": round(1.0 / (t_all * scale_all), 6),
-                                        "s_per_proof": round(t_all * scale_all, 3), "sample": sample_all},
-                        "threads_1": {"threads": 1, "proofs_per_s": round(1.0 / (t_one * scale_s), 6),
-                                      "s_per_proof": round(t_one * scale_s, 2),
-                                      "sample": f"2^{k}-domain MiMC chain, median of 3 runs {[round(x, 2) for x in runs_one]} s "
-                                                f"on 1 thread, scaled x{int(scale_s)} linearly"},
-                        "sample": sample_all + "; oracle/cpu = C++ restatement of ark-ec/ark-poly 0.2 (Pippenger with the "
-                                  "arkworks window rule c = ln(n)+2, one thread per window like ark's rayon path: an MSM uses "
-                                  "<= ceil(254/c)+1 ~ 17 threads however many cores the host has; radix-2 NTT), not the Rust binary",
-                        "phase_ms": [round(x, 1) for x in ph.tolist()]}
+            pk_s = groth16.ProvingKey(ctx, params_s, inst_s)
+            cpu_baseline, parity_check = cpu_port_block(pk_s, params_s, inst_s, z_s, c, cores, 3, f"2^{k}-domain sample", rand_fr)
+            pk_s.free()
+            cpu_baseline["value"] = round(cpu_baseline["value"] / scale_s, 6)
+            cpu_baseline["s_per_proof"] = round(cpu_baseline["s_per_proof"] * scale_s, 3)
+            cpu_baseline["sample"] = f"scaled x{int(scale_s)} linearly from: " + cpu_baseline["sample"]
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            cpu_oracle.groth16_prove(params_s, inst_s, z_s, rand_fr(), rand_fr(), threads=1)
+            ts.append(time.perf_counter() - t0)
+        t_one = statistics.median(ts)
+        cpu_baseline["threads_1"] = {"threads": 1, "proofs_per_s": round(1.0 / (t_one * scale_s), 6),
+                                     "s_per_proof": round(t_one * scale_s, 2),
+                                     "sample": f"2^{k}-domain MiMC chain, median of 3 runs {[round(x, 2) for x in ts]} s on 1 thread, "
+                                               f"scaled x{int(scale_s)} linearly"}
 
-    marlin = None
     table_plan = pk.table_plan() if rank == 0 else None
-    if rank == 0 and world == 1 and not args.no_marlin and args.log_n == 20 and c.name == "bn254":
-        pk.free()                                              # the Groth16 key's window tables make room for the SRS
-        try:
-            marlin = bench_marlin(ctx, "bn254")
-        except Exception as e:                                 # never lose the Groth16 line to the secondary workload
-            marlin = {"error": repr(e)}
+    ctx.dev_free(z_dev)
+    marlin = None
+    extra = {}
+    if solo and primary:
+        pk.free()                                              # the primary key's window tables make room for the next workload
+        pk = None
+        if not args.no_marlin:
+            try:
+                marlin = bench_marlin(ctx, "bn254", cpu=not args.no_cpu_baseline)
+            except Exception as e:                             # never lose the Groth16 line to a secondary workload
+                marlin = {"error": repr(e)}
+        if not args.no_extra_configs:
+            # (name, key, curve, log_n, steps, warmup, skewed, cpu runs, estimated seconds on the GPU box)
+            plan = [("skewed", "bn254_2p20_skewed_witness", "bn254", 20, 24, 8, True, 1, 40),
+                    ("bls22", "bls12_381_2p22", "bls12_381", 22, 12, 4, False, 1, 150),
+                    ("bn24", "bn254_2p24_single_gpu", "bn254", 24, 6, 2, False, 1, 330)]
+            want = set(args.extra.split(","))
+            for name, key, cv, lg, st_, wu, sk, cr, est in plan:
+                if name not in want:
+                    continue
+                spent = time.time() - t_start
+                if spent + est > args.budget_s:
+                    extra[key] = {"skipped": f"{spent:.0f} s spent + {est} s estimated > --budget-s {args.budget_s:.0f}"}
+                    continue
+                try:
+                    t0 = time.time()
+                    extra[key] = config_block(ctx, cv, lg, st_, wu, hbm_meas, skewed=sk, cpu_runs=cr)
+                    extra[key]["block_s"] = round(time.time() - t0, 1)
+                    log(f"[{key}] {extra[key]['value']} proofs/s, parity {extra[key]['parity_check']['device_eq_cpu_port']}, "
+                        f"{extra[key]['block_s']} s")
+                except Exception as e:
+                    extra[key] = {"error": repr(e)}
     if rank == 0:
         proofs = args.steps * world
         out = {
-            "metric": "Groth16 proofs/sec (2^20 constraints, BN256)" if (args.log_n == 20 and c.name == "bn254")
+            "metric": "Groth16 proofs/sec (2^20 constraints, BN256)" if primary
             else f"Groth16 proofs/sec (2^{args.log_n} domain, {c.name})",
             "value": round(proofs / dt, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
@@ -663,10 +815,11 @@ def main():
                        "curve": c.name, "log_domain": args.log_n, "parallelism": f"independent proofs x{world}",
                        "table_plan": table_plan,
                        "pipelining": "none" if args.no_pipeline else f"{os.environ.get('ZKP_LANES', '8 (4 above 2^22)')} proofs in flight per GPU (zkp_groth16_prove_batch_dev), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}"},
-            "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_scan": roofline_scan, "valu_roof": valu_roof,
-            "with_h2d": with_h2d, "latency": latency, "cpu_baseline": cpu_baseline, "parity_check": parity_check,
-            "msm_g1": msm_g1, "marlin_config4": marlin,
-            "phases_ms": phases,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "hbm_peak_measured": hbm_meas,
+            "roofline_ntt": roofline_ntt, "roofline_scan": roofline_scan, "valu_roof": valu_roof,
+            "with_h2d": with_h2d, "latency": latency, "parity_check": parity_check, "scale_parity": scale_parity,
+            "msm_g1": msm_g1, "marlin_config4": marlin, **extra,
+            "phases_ms": phases, "bench_wall_s": round(time.time() - t_start, 1),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

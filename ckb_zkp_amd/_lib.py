@@ -168,6 +168,7 @@ SIGNATURES = {
     "zkp_fs_rng_sample_outside_domain": (C.c_int32, [vp, C.c_int, C.c_uint32, vp]),
     "zkp_merlin_oneshot": (C.c_int32, [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t]),
     "zkp_bench_mulmod": (C.c_int32, [vp, C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    "zkp_bench_hbm_copy": (C.c_int32, [vp, C.c_size_t, C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -189,6 +190,9 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
     if path is None:
         _lib = lib
     return lib
+
+
+ZKP_ERR_INVALID_POINT = -7        # include/zkp_accel.h zkp_status
 
 
 def check(status: int, where: str) -> None:

@@ -98,6 +98,12 @@ class Context:
                    "zkp_bench_mulmod")
         return g.value
 
+    def bench_hbm_copy(self, nbytes: int = 2 << 30) -> float:
+        """zkp_bench_hbm_copy: GB/s (read + written) of a streaming copy kernel on this device"""
+        g = C.c_double()
+        _lib.check(self.lib.zkp_bench_hbm_copy(self.h, nbytes, C.byref(g)), "zkp_bench_hbm_copy")
+        return g.value
+
     # ---- NTT (ark-poly EvaluationDomain ops)
     def ntt(self, curve, data: np.ndarray, op: int) -> np.ndarray:
         """data: (2^k, 4) uint64 Montgomery Fr; returns the transformed copy."""
@@ -167,7 +173,7 @@ class Context:
         bad = C.c_size_t(0)
         fn = self.lib.zkp_g1_decompress if group == 1 else self.lib.zkp_g2_decompress
         rc = fn(self.h, c.cid, _ptr(buf) if n else None, n, _ptr(xy), _ptr(inf), C.byref(bad))
-        if rc == -1 and n:
+        if rc == _lib.ZKP_ERR_INVALID_POINT:
             raise ValueError(f"malformed compressed point at index {bad.value}")
         _lib.check(rc, "zkp_decompress")
         return xy, inf
@@ -194,7 +200,7 @@ class Context:
         bad = C.c_size_t(0)
         fn = self.lib.zkp_g1_subgroup_check if group == 1 else self.lib.zkp_g2_subgroup_check
         rc = fn(self.h, c.cid, _ptr(xy) if n else None, None if infa is None else _ptr(infa), n, C.byref(bad))
-        if rc == -1 and n:
+        if rc == _lib.ZKP_ERR_INVALID_POINT:
             raise ValueError(f"point {bad.value} is not in the prime-order subgroup (or not on the curve)")
         _lib.check(rc, "zkp_subgroup_check")
 

@@ -157,3 +157,40 @@ def mimc_chain_instance(curve, n_samples: int, seed: int = 0xC0FFEE, with_witnes
     inst = R1csInstance(c, 1, num_aux, nc, csr_a, csr_b, csr_c, z)
     inst.constants, inst.preimages = consts, [(pre[2 * s], pre[2 * s + 1]) for s in range(S)]
     return inst
+
+
+def boolean_mimc_instance(curve, log_n: int, seed: int = 0xB001EA4, with_witness: bool = True) -> R1csInstance:
+    """SURVEY.md §8(d) "skewed variant": a satisfiable system of domain 2^log_n in which HALF of the aux variables are
+    booleans (the witness shape of SHA / range-check circuits): S' MiMC-5 samples (12 aux, 10 constraints each) followed by
+    nb = 12 S' bit variables, each with the booleanity row of the reference's `AllocatedBit::alloc`
+    (/root/reference/gadgets/src/algebra/boolean.rs:67-90): (1 - b) * b = 0, i.e. A = one - b, B = b, C = empty —
+    22 S' constraints + 1 input <= 2^log_n.  The bits come from the same counter PRF.  Half of the scalars of the A / B / L
+    MSMs are 0 or 1: half of them vanish and one bucket of the first window receives a quarter of all entries — the case the
+    0/1 fast paths and the bucket balancing exist for."""
+    c = get_curve(curve)
+    S = ((1 << log_n) - 1) // 22
+    base = mimc_chain_instance(c, S, seed=seed, with_witness=with_witness)
+    nb = 12 * S
+    one_m, neg_one_m = fr_to_mont([1], c)[0], fr_to_mont([c.r - 1], c)[0]
+    var = (1 + 12 * S + np.arange(nb)).astype(np.uint32)
+
+    def ext(csr, nnz_per_row, new_cols, new_cf):
+        ptr, col, cf = csr
+        p2 = np.concatenate([ptr, ptr[-1] + nnz_per_row * (1 + np.arange(nb, dtype=np.int64))]).astype(np.uint32)
+        return p2, np.concatenate([col, new_cols.astype(np.uint32)]), np.concatenate([cf, new_cf.reshape(-1, 4)])
+
+    a_cols = np.stack([np.zeros(nb, dtype=np.uint32), var], axis=1).reshape(-1)           # one - b
+    a_cf = np.tile(np.stack([one_m, neg_one_m]), (nb, 1))
+    csr_a = ext(base.csr("a"), 2, a_cols, a_cf)
+    csr_b = ext(base.csr("b"), 1, var, np.tile(one_m, (nb, 1)))
+    csr_c = ext(base.csr("c"), 0, np.zeros(0, dtype=np.uint32), np.zeros((0, 4), dtype=np.uint64))
+    z = None
+    if with_witness:
+        st, bits = (seed ^ 0xB175) & 0xFFFFFFFFFFFFFFFF, []
+        while len(bits) < nb:
+            st, w = splitmix64(st)
+            bits.extend((w >> k) & 1 for k in range(64))
+        z = base.z + bits[:nb]
+    inst = R1csInstance(c, 1, 12 * S + nb, 10 * S + nb, csr_a, csr_b, csr_c, z)
+    inst.num_boolean = nb
+    return inst

@@ -98,4 +98,55 @@ double bench_mulmod(zkp_ctx* ctx, int curve, int field, bool unsaturated) {
   return best;
 }
 
+// "also measure an on-box copy kernel and quote both" — the HBM bandwidth a plain streaming copy reaches on THIS
+// device, next to the nominal 8 TB/s: every lane moves 16 B per iteration (global_load_dwordx4 / global_store_dwordx4), a
+// grid-stride loop over a buffer much larger than the 256 MB of L2 + Infinity Cache, read once and written once.
+typedef uint32_t copy_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const copy_v4* __restrict__ src, copy_v4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+// -> GB/s (read + written bytes over the HIP-event time of `reps` back-to-back copies of `bytes` bytes)
+double bench_hbm_copy(zkp_ctx* ctx, size_t bytes) {
+  hipStream_t st = ctx->cur->stream;
+  int cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  bytes &= ~(size_t)0xFFF;
+  ZKP_REQUIRE(bytes >= (1u << 20), ZKP_ERR_BAD_ARG);
+  copy_v4 *src = nullptr, *dst = nullptr;
+  ZKP_HIP(hipMalloc(&src, bytes));
+  if (hipMalloc(&dst, bytes) != hipSuccess) {
+    (void)hipFree(src);
+    throw StatusError{ZKP_ERR_OOM};
+  }
+  const size_t n16 = bytes / 16;
+  double best = 0.0;
+  try {
+    ZKP_HIP(hipMemsetAsync(src, 0x5a, bytes, st));
+    ZKP_HIP(hipMemsetAsync(dst, 0, bytes, st));
+    for (int wg_per_cu : {8, 16, 32}) {                               // the best grid of the three is the device's figure
+      const int blocks = cus * wg_per_cu, reps = 5;
+      hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, st, src, dst, n16);   // warm-up
+      ZKP_HIP(hipEventRecord(ctx->ev2, st));
+      for (int r = 0; r < reps; r++) hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, st, src, dst, n16);
+      ZKP_HIP(hipEventRecord(ctx->ev3, st));
+      ZKP_HIP(hipEventSynchronize(ctx->ev3));
+      ZKP_HIP(hipGetLastError());
+      float ms = 0.f;
+      ZKP_HIP(hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3));
+      best = std::max(best, 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9);
+    }
+  } catch (...) {
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    throw;
+  }
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  return best;
+}
+
 }  // namespace zkp

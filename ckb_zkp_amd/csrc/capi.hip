@@ -1,5 +1,6 @@
 // extern "C" boundary (include/zkp_accel.h): argument checking, exception -> status mapping, host<->device
 // staging for the host-pointer variants.  No arithmetic lives here.
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
@@ -43,11 +44,13 @@ const char* zkp_status_string(int32_t s) {
     case ZKP_ERR_OOM: return "out of device memory";
     case ZKP_ERR_DEVICE: return "HIP device error / no gfx950 device (there is no CPU fallback)";
     case ZKP_ERR_BAD_HANDLE: return "bad handle";
+    case ZKP_ERR_INVALID_POINT: return "malformed point / not on the curve / not in the prime-order subgroup (InvalidData)";
     default: return "unknown status";
   }
 }
 
-const char* zkp_version(void) { return "zkp_accel 0.1 (gfx950)"; }
+// 0.2: ZKP_ERR_INVALID_POINT; partials slot 4 (L) = identity, slot 3 (H) = h + l (bucket chaining)
+const char* zkp_version(void) { return "zkp_accel 0.2 (gfx950)"; }
 
 int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
   if (!out) return ZKP_ERR_BAD_ARG;
@@ -416,13 +419,14 @@ int32_t zkp_g2_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz,
 }
 static int32_t decompress_any(zkp_ctx* ctx, zkp_curve_t curve, int group, const uint8_t* bytes, size_t n, uint64_t* xy,
                               uint8_t* inf, size_t* bad) {
+  if (bad) *bad = SIZE_MAX;                       // only ZKP_ERR_INVALID_POINT carries an index
   if (n && (!bytes || !xy || !inf)) return ZKP_ERR_BAD_ARG;
   size_t st = 0;
   const int32_t rc = guarded(ctx, [&] { st = points_decompress(ctx, curve, group, bytes, n, xy, inf); });
   if (rc != ZKP_OK) return rc;
   if (st) {
     if (bad) *bad = st - 1;
-    return ZKP_ERR_BAD_ARG;
+    return ZKP_ERR_INVALID_POINT;
   }
   return ZKP_OK;
 }
@@ -441,13 +445,14 @@ int32_t zkp_g2_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, con
   return guarded(ctx, [&] { points_compress(ctx, curve, 2, xy, inf, n, bytes); });
 }
 static int32_t subgroup_any(zkp_ctx* ctx, zkp_curve_t curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n, size_t* bad) {
+  if (bad) *bad = SIZE_MAX;
   if (n && !xy) return ZKP_ERR_BAD_ARG;
   size_t st = 0;
   const int32_t rc = guarded(ctx, [&] { st = points_subgroup_check(ctx, curve, group, xy, inf, n); });
   if (rc != ZKP_OK) return rc;
   if (st) {
     if (bad) *bad = st - 1;
-    return ZKP_ERR_BAD_ARG;
+    return ZKP_ERR_INVALID_POINT;
   }
   return ZKP_OK;
 }
@@ -593,6 +598,10 @@ int32_t zkp_marlin_prove(zkp_ctx* ctx, zkp_marlin_index* index, uint64_t powers_
 int32_t zkp_bench_mulmod(zkp_ctx* ctx, zkp_curve_t curve, int32_t field, int32_t unsaturated, double* out) {
   if (!out || (curve != ZKP_BN254 && curve != ZKP_BLS12_381) || field < 0 || field > 1) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { *out = bench_mulmod(ctx, curve, field, unsaturated != 0); });
+}
+int32_t zkp_bench_hbm_copy(zkp_ctx* ctx, size_t bytes, double* out) {
+  if (!out) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { *out = bench_hbm_copy(ctx, bytes); });
 }
 int32_t zkp_marlin_last_timing(zkp_ctx* ctx, zkp_marlin_timing* out) {
   if (!ctx || !out) return ZKP_ERR_BAD_ARG;

@@ -513,8 +513,10 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     float ms = 0.f, ms_sc = 0.f;
     uint64_t e = 0;
     tic();
+#ifdef ZKP_ABLATION   // timing ablation builds only (ZKP_BUILD_DEFS=-DZKP_ABLATION -> variants/<tag>/): WRONG proofs, never in the shipped library
     static const int skip_k8 = [] { const char* e = getenv("ZKP_DEBUG_SKIP_K8_MASK"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
-    ctx->dbg_skip_k8 = ((skip_k8 >> idx) & 1) && ctx->batch_mode;      // timing ablation: wrong proofs
+    ctx->dbg_skip_k8 = ((skip_k8 >> idx) & 1) && ctx->batch_mode;
+#endif
     msm_run(ctx, handle, 0, sc, n, true, nullptr, res + idx * slot, prof ? &ms : nullptr, &e, fan ? w : 0,
             fan ? sort_src : -1, prof ? &ms_sc : nullptr, fan ? l1_src : -1);
     ctx->dbg_skip_k8 = false;

@@ -47,6 +47,8 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
              uint64_t* n_entries = nullptr, int ws = 0, int sort_src = -1, float* ms_scan = nullptr, int l1_src = -1);
 // bench_kern.hip: sustained rate (1e9 products/s) of the library's Montgomery multipliers; field 0 = Fr, 1 = Fq
 double bench_mulmod(zkp_ctx* ctx, int curve, int field, bool unsaturated);
+// bench_kern.hip: GB/s (read + written) of a streaming device-to-device copy kernel over two `bytes`-byte buffers
+double bench_hbm_copy(zkp_ctx* ctx, size_t bytes);
 // sort_src >= 0: reuse the bucket sort + task schedule that workspace `sort_src` of the same lane computed for the SAME
 // scalars, length, window configuration and identity flags (Groth16: b_g1_query / b_g2_query) instead of redoing it
 bool bases_same_shape(zkp_ctx* ctx, uint64_t h1, uint64_t h2);

@@ -614,10 +614,20 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   ZKP_REQUIRE(ni + n_w + ix->pad_aux == ix->n, ZKP_ERR_BAD_ARG);
   ZKP_REQUIRE(bases_len(ctx, powers_g) >= D + 1 && bases_len(ctx, powers_gamma_g) >= 2, ZKP_ERR_BAD_ARG);
   hipStream_t st = be.st();
+  // Pool memory and the index's pinned slots are recycled by the next proof: on EVERY exit (an exception between an early
+  // commitment and the round that collects it included) the prover's stream and the lane's MSM workspace streams are drained
+  // before the pool lets go of anything an in-flight MSM or its read-back may still touch.
   struct Release {
     Pool* p;
-    ~Release() { p->release_all(); }
-  } release{&ix->pool};
+    zkp_lane* lane;
+    hipStream_t st;
+    ~Release() {
+      for (int w = 1; w < zkp_lane::N_WS; w++)
+        if (lane->ws[w].stream) (void)hipStreamSynchronize(lane->ws[w].stream);
+      (void)hipStreamSynchronize(st);
+      p->release_all();
+    }
+  } release{&ix->pool, ctx->cur, st};
 
   zkp_marlin_timing tm{};
   auto clk = [] { return std::chrono::steady_clock::now(); };

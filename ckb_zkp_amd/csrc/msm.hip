@@ -1043,7 +1043,10 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
              be->group, n, nb, max_tasks, h[0], h[1], h[2], h[3], h[4], h[5]);
       fflush(stdout);
     }
-    if (dbg != 2) vt->combine(st, long_list, tmeta + TM_NLONG, toff, task_partial, buckets, init);
+#ifdef ZKP_ABLATION   // ZKP_DEBUG_MSM=2 skips the combine step (wrong buckets): ablation builds only
+    if (dbg != 2)
+#endif
+      vt->combine(st, long_list, tmeta + TM_NLONG, toff, task_partial, buckets, init);
     if (dbg) {
       hipError_t e = hipStreamSynchronize(st);
       printf("[msm] combine: %s\n", hipGetErrorString(e));
@@ -1092,7 +1095,9 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       ZKP_REQUIRE(!out_xyz_host, ZKP_ERR_BAD_ARG);
       return;
     }
+#ifdef ZKP_ABLATION
     if (ctx->dbg_skip_k8) return;                  // ablation experiments only (wrong result)
+#endif
     // K8: pyramid
     const int L = c - 1;                           // levels with odd entries: 0..L-1 ; root = level L
     SegPlan plan{};
@@ -1324,11 +1329,13 @@ size_t points_decompress(zkp_ctx* ctx, int curve, int group, const uint8_t* byte
   vt->decompress(st, d_bytes, n, d_b, d_xy, d_inf, d_status);
   ZKP_HIP(hipGetLastError());
   uint32_t status = 0;
-  ZKP_HIP(hipMemcpyAsync(xy_out, d_xy, n * ab, hipMemcpyDeviceToHost, st));
-  ZKP_HIP(hipMemcpyAsync(inf_out, d_inf, n, hipMemcpyDeviceToHost, st));
   ZKP_HIP(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
   ZKP_HIP(hipStreamSynchronize(st));
-  return status == none ? 0 : (size_t)status;
+  if (status != none) return (size_t)status;           // failing lanes wrote nothing: the outputs stay untouched
+  ZKP_HIP(hipMemcpyAsync(xy_out, d_xy, n * ab, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(inf_out, d_inf, n, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipStreamSynchronize(st));
+  return 0;
 }
 // 0 = every point is on the curve and in the prime-order subgroup, else 1 + index of the first that is not
 size_t points_subgroup_check(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, const uint8_t* inf, size_t n) {

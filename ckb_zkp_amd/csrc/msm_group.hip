@@ -505,13 +505,15 @@ __global__ __launch_bounds__(64) void decompress_kernel(const uint32_t* __restri
     fail();
     return;
   }
+  // ark-serialize reads the field element (deserialize_with_flags -> Fp::read -> from_repr) BEFORE it looks at the infinity flag:
+  // x >= p is InvalidData for the identity encoding too
+  if (!coords_canonical(x)) {
+    fail();
+    return;
+  }
   if (flags & 1) {
     Affine<F>::inf().store(xy + i * Affine<F>::BYTES);
     inf[i] = 1;
-    return;
-  }
-  if (!coords_canonical(x)) {
-    fail();
     return;
   }
   const F xm = coords_to_mont(x);

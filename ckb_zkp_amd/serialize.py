@@ -202,12 +202,14 @@ def g1_from_bytes(b: bytes, curve, compressed: bool = True, checked: bool = True
         raise SerializationError("UnexpectedFlags")
     body = bytearray(b)
     body[-1] &= 0x3F
+    # ark reads the field element(s) first (deserialize_with_flags -> Fp::read -> from_repr): a non-canonical coordinate is
+    # InvalidData even when the infinity flag is set
+    if any(int.from_bytes(body[i:i + n], "little") >= q for i in range(0, len(body), n)):
+        raise SerializationError("InvalidData")
     if flags & FLAG_INFINITY:
         return None
     if compressed:
         x = int.from_bytes(body, "little")
-        if x >= q:
-            raise SerializationError("InvalidData")
         y = _sqrt_fq(x * x * x + _g1_b(c), q)
         if y is None:
             raise SerializationError("InvalidData")
@@ -250,11 +252,11 @@ def g2_from_bytes(b: bytes, curve, compressed: bool = True, checked: bool = True
         raise SerializationError("UnexpectedFlags")
     body = bytearray(b)
     body[-1] &= 0x3F
+    vals = [int.from_bytes(body[i * n:(i + 1) * n], "little") for i in range(len(body) // n)]
+    if any(v >= q for v in vals):                    # before the infinity flag, like ark (see g1_from_bytes)
+        raise SerializationError("InvalidData")
     if flags & FLAG_INFINITY:
         return None
-    vals = [int.from_bytes(body[i * n:(i + 1) * n], "little") for i in range(len(body) // n)]
-    if any(v >= q for v in vals):
-        raise SerializationError("InvalidData")
     x = (vals[0], vals[1])
     x3 = _fq2_mul(_fq2_mul(x, x, q), x, q)
     bb = _g2_b(c)
@@ -521,9 +523,9 @@ def parameters_from_bytes_abi(ctx, b: bytes, curve, num_constraints: int, checke
             raise SerializationError(f"InvalidData ({e})")
 
     def single(group):
-        xy, inf = pts(group, 1)
-        if inf[0]:
-            raise SerializationError("InvalidData (identity in a key element)")
+        # ark's `Parameters::deserialize` accepts the identity for alpha / beta / gamma / delta (a useless key, not a malformed
+        # one); in the ABI layout the identity is the all-zero coordinate pair, which the prover's tables treat as such
+        xy, _ = pts(group, 1)
         return xy[0]
 
     alpha_g1, beta_g2, gamma_g2, delta_g2 = single(1), single(2), single(2), single(2)

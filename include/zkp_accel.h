@@ -32,7 +32,9 @@ typedef enum {
   ZKP_ERR_DOMAIN_TOO_LARGE = -3, /* == SynthesisError::PolynomialDegreeTooLarge (groth16/src/r1cs_to_qap.rs:123-125) */
   ZKP_ERR_OOM = -4,
   ZKP_ERR_DEVICE = -5,           /* HIP runtime error, or no MI355X/gfx950 device: there is NO CPU fallback */
-  ZKP_ERR_BAD_HANDLE = -6
+  ZKP_ERR_BAD_HANDLE = -6,
+  ZKP_ERR_INVALID_POINT = -7 /* zkp_g*_decompress / zkp_g*_subgroup_check: a point is malformed / off the curve / outside the subgroup
+                               (== ark-serialize SerializationError::InvalidData); *bad_index holds its index */
 } zkp_status;
 
 /* ops of zkp_ntt: ark-poly `EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place`
@@ -170,7 +172,8 @@ int32_t zkp_g2_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_
  * 48 / 96 on BLS12-381) with two flags in the top bits of the last byte: bit 7 = y is the larger of {y, -y} (Fq: as integers;
  * Fq2: c1 first, then c0), bit 6 = the identity.  Decompression (a square root per point) runs on the device, one lane per point:
  * a 2^20 key loads in tens of milliseconds.  On a malformed point (both flags, x >= p, x^3 + b not a square) the call returns
- * ZKP_ERR_BAD_ARG and *bad_index (if not NULL) receives its index.  No subgroup check (= ark's `deserialize_unchecked` for the
+ * ZKP_ERR_INVALID_POINT, *bad_index (if not NULL) receives its index and xy_out / inf_out are left untouched (*bad_index is
+ * SIZE_MAX after any other outcome, so an argument error is never mistaken for "point 0").  No subgroup check (= ark's `deserialize_unchecked` for the
  * cofactor groups; BN254 G1 has cofactor 1).  The container framing (Vec length prefixes, field order of `Parameters`) stays with
  * the caller: ckb_zkp_amd/serialize.py, rust/zkp-accel. */
 int32_t zkp_g1_decompress(zkp_ctx* ctx, zkp_curve_t curve, const uint8_t* bytes, size_t n, uint64_t* xy_out, uint8_t* inf_out,
@@ -183,7 +186,7 @@ int32_t zkp_g2_compress(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, con
  * `is_in_correct_subgroup_assuming_on_curve`, i.e. [r]P = O; what `Parameters::deserialize` / `Proof::deserialize` /
  * `VerifyKey::deserialize` run per element — /root/reference/cli/src/zkp_prove.rs:45, zkp_verify.rs:61-62).  xy: n affine Montgomery points
  * (the layout zkp_g*_decompress writes), inf: optional identity flags (identities pass).  One lane per point, a double-and-add over
- * the group order: ~0.2 s for a 2^20-element G2 query.  ZKP_OK if every point passes; otherwise ZKP_ERR_BAD_ARG and *bad_index
+ * the group order: ~0.2 s for a 2^20-element G2 query.  ZKP_OK if every point passes; otherwise ZKP_ERR_INVALID_POINT and *bad_index
  * (if not NULL) = index of the first point that is off the curve or outside the prime-order subgroup. */
 int32_t zkp_g1_subgroup_check(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, size_t* bad_index);
 int32_t zkp_g2_subgroup_check(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n, size_t* bad_index);
@@ -401,7 +404,10 @@ int32_t zkp_marlin_index_commit(zkp_ctx* ctx, zkp_marlin_index* index, uint64_t 
  * ivk_bytes = to_bytes![index_verifier_key] (the caller owns and serialises the key); x: num_inputs formatted inputs
  * (leading one included), w: the witness without the make_matrices_square padding — Fr Montgomery, host.
  * fixed_challenges == NULL: create_random_proof (messages derived from the transcript).  Non-NULL (7 Fr Montgomery: alpha,
- * eta_a, eta_b, eta_c, beta, gamma, xi): TEST HOOK — the messages are taken as given, the transcript is not consulted. */
+ * eta_a, eta_b, eta_c, beta, gamma, xi): TEST HOOK — the messages are taken as given, the transcript is not consulted.
+ * An index owns the scratch pool and the pinned landing slots of its proofs: ONE zkp_marlin_prove at a time per index (prove
+ * with the same circuit from several threads = one zkp_marlin_index_upload per thread).  On any error the call drains its
+ * streams before the pool is recycled, so a failed proof never leaves work in flight on the index. */
 int32_t zkp_marlin_prove(zkp_ctx* ctx, zkp_marlin_index* index, uint64_t powers_of_g, uint64_t powers_of_gamma_g,
                          const uint8_t* ivk_bytes, size_t ivk_len, const uint64_t* x, const uint64_t* w, size_t n_w,
                          const zkp_marlin_rand* rnd, const uint64_t* fixed_challenges, zkp_marlin_proof* out);
@@ -443,6 +449,10 @@ int32_t zkp_set_profiling(zkp_ctx* ctx, int32_t enable); /* per-phase HIP events
  * roof the MSM / NTT kernels are bound by, measured in the calling process (bench.py `valu_roof`).
  * field: 0 = Fr, 1 = Fq; unsaturated: 0 = 32-bit saturated limbs (field_dev.hpp), 1 = 29/28-bit limbs (unsat_dev.hpp). */
 int32_t zkp_bench_mulmod(zkp_ctx* ctx, zkp_curve_t curve, int32_t field, int32_t unsaturated, double* gmulmod_per_s);
+/* HBM bandwidth (GB/s, bytes read + bytes written) a plain streaming copy kernel reaches on this device between two freshly
+ * allocated `bytes`-byte buffers (>= 1 MiB; use >= 1 GiB so that the 256 MB of Infinity Cache cannot hold it): the measured
+ * peak bench.py quotes next to the nominal 8 TB/s ("also measure an on-box copy kernel and quote both"). */
+int32_t zkp_bench_hbm_copy(zkp_ctx* ctx, size_t bytes, double* gbytes_per_s);
 
 #ifdef __cplusplus
 }

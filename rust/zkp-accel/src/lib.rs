@@ -40,6 +40,9 @@ pub enum Error {
     /// call and choose it here (see `msm_or_arkworks` in the patch under rust/patches/).
     Device(String),
     BadHandle,
+    /// a point handed to the codec entry points is malformed / off the curve / outside the subgroup (the wrappers below turn
+    /// it into `PointError::Invalid(index)`)
+    InvalidPoint,
     Unknown(i32),
 }
 
@@ -55,6 +58,7 @@ impl Error {
                 Error::Device(s.to_string_lossy().into_owned())
             }
             ffi::ZKP_ERR_BAD_HANDLE => Error::BadHandle,
+            ffi::ZKP_ERR_INVALID_POINT => Error::InvalidPoint,
             other => Error::Unknown(other),
         }
     }
@@ -443,7 +447,7 @@ where
             ffi::zkp_g2_decompress(ctx.0, P::CURVE, bytes.as_ptr(), n, xy.as_mut_ptr(), inf.as_mut_ptr(), &mut bad)
         }
     };
-    if st == ffi::ZKP_ERR_BAD_ARG && n > 0 {
+    if st == ffi::ZKP_ERR_INVALID_POINT {
         return Err(PointError::Invalid(bad));
     }
     check(st).map_err(PointError::Accel)?;
@@ -485,7 +489,7 @@ where
             ffi::zkp_g2_subgroup_check(ctx.0, P::CURVE, xy.as_ptr(), inf.as_ptr(), n, &mut bad)
         }
     };
-    if st == ffi::ZKP_ERR_BAD_ARG && n > 0 {
+    if st == ffi::ZKP_ERR_INVALID_POINT {
         return Err(PointError::Invalid(bad));
     }
     check(st).map_err(PointError::Accel)

@@ -2,6 +2,13 @@
  * `extern "C"` binding sees.  Usage:
  *     abi_driver probe                -> creates a context; prints "ctx=<status>"; exit 0 (status may be ZKP_ERR_DEVICE)
  *     abi_driver run <in.bin> <out.bin>
+ *     abi_driver groth16 <in.bin> <out.bin>   the seam of zkp_groth16::create_proof (prover.rs:124): zkp_groth16_pk_upload ->
+ *                                             zkp_groth16_witness_map -> zkp_groth16_prove -> zkp_groth16_prove_batch
+ *     abi_driver marlin <in.bin> <out.bin>    the seam of zkp_marlin::create_random_proof (marlin/src/lib.rs:97): resident SRS,
+ *                                             zkp_marlin_index_upload -> zkp_marlin_prove (transcript-derived challenges)
+ * groth16 / marlin in.bin = a sequence of sections [u64 byte count][payload padded to 8 bytes], in the order the functions
+ * below read them; out.bin = raw little-endian words (see the fwrite calls).  tests/test_gpu_cabi.py writes / checks them.
+ * run mode:
  * in.bin  (little-endian u64 words): curve, log_n, n_points, n_scalars, then 2^log_n x 4 (Fr, Montgomery),
  *         n_points x 8 (G1 affine, Montgomery; BN254 only), n_points bytes padded to 8 (identity flags),
  *         n_scalars x 4 (canonical scalars)
@@ -23,8 +30,195 @@
     }                                                                            \
   } while (0)
 
+/* ---- section reader: [u64 nbytes][payload, zero-padded to a multiple of 8] */
+static void* section(FILE* f, size_t* nbytes) {
+  uint64_t n = 0;
+  if (fread(&n, 8, 1, f) != 1) {
+    fprintf(stderr, "section header missing\n");
+    exit(4);
+  }
+  const size_t padded = (size_t)((n + 7) & ~(uint64_t)7);
+  void* p = malloc(padded ? padded : 8);
+  if (!p || (padded && fread(p, 1, padded, f) != padded)) {
+    fprintf(stderr, "short section (%lu bytes)\n", (unsigned long)n);
+    exit(4);
+  }
+  if (nbytes) *nbytes = (size_t)n;
+  return p;
+}
+static void read_csr(FILE* f, zkp_csr* m) {
+  m->row_ptr = (const uint32_t*)section(f, NULL);
+  m->col = (const uint32_t*)section(f, NULL);
+  m->coeff = (const uint64_t*)section(f, NULL);
+}
+
+/* zkp_groth16::create_proof through the C boundary.  Sections: hdr (u64: curve, num_inputs, num_aux, num_constraints,
+ * n_proofs) | at, bt, ct (row_ptr, col, coeff each) | alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2 | a, b_g1, b_g2, h, l
+ * (xy then identity flags each) | z | r (n_proofs x 4) | s (n_proofs x 4).
+ * out: N | h (N x 4) | proof of (r0, s0) by zkp_groth16_prove (8 fq words + 3 flag words) | n_proofs x the same by
+ * zkp_groth16_prove_batch | the proof of (r0, s0) once more by a second zkp_groth16_prove after the batch (key reuse) */
+static int groth16_mode(const char* in, const char* out) {
+  FILE* f = fopen(in, "rb");
+  if (!f) return 1;
+  uint64_t* hdr = (uint64_t*)section(f, NULL);
+  zkp_groth16_pk_desc d;
+  memset(&d, 0, sizeof d);
+  d.curve = (zkp_curve_t)hdr[0];
+  d.num_inputs = (uint32_t)hdr[1];
+  d.num_aux = (uint32_t)hdr[2];
+  d.num_constraints = (uint32_t)hdr[3];
+  const size_t n_proofs = (size_t)hdr[4];
+  const size_t fq = d.curve == ZKP_BN254 ? 4 : 6, pw = 8 * fq;
+  read_csr(f, &d.at);
+  read_csr(f, &d.bt);
+  read_csr(f, &d.ct);
+  d.alpha_g1 = (const uint64_t*)section(f, NULL);
+  d.beta_g1 = (const uint64_t*)section(f, NULL);
+  d.delta_g1 = (const uint64_t*)section(f, NULL);
+  d.beta_g2 = (const uint64_t*)section(f, NULL);
+  d.delta_g2 = (const uint64_t*)section(f, NULL);
+  size_t nb = 0;
+  d.a_query = (const uint64_t*)section(f, NULL);
+  d.a_inf = (const uint8_t*)section(f, &nb);
+  d.a_len = nb;
+  d.b_g1_query = (const uint64_t*)section(f, NULL);
+  d.b_g1_inf = (const uint8_t*)section(f, &nb);
+  d.b_g1_len = nb;
+  d.b_g2_query = (const uint64_t*)section(f, NULL);
+  d.b_g2_inf = (const uint8_t*)section(f, &nb);
+  d.b_g2_len = nb;
+  d.h_query = (const uint64_t*)section(f, NULL);
+  d.h_inf = (const uint8_t*)section(f, &nb);
+  d.h_len = nb;
+  d.l_query = (const uint64_t*)section(f, NULL);
+  d.l_inf = (const uint8_t*)section(f, &nb);
+  d.l_len = nb;
+  const uint64_t* z = (const uint64_t*)section(f, NULL);
+  const uint64_t* r = (const uint64_t*)section(f, NULL);
+  const uint64_t* s = (const uint64_t*)section(f, NULL);
+  fclose(f);
+
+  zkp_ctx* ctx = NULL;
+  zkp_groth16_pk* pk = NULL;
+  CHECK(zkp_ctx_create(&ctx, 0));
+  CHECK(zkp_groth16_pk_upload(ctx, &d, &pk));
+  uint64_t N = 0;
+  CHECK(zkp_groth16_domain_size(pk, &N));
+  uint64_t* h = (uint64_t*)malloc((size_t)N * 32);
+  CHECK(zkp_groth16_witness_map(ctx, pk, z, h));
+  uint64_t* one = (uint64_t*)calloc(pw, 8);
+  uint64_t* again = (uint64_t*)calloc(pw, 8);
+  uint8_t one_inf[3] = {9, 9, 9}, again_inf[3] = {9, 9, 9};
+  CHECK(zkp_groth16_prove(ctx, pk, z, r, s, one, one_inf));
+  uint64_t* batch = (uint64_t*)calloc(n_proofs * pw, 8);
+  uint8_t* batch_inf = (uint8_t*)malloc(n_proofs * 3);
+  const uint64_t** zs = (const uint64_t**)malloc(n_proofs * sizeof *zs);
+  for (size_t i = 0; i < n_proofs; i++) zs[i] = z;
+  CHECK(zkp_groth16_prove_batch(ctx, pk, n_proofs, zs, r, s, batch, batch_inf));
+  CHECK(zkp_groth16_prove(ctx, pk, z, r, s, again, again_inf));
+  /* error behaviour of the seam: NULL witness, and a freed key must not be usable through a stale context call sequence */
+  if (zkp_groth16_prove(ctx, pk, NULL, r, s, one, one_inf) != ZKP_ERR_BAD_ARG) return 3;
+  CHECK(zkp_groth16_pk_free(ctx, pk));
+
+  f = fopen(out, "wb");
+  if (!f) return 1;
+  fwrite(&N, 8, 1, f);
+  fwrite(h, 32, (size_t)N, f);
+  uint64_t w3[3];
+  fwrite(one, 8, pw, f);
+  for (int k = 0; k < 3; k++) w3[k] = one_inf[k];
+  fwrite(w3, 8, 3, f);
+  for (size_t i = 0; i < n_proofs; i++) {
+    fwrite(batch + i * pw, 8, pw, f);
+    for (int k = 0; k < 3; k++) w3[k] = batch_inf[3 * i + k];
+    fwrite(w3, 8, 3, f);
+  }
+  fwrite(again, 8, pw, f);
+  for (int k = 0; k < 3; k++) w3[k] = again_inf[k];
+  fwrite(w3, 8, 3, f);
+  fclose(f);
+  CHECK(zkp_ctx_destroy(ctx));
+  printf("ok\n");
+  return 0;
+}
+
+/* zkp_marlin::create_random_proof through the C boundary (BN254 or BLS12-381 G1 SRS).  Sections: hdr (u64: curve, num_inputs,
+ * n, pad_aux, n_w, srs_g points, srs_gamma_g points) | a, b, c (row_ptr, col, coeff each) | powers_of_g xy | powers_of_gamma_g
+ * xy | ivk bytes | x | w | rand.w | rand.z_a | rand.z_b | rand.mask | blind_w | blind_z_a | blind_z_b | blind_g_1 |
+ * blind_shifted_g_1.   out: info[6] | the zkp_marlin_proof struct, raw | 12 index commitments (12 x 12 words) + 12 flag words */
+static int marlin_mode(const char* in, const char* out) {
+  FILE* f = fopen(in, "rb");
+  if (!f) return 1;
+  uint64_t* hdr = (uint64_t*)section(f, NULL);
+  zkp_marlin_index_desc d;
+  memset(&d, 0, sizeof d);
+  d.curve = (zkp_curve_t)hdr[0];
+  d.num_inputs = (uint32_t)hdr[1];
+  d.n = (uint32_t)hdr[2];
+  d.pad_aux = (uint32_t)hdr[3];
+  const size_t n_w = (size_t)hdr[4], n_g = (size_t)hdr[5], n_gg = (size_t)hdr[6];
+  read_csr(f, &d.a);
+  read_csr(f, &d.b);
+  read_csr(f, &d.c);
+  const uint64_t* g_xy = (const uint64_t*)section(f, NULL);
+  const uint64_t* gg_xy = (const uint64_t*)section(f, NULL);
+  size_t ivk_len = 0;
+  const uint8_t* ivk = (const uint8_t*)section(f, &ivk_len);
+  const uint64_t* x = (const uint64_t*)section(f, NULL);
+  const uint64_t* w = (const uint64_t*)section(f, NULL);
+  zkp_marlin_rand R;
+  memset(&R, 0, sizeof R);
+  R.w = (const uint64_t*)section(f, NULL);
+  R.z_a = (const uint64_t*)section(f, NULL);
+  R.z_b = (const uint64_t*)section(f, NULL);
+  R.mask = (const uint64_t*)section(f, NULL);
+  R.mask_on_device = 0;
+  R.blind_w = (const uint64_t*)section(f, NULL);
+  R.blind_z_a = (const uint64_t*)section(f, NULL);
+  R.blind_z_b = (const uint64_t*)section(f, NULL);
+  R.blind_g_1 = (const uint64_t*)section(f, NULL);
+  R.blind_shifted_g_1 = (const uint64_t*)section(f, NULL);
+  fclose(f);
+
+  zkp_ctx* ctx = NULL;
+  zkp_marlin_index* ix = NULL;
+  uint64_t h_g = 0, h_gg = 0, info[6];
+  CHECK(zkp_ctx_create(&ctx, 0));
+  CHECK(zkp_bases_upload_g1(ctx, d.curve, g_xy, NULL, n_g, &h_g));
+  CHECK(zkp_bases_upload_g1(ctx, d.curve, gg_xy, NULL, n_gg, &h_gg));
+  CHECK(zkp_marlin_index_upload(ctx, &d, &ix));
+  CHECK(zkp_marlin_index_info(ix, info));
+  uint64_t* icomm = (uint64_t*)calloc(12 * 12, 8);
+  uint8_t icomm_inf[12];
+  CHECK(zkp_marlin_index_commit(ctx, ix, h_g, icomm, icomm_inf));
+  zkp_marlin_proof* proof = (zkp_marlin_proof*)calloc(1, sizeof *proof);
+  CHECK(zkp_marlin_prove(ctx, ix, h_g, h_gg, ivk, ivk_len, x, w, n_w, &R, NULL, proof));
+  if (zkp_marlin_prove(ctx, ix, h_g, h_gg, NULL, 0, x, w, n_w, &R, NULL, proof) != ZKP_ERR_BAD_ARG) return 3; /* no key bytes, no fixed challenges */
+  CHECK(zkp_marlin_index_free(ctx, ix));
+  CHECK(zkp_bases_free(ctx, h_g));
+  CHECK(zkp_bases_free(ctx, h_gg));
+
+  f = fopen(out, "wb");
+  if (!f) return 1;
+  fwrite(info, 8, 6, f);
+  uint64_t sz = sizeof *proof;
+  fwrite(&sz, 8, 1, f);
+  fwrite(proof, 1, sizeof *proof, f);
+  fwrite(icomm, 8, 12 * 12, f);
+  for (int k = 0; k < 12; k++) {
+    uint64_t v = icomm_inf[k];
+    fwrite(&v, 8, 1, f);
+  }
+  fclose(f);
+  CHECK(zkp_ctx_destroy(ctx));
+  printf("ok\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   zkp_ctx* ctx = NULL;
+  if (argc == 4 && strcmp(argv[1], "groth16") == 0) return groth16_mode(argv[2], argv[3]);
+  if (argc == 4 && strcmp(argv[1], "marlin") == 0) return marlin_mode(argv[2], argv[3]);
   if (argc >= 2 && strcmp(argv[1], "probe") == 0) {
     int32_t st = zkp_ctx_create(&ctx, 0);
     printf("version=%s\nctx=%d (%s)\n", zkp_version(), (int)st, zkp_status_string(st));
@@ -32,7 +226,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (argc != 4 || strcmp(argv[1], "run") != 0) {
-    fprintf(stderr, "usage: %s probe | run in.bin out.bin\n", argv[0]);
+    fprintf(stderr, "usage: %s probe | run|groth16|marlin in.bin out.bin\n", argv[0]);
     return 1;
   }
   FILE* f = fopen(argv[2], "rb");
