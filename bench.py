@@ -174,7 +174,8 @@ def bench_marlin(ctx, curve="bn254", samples=87381, reps=3, verify=True, cpu=Fal
     device-side indexer + device-resident prover, verifier messages derived from the Fiat-Shamir transcript round by
     round, the proof checked by the oracle's verifier (which re-derives them).  -> dict for the JSON line."""
     import random
-    from ckb_zkp_amd import codec, kzg10, marlin_dev
+    from ckb_zkp_amd import codec, kzg10
+    from ckb_zkp_amd import marlin as marlin_dev
     from ckb_zkp_amd.circuits import mimc_chain_instance
     from ckb_zkp_amd.params import get_curve
     c = get_curve(curve)

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (moved out of the product package in round 3): a second, host-list implementation of the Marlin prover
-over the C ABI, kept only to cross-check the device-resident product prover (ckb_zkp_amd/marlin_dev.py, csrc/marlin.hip).
+over the C ABI, kept only to cross-check the device-resident product prover (ckb_zkp_amd/marlin.py -> csrc/marlin.hip).
 
 Host-side mirror of the reference's Marlin prover on the MI355X backend (BASELINE.json configs[3]).
 
@@ -18,7 +18,7 @@ import numpy as np
 
 from ckb_zkp_amd import api, codec, kzg10
 from ckb_zkp_amd.api import Context
-from ckb_zkp_amd.marlin_dev import (INDEX_LABELS, LABELS_1, LABELS_2, LABELS_3, ZK_BOUND, MarlinCS, _next_pow2,  # noqa: F401
+from ckb_zkp_amd.marlin import (INDEX_LABELS, LABELS_1, LABELS_2, LABELS_3, ZK_BOUND, MarlinCS, _next_pow2,  # noqa: F401
                                     index_matrices, reindex_by_subdomain)
 from ckb_zkp_amd.params import get_curve
 

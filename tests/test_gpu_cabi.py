@@ -123,7 +123,7 @@ def test_c_program_marlin_seam_matches_the_oracle_prover(tmp_path):
     and the oracle's verifier accepts.  SRS, matrices and the key bytes are produced by the oracle / host code only."""
     import ctypes as C
     from ckb_zkp_amd import _lib
-    from ckb_zkp_amd import marlin_dev as pm
+    from ckb_zkp_amd import marlin as pm
     from ckb_zkp_amd.circuits import mimc_chain_instance
     from oracle.pyref import fs_rng as ofs
     from oracle.pyref import groth16 as og

@@ -72,7 +72,8 @@ def test_marlin_prover_matches_oracle_and_verifies(ctx, curve, kind):
 
 def test_device_vector_primitives(ctx):
     """spmv / gather / divide_by_vanishing / add-constant against plain big-int arithmetic."""
-    from ckb_zkp_amd import marlin_dev
+    from ckb_zkp_amd import marlin as marlin_native
+    from tests import marlin_pyorch as marlin_dev
     c = get_curve("bn254")
     rnd = random.Random(3)
     be = marlin_dev.DeviceBackend(ctx, c)
@@ -108,7 +109,8 @@ def test_device_vector_primitives(ctx):
 @pytest.mark.parametrize("curve,kind", [("bn254", "mimc"), ("bls12_381", "mimc"), ("bn254", "mini")])
 def test_device_resident_marlin_matches_oracle_and_verifies(ctx, curve, kind):
     """marlin_dev.create_proof (all vectors resident in HBM) == the oracle prover, and the proof verifies."""
-    from ckb_zkp_amd import marlin_dev
+    from ckb_zkp_amd import marlin as marlin_native
+    from tests import marlin_pyorch as marlin_dev
     c = get_curve(curve)
     rnd = random.Random(15)
     if kind == "mimc":
@@ -140,7 +142,7 @@ def test_device_resident_marlin_matches_oracle_and_verifies(ctx, curve, kind):
         # ---- create_random_proof: verifier messages DERIVED from the Fiat–Shamir transcript (lib.rs:105-158), by the
         # library's FiatShamirRng on the device side and by the oracle's independent implementation on the other
         assert didx.commit_index(ctx, ck) == ic
-        ivk = marlin_dev.index_verifier_key(didx, ck, ic, ck.vk_g2)
+        ivk = marlin_native.index_verifier_key(didx, ck, ic, ck.vk_g2)
         assert ivk == om.index_verifier_key(oidx, pp, ic)
         rproof = marlin_dev.create_random_proof(ctx, didx, ck, ivk, pcirc_w, R)
         oproof = om.create_random_proof(oidx, pp, ic, ocirc, R)
@@ -177,7 +179,8 @@ class _SwapAB:
 def test_device_index_from_arrays_matches_host_index(ctx, curve, samples, swap):
     """DeviceIndex.from_instance (arithmetization computed on the device from CSR arrays) == marlin.index on the same
     circuit synthesised constraint by constraint; the array-form prover input gives the same proof."""
-    from ckb_zkp_amd import marlin_dev
+    from ckb_zkp_amd import marlin as marlin_native
+    from tests import marlin_pyorch as marlin_dev
     from ckb_zkp_amd.circuits import mimc_chain_instance
     c = get_curve(curve)
     inst = mimc_chain_instance(curve, samples, seed=77)
@@ -217,7 +220,9 @@ def test_marlin_config4_full_size_verifies(ctx):
     prover's proof passes the reference's verifier (AHP equality checks + KZG10 pairing checks, lib.rs:184-250) against
     index commitments computed on the device, and a tampered evaluation is rejected — the size-independent acceptance
     test the reference itself uses (marlin/tests/mini.rs:81-87)."""
-    from ckb_zkp_amd import codec, marlin_dev
+    from ckb_zkp_amd import codec
+    from ckb_zkp_amd import marlin as marlin_native
+    from tests import marlin_pyorch as marlin_dev
     from ckb_zkp_amd.circuits import mimc_chain_instance
     from oracle.pyref.curves import Group
     from oracle.pyref.ntt import Domain
@@ -240,7 +245,7 @@ def test_marlin_config4_full_size_verifies(ctx):
                     num_variables=didx.nrows, num_constraints=didx.nrows, num_non_zeros=didx.num_non_zeros)
         ic = didx.commit_index(ctx, ck)
         # create_random_proof: every verifier message derived from the transcript; the oracle's verifier re-derives them
-        ivk = marlin_dev.index_verifier_key(didx, ck, ic, ck.vk_g2)
+        ivk = marlin_native.index_verifier_key(didx, ck, ic, ck.vk_g2)
         proof = marlin_dev.create_random_proof(ctx, didx, ck, ivk, (inst.z[:1], inst.z[1:]), R)
         wire = dict(commitments=proof["commitments"], evaluations=proof["evaluations"], opening_proofs=proof["opening_proofs"])
         assert om.verify_random_proof(oidx, pp, ic, wire, [])
@@ -251,10 +256,10 @@ def test_marlin_config4_full_size_verifies(ctx):
         assert om.verify_proof(oidx, pp, ic, proof2, [], ch)
         # the C entry point (zkp_marlin_index_upload + zkp_marlin_prove) at full size: same index commitments, the same
         # proof as the Python-orchestrated device prover (same randomness, same transcript), accepted by the verifier
-        nidx = marlin_dev.NativeIndex(ctx, inst)
+        nidx = marlin_native.NativeIndex(ctx, inst)
         try:
             assert nidx.commit_index(ck) == ic
-            nproof = marlin_dev.prove_native(ctx, nidx, ck, ivk, inst.z[:1], inst.z[1:], R)
+            nproof = marlin_native.prove_native(ctx, nidx, ck, ivk, inst.z[:1], inst.z[1:], R)
             assert nproof["challenges"] == proof["challenges"]
             assert nproof["commitments"] == proof["commitments"] and nproof["evaluations"] == proof["evaluations"]
             assert nproof["opening_proofs"] == proof["opening_proofs"]
@@ -273,7 +278,8 @@ def test_native_marlin_prover_matches_oracle(ctx, curve, samples, swap):
     behind the C ABI, no Python between the rounds) against the oracle: index commitments, the proof for supplied verifier
     messages (test hook) and the proof with messages DERIVED from the Fiat–Shamir transcript are bit-identical to the
     oracle's, and the oracle's verifier (which re-derives the messages) accepts; a wrong public input is rejected."""
-    from ckb_zkp_amd import marlin_dev
+    from ckb_zkp_amd import marlin as marlin_native
+    from tests import marlin_pyorch as marlin_dev
     from ckb_zkp_amd.circuits import mimc_chain_instance
     c = get_curve(curve)
     inst = mimc_chain_instance(curve, samples, seed=91)
@@ -284,7 +290,7 @@ def test_native_marlin_prover_matches_oracle(ctx, curve, samples, swap):
                             inst.csr("c"), inst.z)
         ocirc = _SwapAB(ocirc)
     oidx = om.index(OC[curve], ocirc)
-    nidx = marlin_dev.NativeIndex(ctx, inst)
+    nidx = marlin_native.NativeIndex(ctx, inst)
     assert (nidx.xs, nidx.hs, nidx.ks, nidx.bs, nidx.max_degree, nidx.num_non_zeros) == \
         (oidx["dx"].size, oidx["dh"].size, oidx["dk"].size, oidx["db"].size, oidx["max_degree"], oidx["num_non_zeros"])
     beta_srs = 0x13579BDF2468ACE
@@ -296,7 +302,7 @@ def test_native_marlin_prover_matches_oracle(ctx, curve, samples, swap):
         R, ch = _rand_inputs(c, nidx.hs, seed=57)
         x, w = inst.z[:inst.num_inputs], inst.z[inst.num_inputs:]
         # supplied verifier messages (test hook)
-        p = marlin_dev.prove_native(ctx, nidx, ck, None, x, w, R, ch)
+        p = marlin_native.prove_native(ctx, nidx, ck, None, x, w, R, ch)
         o = om.create_proof(oidx, pp, ocirc, R, ch)
         assert p["commitments"] == o["commitments"]
         assert p["query"] == o["query"] and p["evaluations"] == o["evaluations"]
@@ -304,7 +310,7 @@ def test_native_marlin_prover_matches_oracle(ctx, curve, samples, swap):
         # create_random_proof: messages derived inside the library
         ivk = om.index_verifier_key(oidx, pp, ic)
         assert ck.vk_g2 == (pp["h"], pp["beta_h"])
-        p = marlin_dev.prove_native(ctx, nidx, ck, ivk, x, w, R)
+        p = marlin_native.prove_native(ctx, nidx, ck, ivk, x, w, R)
         o = om.create_random_proof(oidx, pp, ic, ocirc, R)
         assert p["challenges"] == o["challenges"]
         assert p["commitments"] == o["commitments"] and p["evaluations"] == o["evaluations"]
@@ -314,7 +320,7 @@ def test_native_marlin_prover_matches_oracle(ctx, curve, samples, swap):
         assert not om.verify_random_proof(oidx, pp, ic, wire, [(v + 1) % c.r for v in x[1:]] or [3])
         # a second proof on the same index (pooled scratch reused) with other randomness differs and verifies
         R2, _ = _rand_inputs(c, nidx.hs, seed=58)
-        p2 = marlin_dev.prove_native(ctx, nidx, ck, ivk, x, w, R2)
+        p2 = marlin_native.prove_native(ctx, nidx, ck, ivk, x, w, R2)
         assert p2["commitments"] != p["commitments"]
         wire2 = dict(commitments=p2["commitments"], evaluations=p2["evaluations"], opening_proofs=p2["opening_proofs"])
         assert om.verify_random_proof(oidx, pp, ic, wire2, x[1:])

@@ -84,11 +84,10 @@ def test_qap_exponents_match_oracle_instance_map(curve):
 
 
 def test_marlin_array_indexer_matches_constraint_by_constraint_synthesis():
-    """marlin_dev.prepare_matrices (make_matrices_square + balance_matrices + column sort on CSR index arrays) yields the
+    """marlin.prepare_matrices (make_matrices_square + balance_matrices + column sort on CSR index arrays) yields the
     matrices marlin.index_matrices builds row by row (ahp/constraint_systems.rs:9-31,100-114), incl. the case where A is
     denser and rows are swapped, and the case with more constraints than variables (padding variables)."""
-    from ckb_zkp_amd import codec, marlin_dev
-    from ckb_zkp_amd import marlin_dev as marlin
+    from ckb_zkp_amd import codec, marlin
     from ckb_zkp_amd.circuits import MimcChain, mimc_chain_instance
     from ckb_zkp_amd.params import get_curve
     from ckb_zkp_amd.r1cs import R1csInstance
@@ -115,7 +114,7 @@ def test_marlin_array_indexer_matches_constraint_by_constraint_synthesis():
                                 inst.csr("c"), inst.z)
             circ = SwapAB(circ)
         cs, mats = marlin.index_matrices(curve, circ)
-        n, pad_aux, arr = marlin_dev.prepare_matrices(inst)
+        n, pad_aux, arr = marlin.prepare_matrices(inst)
         assert n == len(mats[0]) == cs.num_inputs + cs.num_aux and pad_aux == 0
         for want, (ptr, col, cf, rows) in zip(mats, arr):
             vals = codec.fr_from_mont(cf, c)
