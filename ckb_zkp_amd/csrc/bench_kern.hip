@@ -102,10 +102,22 @@ double bench_mulmod(zkp_ctx* ctx, int curve, int field, bool unsaturated) {
 // device, next to the nominal 8 TB/s: every lane moves 16 B per iteration (global_load_dwordx4 / global_store_dwordx4), a
 // grid-stride loop over a buffer much larger than the 256 MB of L2 + Infinity Cache, read once and written once.
 typedef uint32_t copy_v4 __attribute__((ext_vector_type(4)));
+// U independent 16-B loads in flight per lane before the first store; NT: non-temporal loads / stores (no L2 allocation)
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void hbm_copy_kernel(const copy_v4* __restrict__ src, copy_v4* __restrict__ dst, size_t n16) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
-    __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + (U - 1) * stride < n16; i += U * stride) {
+    copy_v4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) v[k] = NT ? __builtin_nontemporal_load(src + i + k * stride) : src[i + k * stride];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      if (NT) __builtin_nontemporal_store(v[k], dst + i + k * stride);
+      else dst[i + k * stride] = v[k];
+    }
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 // -> GB/s (read + written bytes over the HIP-event time of `reps` back-to-back copies of `bytes` bytes)
@@ -127,17 +139,28 @@ double bench_hbm_copy(zkp_ctx* ctx, size_t bytes) {
   try {
     ZKP_HIP(hipMemsetAsync(src, 0x5a, bytes, st));
     ZKP_HIP(hipMemsetAsync(dst, 0, bytes, st));
-    for (int wg_per_cu : {8, 16, 32}) {                               // the best grid of the three is the device's figure
-      const int blocks = cus * wg_per_cu, reps = 5;
-      hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, st, src, dst, n16);   // warm-up
-      ZKP_HIP(hipEventRecord(ctx->ev2, st));
-      for (int r = 0; r < reps; r++) hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, st, src, dst, n16);
-      ZKP_HIP(hipEventRecord(ctx->ev3, st));
-      ZKP_HIP(hipEventSynchronize(ctx->ev3));
-      ZKP_HIP(hipGetLastError());
-      float ms = 0.f;
-      ZKP_HIP(hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3));
-      best = std::max(best, 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9);
+    // the best of (grid, loads in flight, cache policy) is the device's figure
+    for (int variant = 0; variant < 4; variant++) {
+      for (int wg_per_cu : {4, 8, 16, 32}) {
+        const int blocks = cus * wg_per_cu, reps = 5;
+        auto launch = [&] {
+          switch (variant) {
+            case 0: hipLaunchKernelGGL((hbm_copy_kernel<1, false>), dim3(blocks), dim3(256), 0, st, src, dst, n16); break;
+            case 1: hipLaunchKernelGGL((hbm_copy_kernel<4, false>), dim3(blocks), dim3(256), 0, st, src, dst, n16); break;
+            case 2: hipLaunchKernelGGL((hbm_copy_kernel<1, true>), dim3(blocks), dim3(256), 0, st, src, dst, n16); break;
+            default: hipLaunchKernelGGL((hbm_copy_kernel<4, true>), dim3(blocks), dim3(256), 0, st, src, dst, n16); break;
+          }
+        };
+        launch();                                                       // warm-up
+        ZKP_HIP(hipEventRecord(ctx->ev2, st));
+        for (int r = 0; r < reps; r++) launch();
+        ZKP_HIP(hipEventRecord(ctx->ev3, st));
+        ZKP_HIP(hipEventSynchronize(ctx->ev3));
+        ZKP_HIP(hipGetLastError());
+        float ms = 0.f;
+        ZKP_HIP(hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3));
+        best = std::max(best, 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9);
+      }
     }
   } catch (...) {
     (void)hipFree(src);

@@ -9,9 +9,11 @@ reindexed transposes for `t`, the arithmetization polynomials and their evaluati
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
-from ckb_zkp_amd import api, codec, kzg10
+from ckb_zkp_amd import _lib, api, codec, kzg10
 from ckb_zkp_amd.api import Context
 from ckb_zkp_amd.marlin import (INDEX_LABELS, LABELS_1, LABELS_2, LABELS_3, ZK_BOUND, MarlinCS, NativeIndex, _next_pow2,  # noqa: F401
                                 index_matrices, index_verifier_key, prepare_matrices, prove_native, reindex_by_subdomain)
