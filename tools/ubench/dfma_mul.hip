@@ -61,6 +61,9 @@ __device__ __forceinline__ D5 dfma_mont_mul(const D5& a, const D5& b) {
   const double C2 = 20282409603651670423947251286016.0 + 4503599627370496.0;   // 2^104 + 2^52
   const long long B1 = 0x4670000000000000ll;                            // bits(2^104): p_hi = B1 + hi (ulp = 2^52)
   const long long B2 = 0x4330000000000000ll;                            // bits(2^52): p_lo = B2 + lo (ulp = 1)
+  // compile-time constants (constexpr variables force the evaluation: a plain call of the constexpr functions is emitted as run-time bit loops)
+  constexpr double PD0 = (double)p_limb(0), PD1 = (double)p_limb(1), PD2 = (double)p_limb(2), PD3 = (double)p_limb(3), PD4 = (double)p_limb(4);
+  constexpr uint64_t PINV = p_inv52();
   long long col[2 * L + 1];
 #pragma unroll
   for (int k = 0; k <= 2 * L; k++) col[k] = 0;
@@ -79,11 +82,11 @@ __device__ __forceinline__ D5 dfma_mont_mul(const D5& a, const D5& b) {
 #pragma unroll
   for (int i = 0; i < L; i++) {
     const uint64_t t = (uint64_t)col[i] & MASK52;
-    const uint64_t q = (t * p_inv52()) & MASK52;                        // 52-bit low product on the integer pipe
+    const uint64_t q = (t * PINV) & MASK52;                        // 52-bit low product on the integer pipe
     const double qd = u52_to_double(q);
 #pragma unroll
     for (int j = 0; j < L; j++) {
-      const double pj = (double)p_limb(j);
+      const double pj = j == 0 ? PD0 : j == 1 ? PD1 : j == 2 ? PD2 : j == 3 ? PD3 : PD4;
       const double ph = __builtin_fma(qd, pj, C1);
       const double pl = __builtin_fma(qd, pj, C2 - ph);
       col[i + j + 1] += __double_as_longlong(ph) - B1;
@@ -104,19 +107,21 @@ __device__ __forceinline__ D5 dfma_mont_mul(const D5& a, const D5& b) {
 }
 
 // MODE.fp_round bits [3:2] (FP64 / FP16) := 3 = round toward zero; hwreg(HW_REG_MODE = 1, offset 2, width 2)
-__device__ __forceinline__ void fp64_round_toward_zero() { __builtin_amdgcn_s_setreg((1 << 11) | (2 << 6) | 1, 3); }
+// (inline asm, issued AFTER the prologue's integer -> double conversions: with the builtin, LLVM's mode-register pass resets the field
+// to round-to-nearest behind the first v_cvt_f64_u32 it meets)
+__device__ __forceinline__ void fp64_round_toward_zero() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3" ::: "memory"); }
 
 template <int CH>
 __global__ __launch_bounds__(256) void dfma_rate_kernel(double* __restrict__ out, int iters) {
-  fp64_round_toward_zero();
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   D5 a[CH], c[CH];
 #pragma unroll
   for (int k = 0; k < CH; k++) {
 #pragma unroll
-    for (int i = 0; i < L; i++) a[k].v[i] = (double)(((uint64_t)t * 2654435761ull + 40503ull * k + i * 977ull) & (i == L - 1 ? (1ull << 45) - 1 : MASK52));
+    for (int i = 0; i < L; i++) a[k].v[i] = u52_to_double(((uint64_t)t * 2654435761ull + 40503ull * k + i * 977ull) & (i == L - 1 ? (1ull << 45) - 1 : MASK52));
     c[k] = a[k];
   }
+  fp64_round_toward_zero();
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int k = 0; k < CH; k++) c[k] = dfma_mont_mul(c[k], a[k]);
@@ -157,7 +162,6 @@ __global__ __launch_bounds__(256) void unsat_rate_kernel(uint32_t* __restrict__ 
 
 // one product per lane on given operands: a, b, out as 5 u64 limbs each (the check dump)
 __global__ void dfma_check_kernel(const uint64_t* __restrict__ ab, uint64_t* __restrict__ out, size_t n) {
-  fp64_round_toward_zero();
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   D5 a, b;
@@ -166,9 +170,10 @@ __global__ void dfma_check_kernel(const uint64_t* __restrict__ ab, uint64_t* __r
     a.v[i] = u52_to_double(ab[t * 10 + i]);
     b.v[i] = u52_to_double(ab[t * 10 + 5 + i]);
   }
+  fp64_round_toward_zero();
   const D5 r = dfma_mont_mul(a, b);
 #pragma unroll
-  for (int i = 0; i < L; i++) out[t * L + i] = (uint64_t)r.v[i];
+  for (int i = 0; i < L; i++) out[t * L + i] = (uint64_t)__double_as_longlong(r.v[i] + 4503599627370496.0) & MASK52;   // exact: limb < 2^52
 }
 
 #define HIPCHECK(x)                                                               \
