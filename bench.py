@@ -64,6 +64,17 @@ def bench_sharded(args, ctx, c, inst, params, z, rank, world, local):
         ctx.sync()
 
     z_dev = ctx.to_device(z)                                    # witness resident in HBM before the timed region
+    # scale_parity, checked BEFORE timing: the sharded proof of a fixed (r, s) == the proof rank 0 computes alone with the whole key
+    sharded = prover.prove(z_dev, r_, s_)                       # collective: every rank takes part
+    scale_parity = None
+    if rank == 0:
+        from ckb_zkp_amd import groth16
+        pk0 = groth16.ProvingKey(ctx, params, inst)
+        single = pk0.prove_raw(z_dev, codec_mont(c, r_), codec_mont(c, s_), z_on_device=True)
+        pk0.free()
+        scale_parity = {"sharded_eq_single_gpu": bool(np.array_equal(sharded[0], single[0]) and list(sharded[1]) == list(single[1])),
+                        "ranks": world, "note": "one proof with a fixed (r, s): all ranks sharded vs rank 0 alone with the full key"}
+        log(f"scale_parity: {scale_parity['sharded_eq_single_gpu']}")
 
     def step():
         # partial MSMs (this rank's 1/world of every query) -> all_gather_into_tensor on device buffers (RCCL) ->
@@ -95,10 +106,19 @@ def bench_sharded(args, ctx, c, inst, params, z, rank, world, local):
                        "curve": c.name, "log_domain": args.log_n, "parallelism": f"base-sharded x{world}",
                        "note": "witness, h, partial sums and the gathered buffer resident in HBM; NTT pipeline replicated per rank; "
                                "per step: zkp_groth16_prove_partials_dev -> all_gather_into_tensor -> zkp_groth16_fold_assemble_dev"},
+            "scale_parity": scale_parity,
+            "exchange": {"kind": "gloo (host-staged, TEST ONLY)" if args.single_device_test else "rccl" if world > 1 else "none",
+                         "ranks": world, "call": "torch.distributed.all_gather_into_tensor on device buffers" if world > 1 else None,
+                         "bytes_per_rank": prover.pb},
             "roofline": None, "cpu_baseline": None}), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def codec_mont(c, v):
+    from ckb_zkp_amd import codec
+    return codec.fr_to_mont([v], c)[0]
 
 
 def bench_single_process_multi(args):
@@ -143,6 +163,23 @@ def bench_single_process_multi(args):
         for k in range(n):
             m.member(k).sync()
 
+    # scale_parity, checked BEFORE timing, with a fixed (r, s): shard — the proof over all devices == the proof device 0 computes alone
+    # with the whole key; throughput — the same proof from every device's replica
+    r_fix, s_fix = rand_fr(1)[0], rand_fr(1)[0]
+    if shard:
+        multi = mpk.prove_raw(zds, r_fix, s_fix, z_on_device=True)
+        pk0 = groth16.ProvingKey(m.member(0), params, inst)
+        single = pk0.prove_raw(zds[0], r_fix, s_fix, z_on_device=True)
+        pk0.free()
+        ok = bool(np.array_equal(multi[0], single[0]) and list(multi[1]) == list(single[1]))
+        scale_parity = {"sharded_eq_single_gpu": ok, "ranks": n,
+                        "note": "zkp_groth16_prove_multi over all devices vs zkp_groth16_prove_dev on device 0 with the full key"}
+    else:
+        outs, infs = mpk.prove_batch_raw(zds, np.stack([r_fix] * n), np.stack([s_fix] * n), z_on_device=True)
+        ok = bool(all(np.array_equal(outs[k], outs[0]) and list(infs[k]) == list(infs[0]) for k in range(n)))
+        scale_parity = {"all_devices_eq_device0": ok, "ranks": n, "note": "the same (z, r, s) proved once on every device's replica"}
+    log(f"scale_parity: {ok}")
+
     steps(args.warmup)
     sync_all()
     t0 = time.perf_counter()
@@ -162,6 +199,10 @@ def bench_single_process_multi(args):
                    "parallelism": (f"base-sharded x{n}, in-library exchange (zkp_groth16_prove_multi)" if shard
                                    else f"independent proofs x{n}, one process, one host thread per GPU (zkp_groth16_prove_batch_multi)"),
                    "launch": "single process (no torchrun): the C-ABI multi-GPU path"},
+        "scale_parity": scale_parity,
+        "exchange": (dict(mpk.info(), call="inside zkp_groth16_prove_multi: ncclAllGather when the devices are distinct, else "
+                                            "hipMemcpyPeerAsync (said on stderr); witness-map variant measured on proofs 3-4 of the key")
+                     if shard else {"kind": "none (independent proofs, replicated key)", "devices": n}),
         "roofline": None, "cpu_baseline": None}), flush=True)
     for k, d in enumerate(zds):
         m.member(k).dev_free(d)
@@ -819,6 +860,10 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "hbm_peak_measured": hbm_meas,
             "roofline_ntt": roofline_ntt, "roofline_scan": roofline_scan, "valu_roof": valu_roof,
             "with_h2d": with_h2d, "latency": latency, "parity_check": parity_check, "scale_parity": scale_parity,
+            "exchange": None if world == 1 else {"kind": "none on the data path (independent proofs per rank, replicated key)",
+                                                 "control": ("gloo (TEST ONLY)" if args.single_device_test else "rccl") +
+                                                            ": barrier + max-over-ranks all_reduce + the scale_parity all_gather",
+                                                 "ranks": world},
             "msm_g1": msm_g1, "marlin_config4": marlin, **extra,
             "phases_ms": phases, "bench_wall_s": round(time.time() - t_start, 1),
         }

@@ -84,6 +84,7 @@ SIGNATURES = {
     "zkp_ctx_device": (C.c_int32, [vp, C.c_int32, C.POINTER(vp)]),
     "zkp_groth16_pk_upload_multi": (C.c_int32, [vp, C.POINTER(Groth16PkDesc), C.c_int32, C.POINTER(vp)]),
     "zkp_groth16_pk_multi_free": (C.c_int32, [vp, vp]),
+    "zkp_groth16_multi_info": (C.c_int32, [vp, vp, u64p]),
     "zkp_groth16_prove_multi": (C.c_int32, [vp, vp, vp, C.c_int32, vp, vp, vp, vp]),
     "zkp_groth16_prove_batch_multi": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_int32, vp, vp, vp, vp]),
     "zkp_ctx_set_stream": (C.c_int32, [vp, vp]),

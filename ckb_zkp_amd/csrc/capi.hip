@@ -506,6 +506,11 @@ int32_t zkp_groth16_pk_multi_free(zkp_ctx* ctx, zkp_groth16_pk_multi* pk) {
   if (!ctx || !pk || ctx->devs.empty()) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { groth16_pk_multi_free(ctx, pk); });
 }
+int32_t zkp_groth16_multi_info(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, uint64_t info[6]) {
+  if (!ctx || !pk || !info || ctx->devs.empty()) return ZKP_ERR_BAD_ARG;
+  groth16_multi_info(ctx, pk, info);
+  return ZKP_OK;
+}
 int32_t zkp_groth16_prove_multi(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, const uint64_t* const* z, int32_t z_on_device,
                                 const uint64_t* r, const uint64_t* s, uint64_t* proof, uint8_t* inf) {
   if (!ctx || !pk || !z || !z[0] || !r || !s || !proof || !inf || ctx->devs.empty()) return ZKP_ERR_BAD_ARG;

@@ -886,6 +886,9 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
 }  // namespace zkp
 #include <dlfcn.h>
 
+#include <chrono>
+#include <string>
+
 #include <thread>
 struct zkp_groth16_pk_multi {
   int mode = 0, curve = 0;
@@ -895,6 +898,13 @@ struct zkp_groth16_pk_multi {
   void* gathered = nullptr;                 // device 0: n x partials bytes
   std::vector<void*> gathered_all;          // RCCL exchange: a receive buffer on every device
   std::vector<void*> partial;               // per device: 5 XYZZ slots
+  // run-time choices of the sharded prover (zkp_groth16_multi_info): which exchange carried the last proof, and whether the
+  // three chains of the witness map are split over devices 0..2 — measured on this key's own first proofs, not assumed
+  int exchange = 0;                         // 0 = peer copies, 1 = RCCL all-gather
+  int rccl_ranks = 0;
+  int split_choice = -1;                    // -1 undecided, 0 replicated witness map, 1 three-way split
+  int calls = 0;
+  double ms_variant[2] = {0.0, 0.0};        // wall time of a proof with the replicated / split witness map (calls 3 and 4)
 };
 namespace zkp {
 
@@ -984,10 +994,37 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
   const int n = (int)root->devs.size();
   const MsmVtbl* v2 = msm_vtbl(M->curve, 2);
   const size_t slot = v2->xyzz_bytes, pb = 5 * slot;
-  static const bool split_env = !(getenv("ZKP_MULTI_WM_SPLIT") && atoi(getenv("ZKP_MULTI_WM_SPLIT")) == 0);
-  const bool split = split_env && n >= 3;
-  static const bool want_rccl = getenv("ZKP_MULTI_EXCHANGE") && std::string(getenv("ZKP_MULTI_EXCHANGE")) == "rccl";
-  const bool use_rccl = want_rccl && n > 1 && rccl().ready(root->devs);
+  // Witness map: replicated on every device, or its a / b / c chains on devices 0 / 1 / 2 with two N x 32-byte vectors shipped to
+  // device 0 and the slices of h shipped back (n >= 3).  Which one is faster depends on the link (one xGMI hop vs. a PCIe switch)
+  // and on the domain, so the key MEASURES it: proofs 1-2 warm both variants up, proofs 3-4 time them (wall clock of the whole
+  // call, same witness), from proof 5 on the faster one runs.  The proof bytes do not depend on the choice.
+  // ZKP_MULTI_WM_SPLIT=0 / 1 forces a variant.
+  static const int split_env = getenv("ZKP_MULTI_WM_SPLIT") ? atoi(getenv("ZKP_MULTI_WM_SPLIT")) : -1;
+  bool split = false;
+  const int call = M->calls++;
+  if (n >= 3) {
+    if (split_env >= 0) M->split_choice = split_env ? 1 : 0;
+    if (M->split_choice >= 0) split = M->split_choice == 1;
+    else split = (call & 1) == 1;                                   // calls 0, 2: replicated; 1, 3: split
+  } else {
+    M->split_choice = 0;
+  }
+  const auto t_call = std::chrono::steady_clock::now();
+  // Exchange: RCCL all-gather (the exchange BASELINE.json names) whenever the devices are distinct and librccl loads; peer copies
+  // otherwise, said once on stderr.  ZKP_MULTI_EXCHANGE=peer / rccl forces one.
+  static const std::string want = getenv("ZKP_MULTI_EXCHANGE") ? getenv("ZKP_MULTI_EXCHANGE") : "auto";
+  bool use_rccl = false;
+  if (n > 1 && want != "peer") {
+    use_rccl = rccl().ready(root->devs);
+    static bool told = false;
+    if (!use_rccl && !told) {
+      told = true;
+      fprintf(stderr, "[zkp_accel] sharded prover: RCCL all-gather unavailable (%s) — the partial sums travel by peer copies\n",
+              rccl().lib ? "duplicate device ids or ncclCommInitAll failed" : "librccl.so not loadable");
+    }
+  }
+  M->exchange = use_rccl ? 1 : 0;
+  M->rccl_ranks = use_rccl ? n : 0;
   std::vector<uint32_t*> S(n), h(n, nullptr);
   std::vector<char*> res(n);
   // phase 1 — every device: inputs, the four z-MSMs over its slices on the MSM streams, its part of the witness map
@@ -1099,6 +1136,10 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
     ZKP_HIP(hipStreamSynchronize(root->devs[k]->cur->stream));
   }
   ZKP_HIP(hipSetDevice(c0->device));
+  if (n >= 3 && M->split_choice < 0 && call >= 2) {
+    M->ms_variant[split ? 1 : 0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+    if (call >= 3) M->split_choice = M->ms_variant[1] < M->ms_variant[0] ? 1 : 0;
+  }
 }
 }  // namespace
 
@@ -1156,6 +1197,17 @@ void groth16_pk_multi_free(zkp_ctx* root, zkp_groth16_pk_multi* M) {
   if (M->ev_h) (void)hipEventDestroy(M->ev_h);
   (void)hipSetDevice(root->device);
   delete M;
+}
+
+// info[0] = exchange of the last proof (0 peer copies, 1 RCCL all-gather), [1] = RCCL ranks, [2] = witness map (0 replicated, 1 split
+// over devices 0..2, 2 = still measuring), [3] / [4] = microseconds of the timed proof with the replicated / split map, [5] = devices
+void groth16_multi_info(zkp_ctx* root, zkp_groth16_pk_multi* M, uint64_t info[6]) {
+  info[0] = (uint64_t)M->exchange;
+  info[1] = (uint64_t)M->rccl_ranks;
+  info[2] = M->split_choice < 0 ? 2 : (uint64_t)M->split_choice;
+  info[3] = (uint64_t)(M->ms_variant[0] * 1e3);
+  info[4] = (uint64_t)(M->ms_variant[1] * 1e3);
+  info[5] = (uint64_t)root->devs.size();
 }
 
 void groth16_prove_multi(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const* z, bool z_on_device,

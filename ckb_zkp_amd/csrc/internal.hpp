@@ -105,6 +105,7 @@ void groth16_assemble(zkp_ctx* ctx, int curve, const uint64_t* sums_xyz, const u
 // proof over all devices), 1 = replicated key (independent proofs round-robin)
 zkp_groth16_pk_multi* groth16_pk_upload_multi(zkp_ctx* root, const zkp_groth16_pk_desc* d, int mode);
 void groth16_pk_multi_free(zkp_ctx* root, zkp_groth16_pk_multi* pk);
+void groth16_multi_info(zkp_ctx* root, zkp_groth16_pk_multi* pk, uint64_t info[6]);
 void groth16_prove_multi(zkp_ctx* root, zkp_groth16_pk_multi* pk, const uint64_t* const* z, bool z_on_device, const uint64_t* r,
                          const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 void groth16_prove_batch_multi(zkp_ctx* root, zkp_groth16_pk_multi* pk, size_t n, const uint64_t* const* z, bool z_on_device,

@@ -363,6 +363,14 @@ class MultiProvingKey:
             _lib.check(self.ctx.lib.zkp_groth16_pk_multi_free(self.ctx.h, self.h), "zkp_groth16_pk_multi_free")
             self.h = None
 
+    def info(self) -> dict:
+        """zkp_groth16_multi_info: what the last sharded proof did (exchange, witness-map variant and its measured times)"""
+        v = (C.c_uint64 * 6)()
+        _lib.check(self.ctx.lib.zkp_groth16_multi_info(self.ctx.h, self.h, v), "zkp_groth16_multi_info")
+        return {"exchange": "rccl" if v[0] else "peer", "rccl_ranks": int(v[1]),
+                "witness_map": ("replicated", "split over devices 0..2", "measuring")[int(v[2])],
+                "ms_replicated": v[3] / 1e3, "ms_split": v[4] / 1e3, "devices": int(v[5])}
+
     def prove_raw(self, z, r_mont, s_mont, z_on_device: bool = False):
         """SHARD key.  z: (nz, 4) host array, or — z_on_device — a list of one device pointer per rank."""
         c = self.curve

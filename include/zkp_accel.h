@@ -304,12 +304,20 @@ int32_t zkp_groth16_fold_assemble_dev(zkp_ctx* ctx, zkp_curve_t curve, const voi
  *                            tables (BASELINE configs[4]: keys that do not fit one GPU; lower single-proof latency);
  *       ZKP_MULTI_REPLICATE  the whole key on every device (throughput: independent proofs on independent GPUs).
  *   zkp_groth16_prove_multi        (SHARD key) ONE proof over all devices: partial MSMs per device, the five partial sums
- *                          gathered on rank 0 over xGMI (hipMemcpyPeerAsync of n x zkp_groth16_partials_bytes; an RCCL
- *                          ncclAllGather instead with ZKP_MULTI_EXCHANGE=rccl), slot-wise fold + assembly on rank 0.  With
- *                          n >= 3 the witness map is task-split: the a / b / c chains of r1cs_to_qap.rs:144-162 run on ranks
- *                          0 / 1 / 2, rank 0 finishes h and every rank fetches its slice of h for its share of the H MSM
- *                          (ZKP_MULTI_WM_SPLIT=0: replicated witness map).  z_on_device == 0: z[0] is the host assignment;
- *                          != 0: z[k] is a device pointer on rank k's device, k < n.
+ *                          exchanged over xGMI — an RCCL ncclAllGather of n x zkp_groth16_partials_bytes whenever the
+ *                          devices are distinct and librccl.so loads (dlopen, no link-time dependency), else
+ *                          hipMemcpyPeerAsync to rank 0, said once on stderr (ZKP_MULTI_EXCHANGE=rccl / peer forces one) —
+ *                          then slot-wise fold + assembly on rank 0.  With n >= 3 the witness map can be task-split: the
+ *                          a / b / c chains of r1cs_to_qap.rs:144-162 on ranks 0 / 1 / 2, rank 0 finishes h and every rank
+ *                          fetches its slice of h for its share of the H MSM.  Whether that beats the replicated map depends
+ *                          on the link, so the key measures both on its own proofs 3 and 4 (1 and 2 warm them up) and keeps
+ *                          the faster from proof 5 on; the proof bytes do not depend on it (ZKP_MULTI_WM_SPLIT=0 / 1
+ *                          forces).  z_on_device == 0: z[0] is the host assignment; != 0: z[k] is a device pointer on rank
+ *                          k's device, k < n.
+ *   zkp_groth16_multi_info  what the last zkp_groth16_prove_multi did: info[0] = exchange (0 peer copies, 1 RCCL all-gather),
+ *                          info[1] = RCCL ranks, info[2] = witness map (0 replicated, 1 split, 2 still measuring), info[3] /
+ *                          info[4] = microseconds of the timed proof with the replicated / split map (0 = not measured),
+ *                          info[5] = devices.
  *   zkp_groth16_prove_batch_multi  (REPLICATE key) `count` independent proofs, proof i on rank i % n (z[i] host, or a device
  *                          pointer on that rank's device), one host thread per device driving its lanes as
  *                          zkp_groth16_prove_batch does; outputs in input order. */
@@ -321,6 +329,7 @@ int32_t zkp_ctx_device(zkp_ctx* ctx, int32_t rank, zkp_ctx** member);
 int32_t zkp_groth16_pk_upload_multi(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, int32_t mode,
                                     zkp_groth16_pk_multi** out);
 int32_t zkp_groth16_pk_multi_free(zkp_ctx* ctx, zkp_groth16_pk_multi* pk);
+int32_t zkp_groth16_multi_info(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, uint64_t info[6]);
 int32_t zkp_groth16_prove_multi(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, const uint64_t* const* z, int32_t z_on_device,
                                 const uint64_t* r, const uint64_t* s, uint64_t* proof_out, uint8_t* inf_out);
 int32_t zkp_groth16_prove_batch_multi(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, size_t count, const uint64_t* const* z,

@@ -166,3 +166,46 @@ def test_device_sharded_prover_multiprocess_gloo_on_one_gpu(world):
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     # (the ranks share one stdout pipe: their lines can land on one line, so count occurrences, not lines)
     assert out.stdout.count("SHARDED_OK rank") == world, out.stdout[-2000:]
+
+
+def _bench_line(args, torchrun_world=0, timeout=1500):
+    env = dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="16")
+    if torchrun_world:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={torchrun_world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    import json
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0]), out.stderr
+
+
+def test_bench_torchrun_two_ranks_reports_scale_parity_and_exchange():
+    """`bench.py --gpus 2` as the driver launches it (torchrun, one process per rank), both ranks on cuda:0 with the test-only gloo
+    control plane: throughput mode and the base-sharded mode print scale_parity (checked before the timed region) and exchange."""
+    line, _ = _bench_line(["--gpus", "2", "--steps", "4", "--warmup", "2", "--log-n", "12", "--single-device-test",
+                           "--no-cpu-baseline", "--no-marlin", "--no-extra-configs"], torchrun_world=2)
+    assert line["n_gpus"] == 2 and line["scale_parity"]["all_ranks_eq_rank0"] is True and line["scale_parity"]["ranks"] == 2
+    assert line["exchange"]["ranks"] == 2 and "none on the data path" in line["exchange"]["kind"]
+    line, _ = _bench_line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--log-n", "12", "--single-device-test", "--mode", "shard"],
+                          torchrun_world=2)
+    assert line["scaling"] == "strong" and line["scale_parity"]["sharded_eq_single_gpu"] is True
+    assert line["exchange"]["ranks"] == 2 and line["exchange"]["bytes_per_rank"] > 0
+
+
+def test_bench_single_process_three_ranks_measures_the_witness_split():
+    """`bench.py --devices 0,0,0 --mode shard` (zkp_ctx_create_multi + zkp_groth16_prove_multi): scale_parity holds, the exchange
+    falls back to peer copies LOUDLY (RCCL refuses duplicate devices) and the witness-map variant is the measured one: both
+    variants were timed on the key's own proofs and the faster was kept."""
+    line, err = _bench_line(["--devices", "0,0,0", "--mode", "shard", "--steps", "6", "--warmup", "5", "--log-n", "14"])
+    assert line["n_gpus"] == 3 and line["scale_parity"]["sharded_eq_single_gpu"] is True
+    ex = line["exchange"]
+    assert ex["exchange"] == "peer" and ex["rccl_ranks"] == 0 and ex["devices"] == 3
+    assert "RCCL all-gather unavailable" in err
+    assert ex["witness_map"] in ("replicated", "split over devices 0..2") and ex["ms_replicated"] > 0 and ex["ms_split"] > 0
+    assert (ex["witness_map"] == "replicated") == (ex["ms_replicated"] <= ex["ms_split"])
+    line, _ = _bench_line(["--devices", "0,0", "--steps", "4", "--warmup", "2", "--log-n", "12"])
+    assert line["n_gpus"] == 2 and line["scale_parity"]["all_devices_eq_device0"] is True
