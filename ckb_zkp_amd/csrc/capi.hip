@@ -65,6 +65,16 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
   // hardware queues (default 4) and streams that share a queue serialise; 16 queues measured best on MI355X
   // (84 -> 95 proofs/s at 2^20).  The library does NOT touch the process environment: the host exports
   // GPU_MAX_HW_QUEUES=16 before its first HIP call (the Python package and bench.py do so).
+  {
+    static bool warned = false;
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    if (!warned && (!q || atoi(q) < 16)) {
+      warned = true;
+      fprintf(stderr, "[zkp_accel] GPU_MAX_HW_QUEUES is %s: the pipelined provers keep ~32 HIP streams busy and lose about 10 %% of "
+                      "their throughput on the default 4 hardware queues — export GPU_MAX_HW_QUEUES=16 before the process makes its "
+                      "first HIP call (INTEGRATION.md)\n", q ? q : "unset");
+    }
+  }
   zkp_ctx* ctx = new (std::nothrow) zkp_ctx();
   if (!ctx) return ZKP_ERR_OOM;
   ctx->device = device_id;

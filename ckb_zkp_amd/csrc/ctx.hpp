@@ -138,6 +138,7 @@ struct zkp_ctx {
   // the next MSM accumulates on top of the buckets workspace `msm_acc_into` holds and reduces the sum.  Both reset by msm_run.
   bool msm_defer_reduce = false;
   int msm_acc_into = -1;
+  int msm_bucket_ws = -1;      // >= 0: the next MSM keeps its buckets in the bucket array of that workspace (chunked MSMs, msm.hip msm_run)
   bool dbg_skip_k8 = false;    // ABLATION ONLY (ZKP_DEBUG_SKIP_K8_MASK): the next MSM skips its bucket reduction — wrong results, timing experiments
   bool batch_mode = false;     // inside zkp_groth16_prove_batch*: kernels are tuned for throughput of many proofs in flight, not latency
   std::map<std::pair<int, int>, zkp::NttTables> ntt_tables;   // (curve, log_n)

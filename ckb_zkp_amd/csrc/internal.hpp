@@ -24,6 +24,8 @@ void fr_gather(zkp_ctx* ctx, const uint64_t* in, const int32_t* idx, size_t n, u
 void poly_vanishing_fold(zkp_ctx* ctx, int curve, const uint64_t* p, size_t len, size_t n, uint64_t* q, uint64_t* rem);
 void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const uint64_t* z_host, uint64_t* q,
                      uint64_t* eval_out_host);
+void poly_evaluate_batch(zkp_ctx* ctx, int curve, size_t count, const uint64_t* const* p, const size_t* n, const uint64_t* z_host,
+                         uint64_t* out_host);
 
 // msm.hip
 // c_hint > 0: window bits chosen by the caller (Groth16: the B queries are sized by their NON-identity bases); cap_hint > 0:

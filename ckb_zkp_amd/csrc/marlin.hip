@@ -694,28 +694,35 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   // kernels that compute the rest of the round (which otherwise run alone: 12.6 + 4.9 ms per proof in a kernel trace);
   // commit_round collects the result instead of launching the MSM.  ZKP_MARLIN_EARLY=0: every MSM inside commit_round.
   static const bool early_on = !(getenv("ZKP_MARLIN_EARLY") && atoi(getenv("ZKP_MARLIN_EARLY")) == 0);
-  constexpr int EARLY_MAX = 4;
+  constexpr int EARLY_MAX = 8;
   if (!ix->early_pinned) ZKP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->early_pinned), EARLY_MAX * 24 * 8));
   struct Early {
     int label, ws;
+    bool shifted;
   };
   std::vector<Early> early;
-  // -> index into `early` (-1: not started, the caller runs the MSM itself later)
-  auto start_early = [&](int label, const DVec& v) -> int {
+  // -> index into `early` (-1: not started, the caller runs the MSM itself later).  offset: first SRS power (shifted commitments)
+  auto start_early = [&](int label, const DVec& v, size_t offset = 0, bool shifted = false) -> int {
     if (!early_on || (int)early.size() >= EARLY_MAX || v.n == 0) return -1;
     zkp_lane* L = ctx->cur;
     const int w = 1 + (int)(early.size() % (zkp_lane::N_WS - 1));
     hipStream_t ws_st = L->ws[w].stream;
     ZKP_HIP(hipEventRecord(L->ev_fork, st));                         // v is complete on the prover's stream
     ZKP_HIP(hipStreamWaitEvent(ws_st, L->ev_fork, 0));
-    const size_t n = std::min(v.n, bases_len(ctx, powers_g));        // ark min(len) truncation, as msm_run_multi
-    msm_run(ctx, powers_g, 0, v.p, n, true, nullptr, nullptr, nullptr, nullptr, w);
+    ZKP_REQUIRE(offset <= bases_len(ctx, powers_g), ZKP_ERR_BAD_ARG);
+    const size_t n = std::min(v.n, bases_len(ctx, powers_g) - offset);   // ark min(len) truncation, as msm_run_multi
+    msm_run(ctx, powers_g, offset, v.p, n, true, nullptr, nullptr, nullptr, nullptr, w);
     ZKP_HIP(hipMemcpyAsync(ix->early_pinned + early.size() * 24, L->ws[w].out.p, jw64 * 8, hipMemcpyDeviceToHost, ws_st));
     ZKP_HIP(hipEventRecord(L->ws[w].done, ws_st));
-    early.push_back({label, w});
+    early.push_back({label, w, shifted});
     return (int)early.size() - 1;
   };
-  auto commit_early = [&](int l) { (void)start_early(l, poly[l]); };
+  const size_t bound_of[NLAB] = {0, 0, 0, 0, 0, hs - 2, 0, ks - 2, 0};
+  // a polynomial that is final: its commitment MSM (and the one against the shifted powers of a degree-bounded polynomial) starts now
+  auto commit_early = [&](int l) {
+    (void)start_early(l, poly[l]);
+    if (bounded[l]) (void)start_early(l, poly[l], D - bound_of[l], true);
+  };
 
   commit_early(MASK_);
   // ---- first round (prover.rs:150-222)
@@ -730,9 +737,12 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     return p;
   };
   DVec w_poly = be.fold(masked(w_on_h, fr_of(rnd->w)), xs).first;
-  DVec z_a = masked(z_a_ev, fr_of(rnd->z_a)), z_b = masked(z_b_ev, fr_of(rnd->z_b));
   poly[W_] = w_poly;
+  commit_early(W_);                                    // under the interpolations of z_a and z_b
+  DVec z_a = masked(z_a_ev, fr_of(rnd->z_a));
   poly[ZA_] = z_a;
+  commit_early(ZA_);
+  DVec z_b = masked(z_b_ev, fr_of(rnd->z_b));
   poly[ZB_] = z_b;
   const bool hide[NLAB] = {true, true, true, false, false, true, false, false, false};
   const size_t bound[NLAB] = {0, 0, 0, 0, 0, hs - 2, 0, ks - 2, 0};
@@ -750,23 +760,25 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     std::vector<const uint64_t*> ptrs;
     std::vector<std::pair<int, bool>> slot;
     std::vector<std::pair<int, size_t>> early_slot;                 // (label, index into `early`) of the polynomials already under way
+    auto find_early = [&](int l, bool shifted) {
+      for (size_t e = 0; e < early.size(); e++)
+        if (early[e].label == l && early[e].shifted == shifted) return (int)e;
+      return -1;
+    };
+    std::vector<bool> early_shifted;
     for (int l : labels) {
-      size_t e = 0;
-      while (e < early.size() && early[e].label != l) e++;
-      if (e < early.size() && !bounded[l]) {
-        tm.commit_points += poly[l].n;
-        early_slot.push_back({l, e});
-        continue;
-      }
-      offs.push_back(0);
-      ns.push_back(poly[l].n);
-      ptrs.push_back(poly[l].p);
-      slot.push_back({l, false});
-      if (bounded[l]) {                                // shifted_powers(bound) = powers[D - bound ..]
-        offs.push_back(D - bound[l]);
+      for (int sh = 0; sh <= (bounded[l] ? 1 : 0); sh++) {
+        const int e = find_early(l, sh != 0);
+        if (e >= 0) {
+          tm.commit_points += poly[l].n;
+          early_slot.push_back({l, (size_t)e});
+          early_shifted.push_back(sh != 0);
+          continue;
+        }
+        offs.push_back(sh ? D - bound[l] : 0);                       // shifted_powers(bound) = powers[D - bound ..]
         ns.push_back(poly[l].n);
         ptrs.push_back(poly[l].p);
-        slot.push_back({l, true});
+        slot.push_back({l, sh != 0});
       }
     }
     for (size_t nn : ns) tm.commit_points += nn;
@@ -775,9 +787,9 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     if (!early_slot.empty()) {
       for (auto& es : early_slot) ZKP_HIP(hipStreamWaitEvent(st, ctx->cur->ws[early[es.second].ws].done, 0));
       ZKP_HIP(hipStreamSynchronize(st));
-      for (auto& es : early_slot) {
-        memcpy(jac.data() + slot.size() * jw64, ix->early_pinned + es.second * 24, jw64 * 8);
-        slot.push_back({es.first, false});
+      for (size_t i = 0; i < early_slot.size(); i++) {
+        memcpy(jac.data() + slot.size() * jw64, ix->early_pinned + early_slot[i].second * 24, jw64 * 8);
+        slot.push_back({early_slot[i].first, (bool)early_shifted[i]});
       }
     }
     std::vector<size_t> boffs, bns;
@@ -864,6 +876,8 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     be.axpy_into(acc, be.mul(ix->on_k[m][2], inv), etas[m]);
   }
   DVec t3 = be.ifft(be.scale(acc, vab), ks);
+  poly[G2_] = t3.view(1, ks);
+  commit_early(G2_);                                   // g_2 and its shifted commitment run under the |B|-sized transforms below
   DVec den[3];
   const FrE ab = F.mul(alpha, beta);
   for (int m = 0; m < 3; m++)
@@ -899,9 +913,21 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   std::sort(query.begin(), query.end(), [](const Q& a, const Q& b) { return a.label < b.label; });
   ZKP_REQUIRE(query.size() == ZKP_MARLIN_NUM_EVALS, ZKP_ERR_BAD_ARG);
   std::vector<uint8_t> ev_bytes;
+  {
+    // all 21 Horner chains are enqueued, then ONE read-back (a host round trip per polynomial cost 2.5 ms of a proof)
+    std::vector<const uint64_t*> qp(query.size());
+    std::vector<size_t> qn(query.size());
+    std::vector<uint64_t> qz(4 * query.size());
+    for (size_t i = 0; i < query.size(); i++) {
+      qp[i] = query[i].p.p;
+      qn[i] = query[i].p.n;
+      memcpy(qz.data() + 4 * i, (query[i].at_beta ? beta : gamma).data(), 32);
+    }
+    poly_evaluate_batch(ctx, curve, query.size(), qp.data(), qn.data(), qz.data(), out->evaluations);
+  }
   for (size_t i = 0; i < query.size(); i++) {
-    const FrE e = be.evaluate(query[i].p, query[i].at_beta ? beta : gamma);
-    memcpy(out->evaluations + 4 * i, e.data(), 32);
+    FrE e{};
+    memcpy(e.data(), out->evaluations + 4 * i, 32);
     const FrE c = F.to_canonical(e);
     const uint8_t* b = reinterpret_cast<const uint8_t*>(c.data());
     ev_bytes.insert(ev_bytes.end(), b, b + 32);

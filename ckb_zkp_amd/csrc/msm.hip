@@ -821,8 +821,42 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
     }
   } chain_reset{ctx};
   auto be = get_bases(ctx, handle);
-  msm_run_entry(ctx, be.get(), offset, scalars_dev, n, montgomery, out_xyz_host, out_dev_xyzz, ms_accumulate, n_entries,
-                ws_idx, sort_src, ms_scan, l1_src);
+  // Chunked MSM (round 4): a large MSM that runs on its own (Marlin's h_2 and opening witnesses: 6.3 M points) spent 3 ms in its
+  // bucket sort — memory-bound kernels with the vector ALUs idle — before 5.6 ms of VALU-bound accumulation.  Split by index into
+  // chunks that share ONE bucket array (bucket chaining: every chunk but the last defers the reduction, every chunk but the first
+  // accumulates on top of the stored buckets), alternating between this workspace and its partner (ws ^ 2: own stream and sort
+  // scratch), so that the sort of chunk k + 1 runs under the accumulation of chunk k.  The result is the same group element.
+  // ZKP_MSM_CHUNK=<points per chunk> (0 = off); not for MSMs that share a sort, belong to a sort group, are profiled, or are
+  // part of a caller's own bucket chain.
+  const char* ce = getenv("ZKP_MSM_CHUNK");
+  const size_t chunk_pts = ce ? (size_t)strtoull(ce, nullptr, 0) : ((size_t)3 << 19);
+  const bool chunkable = chunk_pts >= 1024 && n >= 2 * chunk_pts && be->group == 1 && !be->var && sort_src < 0 && l1_src < 0 &&
+                         !be->group_flags && !ctx->profiling && !ms_accumulate && !ms_scan && !n_entries &&
+                         !ctx->msm_defer_reduce && ctx->msm_acc_into < 0 && ctx->msm_bucket_ws < 0 && !ctx->batch_mode;
+  if (!chunkable) {
+    msm_run_entry(ctx, be.get(), offset, scalars_dev, n, montgomery, out_xyz_host, out_dev_xyzz, ms_accumulate, n_entries,
+                  ws_idx, sort_src, ms_scan, l1_src);
+    return;
+  }
+  const size_t nch = (n + chunk_pts - 1) / chunk_pts, per = ((n + nch - 1) / nch + 255) & ~(size_t)255;
+  const int wa = ws_idx, wb = ws_idx ^ 2;                               // partner: 0 <-> 2, 1 <-> 3
+  hipStream_t sa = wa == 0 ? ctx->cur->stream : ctx->cur->ws[wa].stream, sb = wb == 0 ? ctx->cur->stream : ctx->cur->ws[wb].stream;
+  // the partner's stream joins behind everything this MSM's stream has seen (scalars complete, bucket array of `wa` free)
+  ZKP_HIP(hipEventRecord(ctx->cur->ws[wa].l1_done, sa));
+  ZKP_HIP(hipStreamWaitEvent(sb, ctx->cur->ws[wa].l1_done, 0));
+  size_t done = 0;
+  for (size_t k = 0; k < nch; k++) {
+    const size_t len = std::min(per, n - done);
+    const bool last = k + 1 == nch;
+    const int w = ((nch - 1 - k) & 1) ? wb : wa;                        // the last chunk runs on `wa`: result, `done` event, read-back
+    ctx->msm_defer_reduce = !last;
+    ctx->msm_acc_into = k > 0 ? wa : -1;
+    ctx->msm_bucket_ws = wa;
+    msm_run_entry(ctx, be.get(), offset + done, scalars_dev + 4 * done, len, montgomery, last ? out_xyz_host : nullptr,
+                  last ? out_dev_xyzz : nullptr, nullptr, nullptr, w, -1, nullptr, -1);
+    done += len;
+  }
+  // the partner stream's last chunk was consumed by a later chunk on `sa` through the acc_done event; nothing of this MSM is left on `sb`
 }
 
 // Reduction plan of the variable-base mode (per (c, W), cached in the context): block descriptors for the two
@@ -874,9 +908,11 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
   // bucket chaining (ctx.hpp): one-shot requests, consumed by this MSM
   const bool defer = ctx->msm_defer_reduce;
   const int into = ctx->msm_acc_into;
+  const int bucket_ws = into >= 0 ? into : ctx->msm_bucket_ws;
   ctx->msm_defer_reduce = false;
   ctx->msm_acc_into = -1;
-  ZKP_REQUIRE(!(defer || into >= 0) || (n > 0 && !be->var && be->group == 1 && !(defer && into >= 0)), ZKP_ERR_BAD_ARG);   // G1 only (msm_acc.hip)
+  ctx->msm_bucket_ws = -1;
+  ZKP_REQUIRE(!(defer || into >= 0) || (n > 0 && !be->var && be->group == 1), ZKP_ERR_BAD_ARG);   // G1 only (msm_acc.hip)
   // sort_src: workspace whose sorted entries + task schedule this MSM reuses (same scalars, window configuration and identity
   // pattern); sort_src == ws_idx = the MSM that ran on this workspace just before (A -> L on one stream)
   const bool reuse = sort_src >= 0;
@@ -1009,14 +1045,14 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     // all-zero bytes are a valid identity (zz == 0), so empty buckets need no kernel
     // (into >= 0: the bucket array of workspace `into`, which holds the finished buckets of an MSM over the same bucket range;
     //  its accumulate + combine must be complete before this one's start)
-    MsmWorkspace& bws = into >= 0 ? ctx->cur->ws[into] : ws;
+    MsmWorkspace& bws = bucket_ws >= 0 ? ctx->cur->ws[bucket_ws] : ws;
     char* buckets = reinterpret_cast<char*>(bws.buckets.get((size_t)2 * nb * XB + XB));
     char* task_partial = reinterpret_cast<char*>(ws.partial.get((size_t)max_tasks * XB));
     static const bool zero_all = getenv("ZKP_MEMSET_BUCKETS") && atoi(getenv("ZKP_MEMSET_BUCKETS")) != 0;   // A/B: round-2 behaviour
     const uint32_t init = into >= 0 ? 1u : 0u;
     if (init) {
       ZKP_REQUIRE(bws.chain_nb == nb && bws.chain_xb == XB, ZKP_ERR_BAD_ARG);
-      if (into != ws_idx) ZKP_HIP(hipStreamWaitEvent(st, bws.acc_done, 0));
+      ZKP_HIP(hipStreamWaitEvent(st, bws.acc_done, 0));        // (recorded on whichever stream ran the MSM that filled them)
     } else if (zero_all) ZKP_HIP(hipMemsetAsync(buckets, 0, (size_t)nb * XB, st));
     else hipLaunchKernelGGL(zero_empty_buckets_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, start, end, nb, buckets, (uint32_t)XB);
     bws.chain_nb = 0;
@@ -1087,9 +1123,9 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     if (defer) {
       // the buckets stay as they are for the MSM that reduces them together with its own (msm_acc_into); this one contributes
       // the identity to whatever sums the results
-      ws.chain_nb = nb;
-      ws.chain_xb = XB;
-      ZKP_HIP(hipEventRecord(ws.acc_done, st));
+      bws.chain_nb = nb;
+      bws.chain_xb = XB;
+      ZKP_HIP(hipEventRecord(bws.acc_done, st));
       vt->write_identity(st, (char*)out_dev_xyzz, out_jac);
       ZKP_HIP(hipGetLastError());
       ZKP_REQUIRE(!out_xyz_host, ZKP_ERR_BAD_ARG);

@@ -403,8 +403,18 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
 // LDS: limb planes of PLANE = TILE + TILE/8 words (8 pad words per 64: the four rows a lane touches in the early stages are
 // 4h rows apart, which would otherwise land in the same banks).
 // (an XOR swizzle without padding — 39 KB, four workgroups per CU instead of three — measured the same: 142.7 vs 142.9 proofs/s)
+// Round 4: no padding but an XOR swizzle of the bank bits — position bits [4:3] ^= bits [6:5] ^ bits [9:8] — which separates the
+// same two conflict patterns (the rows a lane group touches in the first stage pair are 4 rows apart = bits [6:5] with 8 columns;
+// the bit-reversed rows of the load phase differ in bits [9:8]) at 36.9 + 2.3 KB per workgroup: FOUR workgroups per CU instead of
+// three, i.e. the 1024 workgroups of a 2^20 pass are all resident at once instead of 768 + a tail of 256.
+// -DZKP_NTT_PAD restores the padded layout.
+#ifdef ZKP_NTT_PAD
 #define NTT2_PLANE(tile) ((tile) + ((tile) >> 3))
 ZKP_DEV int ntt2_pad(int a) { return a + ((a >> 6) << 3); }
+#else
+#define NTT2_PLANE(tile) (tile)
+ZKP_DEV int ntt2_pad(int a) { return a ^ ((((a >> 5) ^ (a >> 8)) & 3) << 3); }
+#endif
 template <class P>
 ZKP_DEV Fu<P> ntt2_lds_load(const uint32_t* lds, int plane, int pos) {
   Fu<P> r;
@@ -625,23 +635,32 @@ void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* const* data, int count, int lo
   if (log_n == 0) return;  // size-1 transform is the identity (coset scale by g^0, 1/N = 1)
   NttTables& t = get_tables<P>(ctx, curve, log_n);
   const size_t N = (size_t)1 << log_n;
-  uint32_t* scratch = ctx->cur->ntt_scratch.as<uint32_t>((size_t)count * N * 8);
   int S[8], np;
   ntt_plan(log_n, S, &np);
+  // buffers: an even pass count ping-pongs data <-> scratch and ends in `data`; an odd one would end in scratch and pay a copy
+  // (13 us of a 164 us transform at 2^20: three passes) — with a second scratch region its passes go data -> s0 -> s1 -> ... ->
+  // data instead (round 4)
+  const bool odd = (np & 1) && np > 1;
+  uint32_t* scratch = ctx->cur->ntt_scratch.as<uint32_t>((size_t)count * N * 8 * (odd ? 2 : 1));
+  uint32_t* scratch2 = scratch + (size_t)count * N * 8;
   const bool inverse = (op == ZKP_NTT_IFFT || op == ZKP_NTT_COSET_IFFT);
-  // buffers alternate; pass p (0-based) writes dst if (np-1-p) even else scratch; in-place + odd np -> copy
-  const bool odd = (np & 1);
   bool in_scratch = false;
   int logB = 0;
+  const uint32_t* src_base = nullptr;                  // nullptr = the caller's vectors
   for (int p = 0; p < np; p++) {
-    bool to_scratch;
-    if (!odd) to_scratch = ((np - 1 - p) & 1) != 0;
-    else to_scratch = (p & 1) == 0;                   // ends in scratch
+    // destination of pass p: np == 1: scratch (then copied); even np: alternate so that the last lands in data; odd np >= 3:
+    // s0, s1, s0, ..., data (the last two passes use different scratch halves by construction: np - 2 is odd)
+    uint32_t* dst_base;
+    if (np == 1) dst_base = scratch;
+    else if (p == np - 1) dst_base = nullptr;
+    else if (!odd) dst_base = ((np - 1 - p) & 1) ? scratch : nullptr;
+    else dst_base = (p & 1) ? scratch2 : scratch;
     NttPassArgs a{};
     for (int k = 0; k < count; k++) {
-      a.in[k] = in_scratch ? scratch + (size_t)k * N * 8 : data[k];
-      a.out[k] = to_scratch ? scratch + (size_t)k * N * 8 : data[k];
+      a.in[k] = src_base ? src_base + (size_t)k * N * 8 : data[k];
+      a.out[k] = dst_base ? dst_base + (size_t)k * N * 8 : data[k];
     }
+    in_scratch = dst_base != nullptr;
     a.log_n = log_n;
     a.S = S[p];
     a.logB = logB;
@@ -670,7 +689,7 @@ void ntt_run_t(zkp_ctx* ctx, int curve, uint32_t* const* data, int count, int lo
       }
     }
     ntt_launch<P>(ctx->cur->stream, a, (uint32_t)(N >> (S[p] + logC)), count);
-    in_scratch = to_scratch;
+    src_base = dst_base;
     logB += S[p];
   }
   ZKP_HIP(hipGetLastError());

@@ -12,6 +12,8 @@
 // a short scan over chunk heads with z^CHUNK, then a per-chunk replay — 3 products per coefficient, log depth.
 #include <algorithm>
 
+#include <vector>
+
 #include "field_dev.hpp"
 #include "internal.hpp"
 
@@ -66,9 +68,8 @@ __global__ __launch_bounds__(256) void batch_inverse_kernel(uint32_t* __restrict
 
 // phase 1: chunk c covers coefficients [c*CH, min(n,(c+1)*CH)); head[c] = sum_j p_j z^(j - c*CH)
 template <class P>
-__global__ __launch_bounds__(256) void horner_chunk_kernel(const uint32_t* __restrict__ p, size_t n,
-                                                           const uint32_t* __restrict__ z, uint32_t* __restrict__ head,
-                                                           size_t chunks) {
+__device__ __forceinline__ void horner_chunk_body(const uint32_t* __restrict__ p, size_t n, const uint32_t* __restrict__ z,
+                                                  uint32_t* __restrict__ head, size_t chunks) {
   using F = Fp<P>;
   size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= chunks) return;
@@ -77,6 +78,25 @@ __global__ __launch_bounds__(256) void horner_chunk_kernel(const uint32_t* __res
   F acc = F::zero();
   for (size_t j = hi; j-- > lo;) acc = acc * zz + F::load(p + j * 8);
   acc.store(head + c * 8);
+}
+template <class P>
+__global__ __launch_bounds__(256) void horner_chunk_kernel(const uint32_t* __restrict__ p, size_t n,
+                                                           const uint32_t* __restrict__ z, uint32_t* __restrict__ head,
+                                                           size_t chunks) {
+  horner_chunk_body<P>(p, n, z, head, chunks);
+}
+// one evaluation of a batch (poly_evaluate_batch): blockIdx.y selects the job, so the 21 evaluations of a Marlin proof are three
+// launches instead of 63 latency-bound ones
+struct HornerJob {
+  const uint32_t* p;
+  size_t n, chunks, tiles;
+  const uint32_t* z;
+  uint32_t *head, *tile_sum, *ev;
+};
+template <class P>
+__global__ __launch_bounds__(256) void horner_chunk_batch_kernel(const HornerJob* __restrict__ jobs) {
+  const HornerJob j = jobs[blockIdx.y];
+  horner_chunk_body<P>(j.p, j.n, j.z, j.head, j.chunks);
 }
 
 // phase 2: suffix scan over chunk heads, S[c] = head[c] + zc * S[c+1] with zc = z^CHUNK, in three steps:
@@ -104,10 +124,9 @@ __device__ __forceinline__ void scan_tile(uint32_t* sv, uint32_t* sm, int t) {
   }
 }
 template <class P>
-__global__ __launch_bounds__(256) void horner_tile_kernel(uint32_t* __restrict__ head, size_t chunks,
-                                                          const uint32_t* __restrict__ z, uint32_t* __restrict__ tile_sum) {
+__device__ __forceinline__ void horner_tile_body(uint32_t* __restrict__ head, size_t chunks, const uint32_t* __restrict__ z,
+                                                 uint32_t* __restrict__ tile_sum, uint32_t* sv, uint32_t* sm) {
   using F = Fp<P>;
-  __shared__ uint32_t sv[256 * 8], sm[256 * 8];
   const int t = threadIdx.x;
   F zc = F::load(z);
   for (int i = 0; i < 5; i++) zc = zc.sqr();          // z^32 == z^POLY_CHUNK
@@ -120,12 +139,24 @@ __global__ __launch_bounds__(256) void horner_tile_kernel(uint32_t* __restrict__
   if (c < chunks) F::load(sv + (255 - t) * 8).store(head + c * 8);     // local S (as if nothing lay above the tile)
   if (t == 0) F::load(sv + 255 * 8).store(tile_sum + (size_t)blockIdx.x * 8);
 }
+template <class P>
+__global__ __launch_bounds__(256) void horner_tile_kernel(uint32_t* __restrict__ head, size_t chunks,
+                                                          const uint32_t* __restrict__ z, uint32_t* __restrict__ tile_sum) {
+  __shared__ uint32_t sv[256 * 8], sm[256 * 8];
+  horner_tile_body<P>(head, chunks, z, tile_sum, sv, sm);
+}
+template <class P>
+__global__ __launch_bounds__(256) void horner_tile_batch_kernel(const HornerJob* __restrict__ jobs) {
+  __shared__ uint32_t sv[256 * 8], sm[256 * 8];
+  const HornerJob j = jobs[blockIdx.y];
+  if (blockIdx.x >= j.tiles) return;                   // uniform per workgroup
+  horner_tile_body<P>(j.head, j.chunks, j.z, j.tile_sum, sv, sm);
+}
 // one block: suffix scan of `count` values with a constant multiplier z^(32 * 256) per step, tiles of 256 from the top
 template <class P>
-__global__ __launch_bounds__(256) void horner_scan_kernel(uint32_t* __restrict__ head, size_t count,
-                                                          const uint32_t* __restrict__ z, uint32_t* __restrict__ total) {
+__device__ __forceinline__ void horner_scan_body(uint32_t* __restrict__ head, size_t count, const uint32_t* __restrict__ z,
+                                                 uint32_t* __restrict__ total, uint32_t* sv, uint32_t* sm) {
   using F = Fp<P>;
-  __shared__ uint32_t sv[256 * 8], sm[256 * 8];
   const int t = threadIdx.x;
   F zc = F::load(z);
   for (int i = 0; i < 13; i++) zc = zc.sqr();         // z^(POLY_CHUNK * 256)
@@ -146,6 +177,18 @@ __global__ __launch_bounds__(256) void horner_scan_kernel(uint32_t* __restrict__
     __syncthreads();
   }
   if (t == 0 && total) carry.store(total);               // S[0] = p(z)
+}
+template <class P>
+__global__ __launch_bounds__(256) void horner_scan_kernel(uint32_t* __restrict__ head, size_t count,
+                                                          const uint32_t* __restrict__ z, uint32_t* __restrict__ total) {
+  __shared__ uint32_t sv[256 * 8], sm[256 * 8];
+  horner_scan_body<P>(head, count, z, total, sv, sm);
+}
+template <class P>
+__global__ __launch_bounds__(256) void horner_scan_batch_kernel(const HornerJob* __restrict__ jobs) {
+  __shared__ uint32_t sv[256 * 8], sm[256 * 8];
+  const HornerJob j = jobs[blockIdx.y];
+  horner_scan_body<P>(j.tile_sum, j.tiles, j.z, j.ev, sv, sm);
 }
 template <class P>
 __global__ __launch_bounds__(256) void horner_fix_kernel(uint32_t* __restrict__ head, size_t chunks,
@@ -455,6 +498,55 @@ void fr_batch_inverse(zkp_ctx* ctx, int curve, uint64_t* v, size_t n) {
   else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});
   else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
   ZKP_HIP(hipGetLastError());
+}
+
+// out[k] = p_k(z_k) for `count` polynomials (the 21 evaluations of lib.rs:147-156): every Horner chain is enqueued before the single
+// read-back, instead of one host round trip per polynomial.  z_host / out_host: count x 4 u64 (Montgomery).
+void poly_evaluate_batch(zkp_ctx* ctx, int curve, size_t count, const uint64_t* const* p, const size_t* n, const uint64_t* z_host,
+                         uint64_t* out_host) {
+  if (count == 0) return;
+  ZKP_REQUIRE(curve == ZKP_BN254 || curve == ZKP_BLS12_381, ZKP_ERR_UNSUPPORTED_CURVE);
+  hipStream_t st = ctx->cur->stream;
+  size_t words = 16 * count;                                          // z_k and p_k(z_k)
+  std::vector<size_t> off(count);
+  for (size_t k = 0; k < count; k++) {
+    const size_t chunks = (n[k] + POLY_CHUNK - 1) / POLY_CHUNK, tiles = (chunks + 255) / 256;
+    off[k] = words;
+    words += (chunks + tiles + 2) * 8;
+  }
+  const size_t job_words = (count * sizeof(HornerJob) + 3) / 4;
+  uint32_t* buf = ctx->poly_tmp.as<uint32_t>(words + job_words + 8);
+  uint32_t* zd = buf;
+  uint32_t* ev = buf + 8 * count;
+  HornerJob* jobs_dev = reinterpret_cast<HornerJob*>(buf + ((words + 3) & ~(size_t)3));
+  ZKP_HIP(hipMemcpyAsync(zd, z_host, 32 * count, hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipMemsetAsync(ev, 0, 32 * count, st));                     // an empty polynomial evaluates to zero
+  std::vector<HornerJob> jobs;
+  size_t max_chunks = 0, max_tiles = 0;
+  for (size_t k = 0; k < count; k++) {
+    if (n[k] == 0) continue;
+    const size_t chunks = (n[k] + POLY_CHUNK - 1) / POLY_CHUNK, tiles = (chunks + 255) / 256;
+    uint32_t* head = buf + off[k];
+    jobs.push_back(HornerJob{reinterpret_cast<const uint32_t*>(p[k]), n[k], chunks, tiles, zd + 8 * k, head, head + (chunks + 1) * 8,
+                             ev + 8 * k});
+    max_chunks = std::max(max_chunks, chunks);
+    max_tiles = std::max(max_tiles, tiles);
+  }
+  if (!jobs.empty()) {
+    ZKP_HIP(hipMemcpyAsync(jobs_dev, jobs.data(), jobs.size() * sizeof(HornerJob), hipMemcpyHostToDevice, st));
+    ZKP_HIP(hipStreamSynchronize(st));                                // `jobs` (pageable) is consumed; nothing is in flight before it anyway
+    auto go = [&](auto tag) {
+      using P = decltype(tag);
+      hipLaunchKernelGGL(horner_chunk_batch_kernel<P>, dim3((max_chunks + 255) / 256, jobs.size()), dim3(256), 0, st, jobs_dev);
+      hipLaunchKernelGGL(horner_tile_batch_kernel<P>, dim3(max_tiles, jobs.size()), dim3(256), 0, st, jobs_dev);
+      hipLaunchKernelGGL(horner_scan_batch_kernel<P>, dim3(1, jobs.size()), dim3(256), 0, st, jobs_dev);
+    };
+    if (curve == ZKP_BN254) go(Bn254Fr{});
+    else go(Bls381Fr{});
+  }
+  ZKP_HIP(hipGetLastError());
+  ZKP_HIP(hipMemcpyAsync(out_host, ev, 32 * count, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipStreamSynchronize(st));
 }
 
 // q (n-1 coeffs, may be nullptr) = p / (X - z) ; eval_out (host, may be nullptr) = p(z)

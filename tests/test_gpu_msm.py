@@ -372,3 +372,50 @@ def test_msm_many_long_buckets(ctx, curve, group, log_n, distinct):
         assert got == G.mul(G.gen, e)
     finally:
         bases.free()
+
+
+@pytest.mark.parametrize("chunk,n", [(40000, (1 << 18) - 3), (1 << 16, (1 << 18) + 777), (100000, 300001)])
+def test_chunked_msm_equals_unchunked_and_known_dlog(ctx, monkeypatch, chunk, n):
+    """Round 4: a large stand-alone G1 MSM is split by index into chunks that share one bucket array (bucket chaining) on two
+    workspaces, so that the sort of chunk k + 1 runs under the accumulation of chunk k (msm.hip msm_run, ZKP_MSM_CHUNK).  Odd and even
+    chunk counts, a ragged last chunk, zero / one / r - 1 scalars and identity bases: the result equals the unchunked MSM and the
+    known-discrete-log expectation, call after call (the workspaces are reused)."""
+    curve = "bn254"
+    c = get_curve(curve)
+    G = Group(OC[curve], 1)
+    rng = np.random.default_rng(2026)
+    d = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    d[:, 3] >>= np.uint64(4)
+    d[5] = 0                                                     # an identity base
+    g_xy, _ = to_abi_points(curve, 1, [G.gen])
+    xy, inf = ctx.fixed_base_mul(c, 1, g_xy, d)
+    assert inf[5] == 1
+    bases = ctx.upload_bases(c, 1, xy, inf)
+    k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    k[:, 3] >>= np.uint64(4)
+    k[7] = 0
+    k[8] = 0
+    k[8, 0] = 1
+    k[9] = codec.fr_canonical([c.r - 1], c)[0]
+    k[n // 2: n // 2 + 5000] = k[n // 2]                          # a run of identical scalars across a chunk boundary region
+    try:
+        e = sum(a * b for a, b in zip(codec.limbs_to_ints(d), codec.limbs_to_ints(k))) % c.r
+        want = G.mul(G.gen, e)
+        monkeypatch.setenv("ZKP_MSM_CHUNK", "0")
+        plain = jac_limbs_to_affine_oracle(curve, 1, bases.msm(k))
+        assert plain == want
+        monkeypatch.setenv("ZKP_MSM_CHUNK", str(chunk))
+        for _ in range(3):
+            assert jac_limbs_to_affine_oracle(curve, 1, bases.msm(k)) == want
+        # Montgomery-scalar batch entry point (PC::commit): two chunked MSMs in flight on partner workspaces + two plain ones
+        km = codec.fr_to_mont(codec.limbs_to_ints(k), c).reshape(-1, 4)
+        kd = ctx.to_device(km)
+        outs = bases.msm_mont_batch_dev([(kd, n, 0), (kd, n, 0), (kd, 1000, 0), (kd + 32 * 10, n - 10, 10)])
+        assert jac_limbs_to_affine_oracle(curve, 1, outs[0]) == want and jac_limbs_to_affine_oracle(curve, 1, outs[1]) == want
+        monkeypatch.setenv("ZKP_MSM_CHUNK", "0")
+        ref = bases.msm_mont_batch_dev([(kd, 1000, 0), (kd + 32 * 10, n - 10, 10)])
+        assert np.array_equal(jac_limbs_to_affine_oracle(curve, 1, outs[2]), jac_limbs_to_affine_oracle(curve, 1, ref[0]))
+        assert jac_limbs_to_affine_oracle(curve, 1, outs[3]) == jac_limbs_to_affine_oracle(curve, 1, ref[1])
+        ctx.dev_free(kd)
+    finally:
+        bases.free()

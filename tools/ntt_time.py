@@ -3,7 +3,8 @@
     python tools/ntt_time.py [curve=bn254] [log_ns=20,21,22,23]      (ZKP_ACCEL_LIB selects a build variant)"""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ckb_zkp_amd.api import Context, NTT_FFT, NTT_IFFT, NTT_COSET_FFT, NTT_COSET_IFFT
 from ckb_zkp_amd.params import get_curve
 c = get_curve(sys.argv[1] if len(sys.argv) > 1 else "bn254")

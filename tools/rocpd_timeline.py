@@ -1,29 +1,33 @@
 #!/usr/bin/env python3
-"""Kernel timeline of the LAST `span_ms` of a rocprofv3 kernel-trace database, one line per kernel (start / end in us relative to
-the window start, queue, name); kernels shorter than `min_us` are folded into a count per name.
-    python tools/rocpd_timeline.py x.db [span_ms=12] [min_us=30]"""
+"""Coarse timeline of the LAST `win` ms of a rocprofv3 kernel-trace database: per `step`-ms bucket the busy time of the kernels that
+ran in it (top 4 by busy time) — where a serial prover (Marlin) spends its wall clock, phase by phase.
+    python tools/rocpd_timeline.py x.db [win_ms=82] [step_ms=1.0]"""
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
-span = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
-min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 30.0
+win = float(sys.argv[2]) if len(sys.argv) > 2 else 82.0
+step = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 cur = db.cursor()
 syms = {r[0]: re.sub(r"\(.*", "", r[1]) for r in cur.execute("select id, kernel_name from rocpd_info_kernel_symbol")}
-cols = [r[1] for r in cur.execute("pragma table_info(rocpd_kernel_dispatch)")]
-qcol = "queue_id" if "queue_id" in cols else None
-rows = cur.execute(f"select kernel_id, start, end{', ' + qcol if qcol else ''} from rocpd_kernel_dispatch order by start").fetchall()
-t1 = max(r[2] for r in rows)
-t0 = t1 - span * 1e6
-small = {}
-for r in rows:
-    if r[2] < t0:
+rows = cur.execute("select kernel_id, start, end from rocpd_kernel_dispatch order by start").fetchall()
+def short(n):
+    n = re.sub(r"^_ZN3zkp\d*", "", n)
+    n = re.sub(r"^\d*cfg_c\d+\d*", "", n)
+    m = re.search(r"([a-z_0-9]+_kernel)", n)
+    b = m.group(1).replace("_kernel", "") if m else n[:24]
+    return b + (":G2" if "Fp2" in n else "")
+end = max(r[2] for r in rows)
+a = end - win * 1e6
+nb = int(win / step + 0.999)
+buckets = [dict() for _ in range(nb)]
+for k, s, e in rows:
+    if e <= a:
         continue
-    name = re.sub(r"^_ZN3zkp\d*", "", syms.get(r[0], "?"))[:60]
-    dur = (r[2] - r[1]) / 1e3
-    if dur < min_us:
-        s = small.setdefault(name, [0, 0.0])
-        s[0] += 1
-        s[1] += dur
-        continue
-    print(f"{(r[1] - t0) / 1e3:9.1f} {(r[2] - t0) / 1e3:9.1f} {dur:8.1f} q{r[3] if qcol else '?'}  {name}")
-for n, (c, d) in sorted(small.items(), key=lambda x: -x[1][1]):
-    print(f"   short: {c:4d} x {n}  total {d:.1f} us")
+    s = max(s, a)
+    n = short(syms.get(k, str(k)))
+    b0, b1 = int((s - a) / (step * 1e6)), int((e - a - 1) / (step * 1e6))
+    for b in range(b0, min(b1, nb - 1) + 1):
+        lo, hi = a + b * step * 1e6, a + (b + 1) * step * 1e6
+        buckets[b][n] = buckets[b].get(n, 0.0) + (min(e, hi) - max(s, lo)) / 1e6
+for b, d in enumerate(buckets):
+    top = sorted(d.items(), key=lambda kv: -kv[1])[:4]
+    print(f"{b * step:6.1f} ms  sum {sum(d.values()):5.2f}  " + "  ".join(f"{n} {t:.2f}" for n, t in top))

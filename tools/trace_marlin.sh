@@ -9,5 +9,6 @@ rocprofv3 --kernel-trace -d $OUT/trace -o t -- python $ROOT/bench.py --workload 
 cd $ROOT
 DB=$(find $OUT/trace -name "*.db" | head -1)
 python tools/rocpd_gaps.py $DB ${WIN:-85} 100 > $OUT/gaps.txt 2>&1
+python tools/rocpd_timeline.py $DB ${WIN:-85} 1.0 > $OUT/timeline.txt 2>&1
 find $OUT -name "*.db" -delete
 cat $OUT/gaps.txt
