@@ -180,6 +180,91 @@ HostField fq_field(int curve) {
 }
 using FrE = HostField::E;
 
+// ---- host-side tail of a commitment: Jacobian (+ Jacobian) -> affine on the CPU (round 4).  The Jacobian MSM results are on the host
+// anyway; a device launch for "add the blinding MSM, invert Z" is ONE lane running a 254-step Fermat chain (0.25-0.3 ms per launch, alone
+// on the device, once per AHP round and twice per opening).  Here: a = 0 short Weierstrass formulas on HostField (ark's add_assign /
+// double_in_place semantics: identity operands, equal operands, opposite operands) and ONE inversion for all points of a round
+// (Montgomery's trick).  Coordinates are Fq Montgomery words, N per coordinate, exactly what the device kernels read / write.
+struct HostJac {
+  HostField::E x, y, z;
+};
+HostJac host_jac_load(const HostField& F, const uint64_t* p) {
+  HostJac j{};
+  memcpy(j.x.data(), p, 4 * F.N);
+  memcpy(j.y.data(), reinterpret_cast<const uint32_t*>(p) + F.N, 4 * F.N);
+  memcpy(j.z.data(), reinterpret_cast<const uint32_t*>(p) + 2 * F.N, 4 * F.N);
+  return j;
+}
+HostJac host_jac_dbl(const HostField& F, const HostJac& p) {          // dbl-2009-l
+  if (F.is_zero(p.z)) return p;
+  const auto A = F.mul(p.x, p.x), B = F.mul(p.y, p.y), C = F.mul(B, B);
+  auto t = F.add(p.x, B);
+  t = F.sub(F.sub(F.mul(t, t), A), C);
+  const auto D = F.add(t, t), E = F.add(F.add(A, A), A), Fq = F.mul(E, E);
+  HostJac r;
+  r.x = F.sub(Fq, F.add(D, D));
+  auto c8 = F.add(C, C);
+  c8 = F.add(c8, c8);
+  c8 = F.add(c8, c8);
+  r.y = F.sub(F.mul(E, F.sub(D, r.x)), c8);
+  const auto yz = F.mul(p.y, p.z);
+  r.z = F.add(yz, yz);
+  return r;
+}
+HostJac host_jac_add(const HostField& F, const HostJac& p, const HostJac& q) {   // add-2007-bl
+  if (F.is_zero(p.z)) return q;
+  if (F.is_zero(q.z)) return p;
+  const auto z1z1 = F.mul(p.z, p.z), z2z2 = F.mul(q.z, q.z);
+  const auto u1 = F.mul(p.x, z2z2), u2 = F.mul(q.x, z1z1);
+  const auto s1 = F.mul(F.mul(p.y, q.z), z2z2), s2 = F.mul(F.mul(q.y, p.z), z1z1);
+  if (u1 == u2) {
+    if (s1 == s2) return host_jac_dbl(F, p);
+    HostJac inf{};
+    inf.x = F.one_();
+    inf.y = F.one_();
+    return inf;
+  }
+  const auto h = F.sub(u2, u1);
+  auto i = F.add(h, h);
+  i = F.mul(i, i);
+  const auto j = F.mul(h, i);
+  auto rr = F.sub(s2, s1);
+  rr = F.add(rr, rr);
+  const auto v = F.mul(u1, i);
+  HostJac r;
+  r.x = F.sub(F.sub(F.mul(rr, rr), j), F.add(v, v));
+  auto s1j = F.mul(s1, j);
+  s1j = F.add(s1j, s1j);
+  r.y = F.sub(F.mul(rr, F.sub(v, r.x)), s1j);
+  auto zz = F.add(p.z, q.z);
+  zz = F.sub(F.sub(F.mul(zz, zz), z1z1), z2z2);
+  r.z = F.mul(zz, h);
+  return r;
+}
+// k points -> affine words (N per coordinate, zeros for the identity) + identity flags; one field inversion in total
+void host_into_affine(const HostField& F, const std::vector<HostJac>& pts, uint64_t* xy_out, size_t stride64, uint8_t* inf_out) {
+  const size_t k = pts.size();
+  std::vector<HostField::E> pref(k);
+  HostField::E acc = F.one_();
+  for (size_t i = 0; i < k; i++) {
+    pref[i] = acc;
+    if (!F.is_zero(pts[i].z)) acc = F.mul(acc, pts[i].z);
+  }
+  HostField::E inv = F.inverse(acc);
+  for (size_t i = k; i-- > 0;) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(xy_out + i * stride64);
+    memset(o, 0, 8 * F.N);
+    inf_out[i] = F.is_zero(pts[i].z) ? 1 : 0;
+    if (inf_out[i]) continue;
+    const auto zi = F.mul(inv, pref[i]);
+    inv = F.mul(inv, pts[i].z);
+    const auto zi2 = F.mul(zi, zi);
+    const auto ax = F.mul(pts[i].x, zi2), ay = F.mul(pts[i].y, F.mul(zi2, zi));
+    memcpy(o, ax.data(), 4 * F.N);
+    memcpy(o + F.N, ay.data(), 4 * F.N);
+  }
+}
+
 size_t next_pow2(size_t n) {
   size_t s = 1;
   while (s < n) s <<= 1;
@@ -814,7 +899,17 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
           has[k] = 1;
           memcpy(bj.data() + k * jw64, bjac.data() + bslot[k] * jw64, jw64 * 8);
         }
-      points_fold_into_affine(ctx, curve, 1, jac.data(), bj.data(), has.data(), slot.size(), axy.data(), ainf.data());
+      static const bool host_tail = !(getenv("ZKP_MARLIN_HOST_AFFINE") && atoi(getenv("ZKP_MARLIN_HOST_AFFINE")) == 0);
+      if (host_tail) {
+        std::vector<HostJac> pts(slot.size());
+        for (size_t k = 0; k < slot.size(); k++) {
+          pts[k] = host_jac_load(chal.Fq, jac.data() + k * jw64);
+          if (has[k]) pts[k] = host_jac_add(chal.Fq, pts[k], host_jac_load(chal.Fq, bj.data() + k * jw64));
+        }
+        host_into_affine(chal.Fq, pts, axy.data(), aw64, ainf.data());
+      } else {
+        points_fold_into_affine(ctx, curve, 1, jac.data(), bj.data(), has.data(), slot.size(), axy.data(), ainf.data());
+      }
       for (size_t k = 0; k < slot.size(); k++) {
         Commitment& c = comm[slot[k].first];
         std::vector<uint64_t>& dst = slot[k].second ? c.sxy : c.xy;
@@ -878,18 +973,32 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   DVec t3 = be.ifft(be.scale(acc, vab), ks);
   poly[G2_] = t3.view(1, ks);
   commit_early(G2_);                                   // g_2 and its shifted commitment run under the |B|-sized transforms below
-  DVec den[3];
   const FrE ab = F.mul(alpha, beta);
-  for (int m = 0; m < 3; m++)
-    den[m] = be.addc(be.axpy(be.axpy(ix->on_b[m][3], ix->on_b[m][0], F.neg(alpha)), ix->on_b[m][1], F.neg(beta)), ab);
-  DVec a_on_b = be.zeros(bs);
-  for (int m = 0; m < 3; m++)
-    be.axpy_into(a_on_b, be.mul(be.mul(ix->on_b[m][2], den[(m + 1) % 3]), den[(m + 2) % 3]), etas[m]);
-  DVec a_poly = be.ifft(be.scale(a_on_b, vab), bs);
-  DVec b_poly = be.ifft(be.mul(be.mul(den[0], den[1]), den[2]), bs);
-  {
+  if (4 * ks - 3 <= bs && ks >= 4) {
+    // (a - b t) over B in one fused pass + ONE inverse transform: b's evaluations over B are already the transform pmul would
+    // recompute (|B| >= deg(b t) + 1: no wrap-around), so the interpolations of a and b and the forward transform of b_poly drop out
+    // (five transforms of size |B| -> two); see marlin_h2_numerator (poly.hip)
+    DVec t_on_b = be.fft(t3, bs);
+    const uint64_t* onb[12];
+    for (int m = 0; m < 3; m++)
+      for (int q = 0; q < 4; q++) onb[4 * m + q] = ix->on_b[m][q].p;
+    uint64_t kh[6 * 4];
+    const FrE kk[6] = {alpha, beta, ab, F.mul(etas[0], vab), F.mul(etas[1], vab), F.mul(etas[2], vab)};
+    for (int q = 0; q < 6; q++) memcpy(kh + 4 * q, kk[q].data(), 32);
+    DVec num = be.alloc(bs);
+    marlin_h2_numerator(ctx, curve, onb, t_on_b.p, kh, num.p, bs);
+    DVec h2 = be.fold(be.ifft(num, bs).view(0, 4 * ks - 3), ks).first;
+    poly[H2_] = h2.view(0, 3 * ks - 3);
+  } else {
+    DVec den[3];
+    for (int m = 0; m < 3; m++)
+      den[m] = be.addc(be.axpy(be.axpy(ix->on_b[m][3], ix->on_b[m][0], F.neg(alpha)), ix->on_b[m][1], F.neg(beta)), ab);
+    DVec a_on_b = be.zeros(bs);
+    for (int m = 0; m < 3; m++)
+      be.axpy_into(a_on_b, be.mul(be.mul(ix->on_b[m][2], den[(m + 1) % 3]), den[(m + 2) % 3]), etas[m]);
+    DVec a_poly = be.ifft(be.scale(a_on_b, vab), bs);
+    DVec b_poly = be.ifft(be.mul(be.mul(den[0], den[1]), den[2]), bs);
     DVec h2 = be.fold(be.sub(a_poly.view(0, 3 * ks - 2), be.pmul(b_poly.view(0, 3 * ks - 2), t3)), ks).first;
-    poly[G2_] = t3.view(1, ks);
     poly[H2_] = h2.view(0, 3 * ks - 3);
   }
   lap(&tm.ms_round[2]);
@@ -1000,28 +1109,40 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
       }
     }
     out->num_opening_proofs = (uint32_t)npts;
+    // witness of the blinding polynomial rb0 + rb1 X at the point: quotient rb1 (degree 0), rand_v = rb(point) = rb0 + rb1 z — host
+    // arithmetic; the one-term MSMs rb1 * gamma_g[0] of both points run as ONE batched call, the sums and the affine conversions of
+    // both opening proofs on the host with one inversion (was: per point an upload, a division launch chain, an MSM, a fold launch and
+    // an into_affine launch, each with its own synchronisation)
+    std::vector<int> has_rand(npts, 0);
+    std::vector<FrE> rb1s;
     for (int k = 0; k < npts; k++) {
-      std::vector<uint64_t> pt(wjac.begin() + k * jw64, wjac.begin() + (k + 1) * jw64);
       out->opening_has_rand[k] = 0;
       memset(out->opening_rand_v + 4 * k, 0, 32);
       if (!F.is_zero(rbs[k][0]) || !F.is_zero(rbs[k][1])) {
-        // witness of the blinding polynomial rb0 + rb1 X at the point: quotient rb1 (degree 0), rand_v = rb(point)
-        DVec rbd = be.upload(std::vector<FrE>{rbs[k][0], rbs[k][1]});
-        DVec qb = be.alloc(1);
-        FrE ev{};
-        poly_div_linear(ctx, curve, rbd.p, 2, reinterpret_cast<const uint64_t*>(pts[k].data()), qb.p,
-                        reinterpret_cast<uint64_t*>(ev.data()));
-        std::vector<uint64_t> two(2 * jw64);
-        memcpy(two.data(), pt.data(), jw64 * 8);
-        msm_run(ctx, powers_gamma_g, 0, qb.p, 1, true, two.data() + jw64);
-        point_fold(ctx, curve, 1, two.data(), 2, pt.data());
+        has_rand[k] = 1;
+        const FrE ev = F.add(rbs[k][0], F.mul(rbs[k][1], pts[k]));
         out->opening_has_rand[k] = 1;
         memcpy(out->opening_rand_v + 4 * k, ev.data(), 32);
+        rb1s.push_back(rbs[k][1]);
       }
-      uint8_t inf = 0;
-      point_into_affine(ctx, curve, 1, pt.data(), out->opening_w + k * 12, &inf);
-      out->opening_w_inf[k] = inf;
     }
+    std::vector<uint64_t> bj(std::max<size_t>(rb1s.size(), 1) * jw64);
+    if (!rb1s.empty()) {
+      DVec qb = be.upload(rb1s);
+      std::vector<size_t> boffs(rb1s.size(), 0), bns(rb1s.size(), 1);
+      std::vector<const uint64_t*> bptrs;
+      for (size_t i2 = 0; i2 < rb1s.size(); i2++) bptrs.push_back(qb.p + 4 * i2);
+      msm_run_batch(ctx, powers_gamma_g, rb1s.size(), boffs.data(), bptrs.data(), bns.data(), true, bj.data());
+    }
+    std::vector<HostJac> hp(npts);
+    for (int k = 0, b = 0; k < npts; k++) {
+      hp[k] = host_jac_load(chal.Fq, wjac.data() + (size_t)k * jw64);
+      if (has_rand[k]) hp[k] = host_jac_add(chal.Fq, hp[k], host_jac_load(chal.Fq, bj.data() + (size_t)(b++) * jw64));
+    }
+    uint8_t oinf[2] = {0, 0};
+    memset(out->opening_w, 0, sizeof out->opening_w);
+    host_into_affine(chal.Fq, hp, out->opening_w, 12, oinf);
+    for (int k = 0; k < npts; k++) out->opening_w_inf[k] = oinf[k];
   }
   // ---- results
   for (int l = 0; l < NLAB; l++) {

@@ -244,7 +244,7 @@ static void poly_div_linear_t(zkp_ctx* ctx, const uint32_t* p, size_t n, const u
 void fr_vec_op(zkp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, const uint64_t* k_host,
                uint64_t* out, size_t n) {
   ZKP_REQUIRE(op >= 0 && op <= 5, ZKP_ERR_BAD_ARG);
-  uint32_t* kd = ctx->poly_consts.as<uint32_t>(64);
+  uint32_t* kd = ctx->poly_consts.as<uint32_t>(128);
   if (k_host) ZKP_HIP(hipMemcpyAsync(kd, k_host, 32, hipMemcpyHostToDevice, ctx->cur->stream));
   if (n == 0) return;
   auto launch = [&](auto tag) {
@@ -252,6 +252,50 @@ void fr_vec_op(zkp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_
     hipLaunchKernelGGL(vec_op_kernel<P>, dim3((n + 255) / 256), dim3(256), 0, ctx->cur->stream,
                        reinterpret_cast<const uint32_t*>(a), reinterpret_cast<const uint32_t*>(b), kd,
                        reinterpret_cast<uint32_t*>(out), n, op);
+  };
+  if (curve == ZKP_BN254) launch(Bn254Fr{});
+  else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});
+  else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+  ZKP_HIP(hipGetLastError());
+}
+
+// Marlin, third round (ahp/prover.rs:380-417), evaluations over the domain B in ONE pass (round 4; was 24 element-wise launches over
+// 2^23-element vectors):   den_m = row_col_m - alpha row_m - beta col_m + alpha beta,
+//     a = v_H(alpha) v_H(beta) sum_m eta_m val_m den_{m+1} den_{m+2},   b = den_0 den_1 den_2,   out = a - b * t
+// with t = the evaluations of t(X) over B: (a - b t)(X) has degree < |B|, so its interpolation IS a_poly - b_poly * t_poly.
+// k: 6 Fr (Montgomery) = alpha, beta, alpha*beta, eta_m * v_H(alpha) v_H(beta) for m = 0, 1, 2
+struct MarlinOnB {
+  const uint32_t* v[12];      // [m][row, col, val, row_col]
+};
+template <class P>
+__global__ __launch_bounds__(256) void marlin_h2_numerator_kernel(MarlinOnB in, const uint32_t* __restrict__ t, const uint32_t* __restrict__ k,
+                                                                  uint32_t* __restrict__ out, size_t n) {
+  using F = Fp<P>;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const F alpha = F::load(k), beta = F::load(k + 8), ab = F::load(k + 16);
+  F den[3];
+#pragma unroll
+  for (int m = 0; m < 3; m++)
+    den[m] = F::load(in.v[4 * m + 3] + i * 8) - alpha * F::load(in.v[4 * m] + i * 8) - beta * F::load(in.v[4 * m + 1] + i * 8) + ab;
+  const F p01 = den[0] * den[1], p12 = den[1] * den[2], p20 = den[2] * den[0];
+  F a = F::load(k + 24) * (F::load(in.v[2] + i * 8) * p12);
+  a = a + F::load(k + 32) * (F::load(in.v[6] + i * 8) * p20);
+  a = a + F::load(k + 40) * (F::load(in.v[10] + i * 8) * p01);
+  (a - (p01 * den[2]) * F::load(t + i * 8)).store(out + i * 8);
+}
+void marlin_h2_numerator(zkp_ctx* ctx, int curve, const uint64_t* const* on_b, const uint64_t* t, const uint64_t* k_host, uint64_t* out,
+                         size_t n) {
+  if (n == 0) return;
+  hipStream_t st = ctx->cur->stream;
+  uint32_t* kd = ctx->poly_consts.as<uint32_t>(128) + 64;
+  ZKP_HIP(hipMemcpyAsync(kd, k_host, 6 * 32, hipMemcpyHostToDevice, st));
+  MarlinOnB in;
+  for (int j = 0; j < 12; j++) in.v[j] = reinterpret_cast<const uint32_t*>(on_b[j]);
+  auto launch = [&](auto tag) {
+    using P = decltype(tag);
+    hipLaunchKernelGGL(marlin_h2_numerator_kernel<P>, dim3((n + 255) / 256), dim3(256), 0, st, in, reinterpret_cast<const uint32_t*>(t),
+                       (const uint32_t*)kd, reinterpret_cast<uint32_t*>(out), n);
   };
   if (curve == ZKP_BN254) launch(Bn254Fr{});
   else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});
@@ -461,6 +505,24 @@ void fr_gather(zkp_ctx* ctx, const uint64_t* in, const int32_t* idx, size_t n, u
 void poly_vanishing_fold(zkp_ctx* ctx, int curve, const uint64_t* p, size_t len, size_t n, uint64_t* q, uint64_t* rem) {
   ZKP_REQUIRE(n > 0, ZKP_ERR_BAD_ARG);
   hipStream_t st = ctx->cur->stream;
+  if (n == 1 && len > 4096 && q && rem) {
+    // X^1 - 1 (Marlin's division by v_X with one public input): a running sum over the WHOLE vector.  The strided-suffix-sum
+    // kernels below would give it 2 sqrt(len) lanes with sqrt(len) serial additions each (1.5 ms for 2^20 coefficients); it is the
+    // division by (X - 1): blocked-scan Horner with z = 1, quotient and p(1) = the remainder in one go.
+    auto go = [&](auto tag) {
+      using P = decltype(tag);
+      uint32_t* zd = ctx->poly_consts.as<uint32_t>(128) + 32;           // (words 0..23 belong to fr_vec_op / poly_div_linear)
+      uint32_t one[8];
+      for (int i = 0; i < 8; i++) one[i] = P::ONE[i];
+      ZKP_HIP(hipMemcpyAsync(zd, one, 32, hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
+      poly_div_linear_t<P>(ctx, reinterpret_cast<const uint32_t*>(p), len, zd, reinterpret_cast<uint32_t*>(q),
+                           reinterpret_cast<uint32_t*>(rem));
+    };
+    if (curve == ZKP_BN254) go(Bn254Fr{});
+    else if (curve == ZKP_BLS12_381) go(Bls381Fr{});
+    else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+    return;
+  }
   const size_t R = std::max<size_t>((len + n - 1) / n, 1);
   size_t C = R;
   if (R > 8) {
@@ -552,7 +614,7 @@ void poly_evaluate_batch(zkp_ctx* ctx, int curve, size_t count, const uint64_t* 
 // q (n-1 coeffs, may be nullptr) = p / (X - z) ; eval_out (host, may be nullptr) = p(z)
 void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const uint64_t* z_host, uint64_t* q,
                      uint64_t* eval_out_host) {
-  uint32_t* zd = ctx->poly_consts.as<uint32_t>(64);
+  uint32_t* zd = ctx->poly_consts.as<uint32_t>(128);
   ZKP_HIP(hipMemcpyAsync(zd, z_host, 32, hipMemcpyHostToDevice, ctx->cur->stream));
   uint32_t* ev = zd + 16;
   if (n == 0) {
