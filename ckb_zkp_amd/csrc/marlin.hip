@@ -748,18 +748,6 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     return e;
   };
 
-  // ---- prover_init (prover.rs:86-147): z = x ++ w ++ padding ones; z_a = A z, z_b = B z
-  DVec z = be.alloc(ix->n);
-  ZKP_HIP(hipMemcpyAsync(z.p, x_mont, ni * 32, hipMemcpyHostToDevice, st));
-  if (n_w) ZKP_HIP(hipMemcpyAsync(z.p + 4 * ni, w_mont, n_w * 32, hipMemcpyHostToDevice, st));
-  if (ix->pad_aux) {
-    DVec ones = be.zeros(ix->pad_aux);
-    DVec tgt = z.view(ni + n_w, ix->n);
-    const FrE o = F.one_();
-    be.op(ZKP_VEC_ADDC, ones, nullptr, tgt, ix->pad_aux, &o);
-  }
-  DVec z_a_ev = be.spmv(ix->csr[0].rp, ix->csr[0].col, ix->csr[0].cf, z, ix->n);
-  DVec z_b_ev = be.spmv(ix->csr[1].rp, ix->csr[1].col, ix->csr[1].cf, z, ix->n);
   // the mask polynomial is an input: prepared first so that its commitment (the largest MSM of the round) runs under the
   // interpolations below
   const size_t mask_len = 3 * hs + 2 * 1 - 2;
@@ -779,28 +767,41 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   // kernels that compute the rest of the round (which otherwise run alone: 12.6 + 4.9 ms per proof in a kernel trace);
   // commit_round collects the result instead of launching the MSM.  ZKP_MARLIN_EARLY=0: every MSM inside commit_round.
   static const bool early_on = !(getenv("ZKP_MARLIN_EARLY") && atoi(getenv("ZKP_MARLIN_EARLY")) == 0);
-  constexpr int EARLY_MAX = 8;
+  constexpr int EARLY_MAX = 16;
   if (!ix->early_pinned) ZKP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->early_pinned), EARLY_MAX * 24 * 8));
   struct Early {
     int label, ws;
     bool shifted;
-  };
+    int kind;               // 0: commitment MSM over powers_of_g; 1: blinding MSM over powers_of_gamma_g (label / shifted: whose);
+  };                        // 2: blinding term of opening proof `label`
   std::vector<Early> early;
   // -> index into `early` (-1: not started, the caller runs the MSM itself later).  offset: first SRS power (shifted commitments)
-  auto start_early = [&](int label, const DVec& v, size_t offset = 0, bool shifted = false) -> int {
+  auto start_early = [&](int label, const DVec& v, size_t offset = 0, bool shifted = false, int kind = 0) -> int {
     if (!early_on || (int)early.size() >= EARLY_MAX || v.n == 0) return -1;
     zkp_lane* L = ctx->cur;
     const int w = 1 + (int)(early.size() % (zkp_lane::N_WS - 1));
     hipStream_t ws_st = L->ws[w].stream;
+    const uint64_t handle = kind == 0 ? powers_g : powers_gamma_g;
     ZKP_HIP(hipEventRecord(L->ev_fork, st));                         // v is complete on the prover's stream
     ZKP_HIP(hipStreamWaitEvent(ws_st, L->ev_fork, 0));
-    ZKP_REQUIRE(offset <= bases_len(ctx, powers_g), ZKP_ERR_BAD_ARG);
-    const size_t n = std::min(v.n, bases_len(ctx, powers_g) - offset);   // ark min(len) truncation, as msm_run_multi
-    msm_run(ctx, powers_g, offset, v.p, n, true, nullptr, nullptr, nullptr, nullptr, w);
+    ZKP_REQUIRE(offset <= bases_len(ctx, handle), ZKP_ERR_BAD_ARG);
+    const size_t n = std::min(v.n, bases_len(ctx, handle) - offset);     // ark min(len) truncation, as msm_run_multi
+    msm_run(ctx, handle, offset, v.p, n, true, nullptr, nullptr, nullptr, nullptr, w);
     ZKP_HIP(hipMemcpyAsync(ix->early_pinned + early.size() * 24, L->ws[w].out.p, jw64 * 8, hipMemcpyDeviceToHost, ws_st));
     ZKP_HIP(hipEventRecord(L->ws[w].done, ws_st));
-    early.push_back({label, w, shifted});
+    early.push_back({label, w, shifted, kind});
     return (int)early.size() - 1;
+  };
+  auto find_early = [&](int l, bool shifted, int kind) {
+    for (size_t e = 0; e < early.size(); e++)
+      if (early[e].label == l && early[e].shifted == shifted && early[e].kind == kind) return (int)e;
+    return -1;
+  };
+  // result of early MSM e (Jacobian, jw64 words) once its workspace stream has reached it
+  auto collect_early = [&](int e, uint64_t* dst) {
+    ZKP_HIP(hipStreamWaitEvent(st, ctx->cur->ws[early[e].ws].done, 0));
+    ZKP_HIP(hipStreamSynchronize(st));
+    memcpy(dst, ix->early_pinned + (size_t)e * 24, jw64 * 8);
   };
   const size_t bound_of[NLAB] = {0, 0, 0, 0, 0, hs - 2, 0, ks - 2, 0};
   // a polynomial that is final: its commitment MSM (and the one against the shifted powers of a degree-bounded polynomial) starts now
@@ -810,6 +811,35 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   };
 
   commit_early(MASK_);
+  // the hiding blinders are inputs too: their two-term MSMs over powers_of_gamma_g (one full bucket pipeline each: ~1 ms of latency-
+  // bound launches, little work) start now and are collected by the round that needs them — they used to run as a second, blocking
+  // batch behind the commitment MSMs of every round
+  const bool hide[NLAB] = {true, true, true, false, false, true, false, false, false};
+  const uint64_t* blind_host[NLAB] = {rnd->blind_w, rnd->blind_z_a, rnd->blind_z_b, nullptr, nullptr, rnd->blind_g_1,
+                                      nullptr,      nullptr,        nullptr};
+  DVec blind_dev[NLAB], blind_s_dev;
+  for (int l = 0; l < NLAB; l++)
+    if (hide[l]) blind_dev[l] = be.upload(blind_host[l], 2);
+  blind_s_dev = be.upload(rnd->blind_shifted_g_1, 2);
+  for (int l = 0; l < NLAB; l++)
+    if (hide[l]) {
+      (void)start_early(l, blind_dev[l], 0, false, 1);
+      if (bounded[l]) (void)start_early(l, blind_s_dev, 0, true, 1);
+    }
+  // (round 4: the witness crosses PCIe from pageable host memory AFTER the mask MSM is under way — the copy blocks the host for
+  //  about a millisecond, during which the device used to idle)
+  // ---- prover_init (prover.rs:86-147): z = x ++ w ++ padding ones; z_a = A z, z_b = B z
+  DVec z = be.alloc(ix->n);
+  ZKP_HIP(hipMemcpyAsync(z.p, x_mont, ni * 32, hipMemcpyHostToDevice, st));
+  if (n_w) ZKP_HIP(hipMemcpyAsync(z.p + 4 * ni, w_mont, n_w * 32, hipMemcpyHostToDevice, st));
+  if (ix->pad_aux) {
+    DVec ones = be.zeros(ix->pad_aux);
+    DVec tgt = z.view(ni + n_w, ix->n);
+    const FrE o = F.one_();
+    be.op(ZKP_VEC_ADDC, ones, nullptr, tgt, ix->pad_aux, &o);
+  }
+  DVec z_a_ev = be.spmv(ix->csr[0].rp, ix->csr[0].col, ix->csr[0].cf, z, ix->n);
+  DVec z_b_ev = be.spmv(ix->csr[1].rp, ix->csr[1].col, ix->csr[1].cf, z, ix->n);
   // ---- first round (prover.rs:150-222)
   DVec x_poly = be.ifft(z.view(0, ni), xs);
   DVec x_on_h = be.fft(x_poly, hs);
@@ -829,14 +859,7 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   commit_early(ZA_);
   DVec z_b = masked(z_b_ev, fr_of(rnd->z_b));
   poly[ZB_] = z_b;
-  const bool hide[NLAB] = {true, true, true, false, false, true, false, false, false};
   const size_t bound[NLAB] = {0, 0, 0, 0, 0, hs - 2, 0, ks - 2, 0};
-  const uint64_t* blind_host[NLAB] = {rnd->blind_w, rnd->blind_z_a, rnd->blind_z_b, nullptr, nullptr, rnd->blind_g_1,
-                                      nullptr,      nullptr,        nullptr};
-  DVec blind_dev[NLAB], blind_s_dev;
-  for (int l = 0; l < NLAB; l++)
-    if (hide[l]) blind_dev[l] = be.upload(blind_host[l], 2);
-  blind_s_dev = be.upload(rnd->blind_shifted_g_1, 2);
   Commitment comm[NLAB];
 
   // PC::commit (pc/mod.rs:34-71) of one round: one batched MSM call per base vector
@@ -845,15 +868,10 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     std::vector<const uint64_t*> ptrs;
     std::vector<std::pair<int, bool>> slot;
     std::vector<std::pair<int, size_t>> early_slot;                 // (label, index into `early`) of the polynomials already under way
-    auto find_early = [&](int l, bool shifted) {
-      for (size_t e = 0; e < early.size(); e++)
-        if (early[e].label == l && early[e].shifted == shifted) return (int)e;
-      return -1;
-    };
     std::vector<bool> early_shifted;
     for (int l : labels) {
       for (int sh = 0; sh <= (bounded[l] ? 1 : 0); sh++) {
-        const int e = find_early(l, sh != 0);
+        const int e = find_early(l, sh != 0, 0);
         if (e >= 0) {
           tm.commit_points += poly[l].n;
           early_slot.push_back({l, (size_t)e});
@@ -880,8 +898,11 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     std::vector<size_t> boffs, bns;
     std::vector<const uint64_t*> bptrs;
     std::vector<size_t> bslot(slot.size(), (size_t)-1);
+    std::vector<int> bearly(slot.size(), -1);
     for (size_t k = 0; k < slot.size(); k++)
       if (hide[slot[k].first]) {
+        bearly[k] = find_early(slot[k].first, slot[k].second, 1);
+        if (bearly[k] >= 0) continue;
         bslot[k] = bptrs.size();
         boffs.push_back(0);
         bns.push_back(2);
@@ -898,6 +919,9 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
         if (bslot[k] != (size_t)-1) {
           has[k] = 1;
           memcpy(bj.data() + k * jw64, bjac.data() + bslot[k] * jw64, jw64 * 8);
+        } else if (bearly[k] >= 0) {
+          has[k] = 1;
+          collect_early(bearly[k], bj.data() + k * jw64);
         }
       static const bool host_tail = !(getenv("ZKP_MARLIN_HOST_AFFINE") && atoi(getenv("ZKP_MARLIN_HOST_AFFINE")) == 0);
       if (host_tail) {
@@ -1061,28 +1085,44 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   std::vector<DVec> wq(npts);
   std::vector<int> wq_early(npts, -1);
   std::vector<std::array<FrE, 2>> rbs(npts);
+  // the blinding polynomial rb0 + rb1 X of every opening is a combination of INPUTS (the hiding blinders) with powers of xi: known
+  // now.  Its witness at any point is the constant rb1, so the one-term MSMs rb1 * gamma_g[0] start here, under the combinations,
+  // divisions and witness MSMs below (they used to run as a blocking batch at the very end of the proof).
+  std::vector<int> rb_early(npts, -1);
+  std::vector<DVec> rb1_dev(npts);
+  for (int k = 0; k < npts; k++) {
+    std::array<FrE, 2> rb = {F.zero(), F.zero()};
+    FrE c = one;
+    for (const Q& q : query) {
+      if (order != 0 && q.at_beta != pt_is_beta[k]) continue;
+      const int l = q.l;
+      if (l >= 0 && hide[l])
+        for (int i = 0; i < 2; i++) rb[i] = F.add(rb[i], F.mul(c, fr_of(blind_host[l] + 4 * i)));
+      if (l >= 0 && bounded[l] && hide[l]) {
+        const FrE sc = F.mul(c, xi);
+        for (int i = 0; i < 2; i++) rb[i] = F.add(rb[i], F.mul(sc, fr_of(rnd->blind_shifted_g_1 + 4 * i)));
+      }
+      c = F.mul(c, xi2);
+    }
+    rbs[k] = rb;
+    if (!F.is_zero(rb[0]) || !F.is_zero(rb[1])) {
+      rb1_dev[k] = be.upload(std::vector<FrE>{rb[1]});
+      rb_early[k] = start_early(k, rb1_dev[k], 0, false, 2);
+    }
+  }
   for (int k = 0; k < npts; k++) {
     DVec p = be.zeros(D + 1);
-    std::array<FrE, 2> rb = {F.zero(), F.zero()};
     FrE c = one;
     for (const Q& q : query) {
       if (order != 0 && q.at_beta != pt_is_beta[k]) continue;
       be.axpy_into(p, q.p, c);
       const int l = q.l;
-      if (l >= 0 && hide[l])
-        for (int i = 0; i < 2; i++) rb[i] = F.add(rb[i], F.mul(c, fr_of(blind_host[l] + 4 * i)));
-      if (l >= 0 && bounded[l]) {
-        const FrE sc = F.mul(c, xi);
-        be.axpy_into(p, q.p, sc, D - bound[l]);
-        if (hide[l])
-          for (int i = 0; i < 2; i++) rb[i] = F.add(rb[i], F.mul(sc, fr_of(rnd->blind_shifted_g_1 + 4 * i)));
-      }
+      if (l >= 0 && bounded[l]) be.axpy_into(p, q.p, F.mul(c, xi), D - bound[l]);
       c = F.mul(c, xi2);
     }
     DVec qv = be.alloc(D);
     poly_div_linear(ctx, curve, p.p, D + 1, reinterpret_cast<const uint64_t*>(pts[k].data()), qv.p, nullptr);
     wq[k] = qv;
-    rbs[k] = rb;
     if (k + 1 < npts) wq_early[k] = start_early(-1, qv);            // under the next point's combination + division
   }
   {
@@ -1127,12 +1167,28 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
       }
     }
     std::vector<uint64_t> bj(std::max<size_t>(rb1s.size(), 1) * jw64);
-    if (!rb1s.empty()) {
-      DVec qb = be.upload(rb1s);
-      std::vector<size_t> boffs(rb1s.size(), 0), bns(rb1s.size(), 1);
+    {
+      std::vector<size_t> boffs, bns;
       std::vector<const uint64_t*> bptrs;
-      for (size_t i2 = 0; i2 < rb1s.size(); i2++) bptrs.push_back(qb.p + 4 * i2);
-      msm_run_batch(ctx, powers_gamma_g, rb1s.size(), boffs.data(), bptrs.data(), bns.data(), true, bj.data());
+      std::vector<size_t> dst;
+      for (int k = 0, b = 0; k < npts; k++) {
+        if (!has_rand[k]) continue;
+        if (rb_early[k] >= 0) {
+          collect_early(rb_early[k], bj.data() + (size_t)b * jw64);
+        } else {                                                       // early MSMs off / slots exhausted: blocking batch
+          if (!rb1_dev[k].p) rb1_dev[k] = be.upload(std::vector<FrE>{rbs[k][1]});
+          boffs.push_back(0);
+          bns.push_back(1);
+          bptrs.push_back(rb1_dev[k].p);
+          dst.push_back((size_t)b);
+        }
+        b++;
+      }
+      if (!bptrs.empty()) {
+        std::vector<uint64_t> tmp(bptrs.size() * jw64);
+        msm_run_batch(ctx, powers_gamma_g, bptrs.size(), boffs.data(), bptrs.data(), bns.data(), true, tmp.data());
+        for (size_t i2 = 0; i2 < dst.size(); i2++) memcpy(bj.data() + dst[i2] * jw64, tmp.data() + i2 * jw64, jw64 * 8);
+      }
     }
     std::vector<HostJac> hp(npts);
     for (int k = 0, b = 0; k < npts; k++) {
