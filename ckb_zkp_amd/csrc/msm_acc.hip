@@ -194,10 +194,12 @@ static uint32_t dbg_mask() {
 void ZKP_CFG_SYM(msm_accumulate_launch)(hipStream_t s, const char* table, const uint32_t* vals, const uint4* desc,
                                         const uint32_t* n_tasks_dev, uint32_t max_tasks, char* buckets, char* partial,
                                         uint32_t* redo, uint32_t init) {
-  // G2: 1 wave/SIMD (VGPRs + AGPRs as spill space, default) vs 2 waves/SIMD (256 VGPRs + 704 B scratch): the latter makes
-  // the kernel itself 7 % faster but the whole proof 8 % slower (it starves the concurrent streams) — ZKP_G2_ACC_OCC=1|2
+  // BLS12-381 G2: 1 wave/SIMD (VGPRs + AGPRs as spill space) vs 2 waves/SIMD (256 VGPRs + 168 B scratch since the round-3 streamed
+  // reductions freed registers; it was 704 B in round 2, when two waves made the proof 8 % slower).  Round 4, 2^22 proofs on one box:
+  // kernel 13.16 -> 12.29 ms, 0.717 -> 0.770 of the multiplier ceiling, 19.97 -> 20.15 proofs/s: two waves are the default
+  // (ZKP_G2_ACC_OCC=1 restores).  BN254 G2 compiles to 213 VGPRs / two waves either way.
   static const unsigned lds = [] { const char* e = getenv("ZKP_ACC_LDS_BYTES"); return e ? (unsigned)atoi(e) : 0u; }();
-  static const int occ = [] { const char* e = getenv("ZKP_G2_ACC_OCC"); return e ? atoi(e) : 1; }();
+  static const int occ = [] { const char* e = getenv("ZKP_G2_ACC_OCC"); return e ? atoi(e) : 2; }();
   static const int occ1 = [] { const char* e = getenv("ZKP_G1_ACC_OCC"); return e ? atoi(e) : 3; }();
   (void)hipMemsetAsync(redo, 0, sizeof(uint32_t), s);
   struct Redo {                                  // every launch path below is followed by the exact redo kernel
