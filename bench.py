@@ -257,9 +257,12 @@ def bench_marlin(ctx, curve="bn254", samples=87381, reps=3, verify=True, cpu=Fal
     # Since round 3 the commitments of the mask polynomial and t(X) start DURING their rounds (marlin.hip, early commitments), so
     # the commit phases alone no longer hold all the MSM time: the clock is rounds + commits (conservative: it also holds the NTTs).
     commit_s = (sum(tm["ms_commit"]) + sum(tm["ms_round"])) * 1e-3
+    mpmc, msrc = recorded("r04_pmc_marlin_accumulate.json")
     roofline = {"bound": "hbm", "kernel": "accumulate_kernel inside the commitment MSMs (PC::commit of the three AHP rounds)",
                 "achieved": round(commit_bytes / commit_s / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(commit_bytes / commit_s / 1e9 / 8000.0, 5), "traffic": None,
+                "frac": round(commit_bytes / commit_s / 1e9 / 8000.0, 5),
+                "traffic": mpmc["traffic_bytes_per_proof_commit_msms"] if mpmc else None,
+                "traffic_kind": "recorded" if mpmc else None, "traffic_source": msrc,
                 "algorithmic_bytes": int(commit_bytes), "ms": round(commit_s * 1e3, 3), "points": tm["commit_points"],
                 "ns_per_point": round(commit_s * 1e9 / max(tm["commit_points"], 1), 3),
                 "note": "integer-VALU bound like the Groth16 MSMs (DESIGN.md); time = the three AHP rounds + their commit phases "
@@ -356,10 +359,20 @@ def make_rand_fr(c, seed):
 
 def hbm_peak_block(ctx):
     """the on-box streaming-copy bandwidth next to the nominal 8 TB/s (zkp_bench_hbm_copy, 2 x 2 GiB buffers)."""
-    g = ctx.bench_hbm_copy(2 << 30)
+    g = max(ctx.bench_hbm_copy(1 << 30), ctx.bench_hbm_copy(2 << 30))
     return {"value": round(g, 1), "unit": "GB/s", "nominal": 8000.0, "frac_of_nominal": round(g / 8000.0, 4),
-            "note": "zkp_bench_hbm_copy: grid-stride dwordx4 copy kernel between two 2 GiB buffers (read + written bytes / HIP-event "
-                    "time, best of three grids), measured in this process; every roofline block quotes its fraction of BOTH peaks"}
+            "note": "zkp_bench_hbm_copy: grid-stride dwordx4 copy kernels (1 / 4 loads in flight, plain / non-temporal, 4-32 workgroups "
+                    "per CU) between two 1 GiB and two 2 GiB buffers, read + written bytes / HIP-event time, best variant, measured in "
+                    "this process; every roofline block quotes its fraction of BOTH peaks"}
+
+
+def recorded(name):
+    """a value recorded under profiles/ by a separate rocprofv3 --pmc pass (PMC counters cannot be read from inside the process)"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    try:
+        return json.load(open(path)), "profiles/" + name
+    except (OSError, ValueError):
+        return None, None
 
 
 def with_measured(block, hbm_meas):
@@ -456,6 +469,11 @@ def ntt_roofline(ctx, c, log_n, hbm_meas):
                         "frac_of_measured_peak": round(ach * passes / hbm_meas["value"], 4) if hbm_meas else None,
                         "note": "one pass reads and writes the vector once (64*N bytes)"},
            "valu": {"mulmods_per_element": round(mm, 2), "gmulmod_per_s": round(mm * N / (t_ntt * 1e-3) / 1e9, 1)}}
+    pmc, src = recorded("r04_pmc_ntt.json")
+    if pmc:
+        out["valu_busy_recorded"] = dict(pmc, source=src, kind="recorded",
+                                         note="SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES per SIMD of ntt_pass2_kernel (tools/pmc_ntt.sh): the share "
+                                              "of the kernel's cycles in which a SIMD's vector ALU is issuing — the binding roof of this kernel")
     return with_measured(out, hbm_meas)
 
 

@@ -24,6 +24,9 @@ void fr_gather(zkp_ctx* ctx, const uint64_t* in, const int32_t* idx, size_t n, u
 void poly_vanishing_fold(zkp_ctx* ctx, int curve, const uint64_t* p, size_t len, size_t n, uint64_t* q, uint64_t* rem);
 void poly_div_linear(zkp_ctx* ctx, int curve, const uint64_t* p, size_t n, const uint64_t* z_host, uint64_t* q,
                      uint64_t* eval_out_host);
+void marlin_round2_prod(zkp_ctx* ctx, int curve, const uint64_t* ra, const uint64_t* za, const uint64_t* zb, const uint64_t* t,
+                        const uint64_t* z, const uint64_t* k_host, uint64_t* out, size_t n);
+void marlin_t3_evals(zkp_ctx* ctx, int curve, const uint64_t* const* on_k, const uint64_t* k_host, uint64_t* out, size_t n);
 void marlin_h2_numerator(zkp_ctx* ctx, int curve, const uint64_t* const* on_b, const uint64_t* t, const uint64_t* k_host, uint64_t* out,
                          size_t n);
 void poly_evaluate_batch(zkp_ctx* ctx, int curve, size_t count, const uint64_t* const* p, const size_t* n, const uint64_t* z_host,

@@ -961,7 +961,6 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   const FrE ec = chal.rng ? chal.rand_fr() : chal.fixed_at(3);
   // ---- second round (prover.rs:230-321)
   const FrE one = F.one_();
-  DVec m_poly = be.axpy(be.axpy(be.scale(be.pmul(z_a, z_b), ec), z_a, ea), z_b, eb);
   const FrE v_alpha = F.sub(F.pow2k(alpha, log2_of(hs)), one);
   DVec r_alpha_on_h = be.scale(be.binv(be.addc(be.scale(ix->h_el, F.neg(one)), alpha)), v_alpha);
   DVec r_alpha = be.ifft(r_alpha_on_h, hs);
@@ -974,8 +973,18 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   commit_early(T_);                                                        // under the product FFTs below
   DVec z_poly = be.axpy(be.sub(be.shift(w_poly, xs), w_poly), x_poly, one);          // w * v_X + x
   {
-    const size_t size = next_pow2(std::max({mask.n, r_alpha.n + m_poly.n, t_poly.n + z_poly.n}));
-    DVec prod = be.sub(be.mul(be.fft(r_alpha, size), be.fft(m_poly, size)), be.mul(be.fft(t_poly, size), be.fft(z_poly, size)));
+    // m(X) = eta_c z_a z_b + eta_a z_a + eta_b z_b (z_a.n + z_b.n - 1 coefficients) is formed pointwise over the product domain
+    const size_t m_n = z_a.n + z_b.n - 1;
+    const size_t size = next_pow2(std::max({mask.n, r_alpha.n + m_n, t_poly.n + z_poly.n}));
+    DVec prod = be.alloc(size);
+    {
+      DVec RA = be.fft(r_alpha, size), ZA = be.fft(z_a, size), ZB = be.fft(z_b, size), TT = be.fft(t_poly, size), ZZ = be.fft(z_poly, size);
+      uint64_t kh[3 * 4];
+      memcpy(kh, ea.data(), 32);
+      memcpy(kh + 4, eb.data(), 32);
+      memcpy(kh + 8, ec.data(), 32);
+      marlin_round2_prod(ctx, curve, RA.p, ZA.p, ZB.p, TT.p, ZZ.p, kh, prod.p, size);
+    }
     DVec q1 = be.axpy(be.ifft(prod, size), mask, one);
     auto hx = be.fold(q1, hs);
     poly[T_] = t_poly;
@@ -989,12 +998,17 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   // ---- third round (prover.rs:331-427)
   const FrE v_beta = F.sub(F.pow2k(beta, log2_of(hs)), one);
   const FrE vab = F.mul(v_alpha, v_beta);
-  DVec acc = be.zeros(ks);
-  for (int m = 0; m < 3; m++) {
-    DVec inv = be.binv(be.mul(be.addc(be.scale(ix->on_k[m][0], F.neg(one)), beta), be.addc(be.scale(ix->on_k[m][1], F.neg(one)), alpha)));
-    be.axpy_into(acc, be.mul(ix->on_k[m][2], inv), etas[m]);
+  DVec acc = be.alloc(ks);                                // = v_H(alpha) v_H(beta) sum_m eta_m val_m / ((beta - row_m)(alpha - col_m)) over K
+  {
+    const uint64_t* onk[9];
+    for (int m = 0; m < 3; m++)
+      for (int q = 0; q < 3; q++) onk[3 * m + q] = ix->on_k[m][q].p;
+    uint64_t kh[5 * 4];
+    const FrE kk[5] = {alpha, beta, F.mul(etas[0], vab), F.mul(etas[1], vab), F.mul(etas[2], vab)};
+    for (int q = 0; q < 5; q++) memcpy(kh + 4 * q, kk[q].data(), 32);
+    marlin_t3_evals(ctx, curve, onk, kh, acc.p, ks);
   }
-  DVec t3 = be.ifft(be.scale(acc, vab), ks);
+  DVec t3 = be.ifft(acc, ks);
   poly[G2_] = t3.view(1, ks);
   commit_early(G2_);                                   // g_2 and its shifted commitment run under the |B|-sized transforms below
   const FrE ab = F.mul(alpha, beta);

@@ -259,6 +259,108 @@ void fr_vec_op(zkp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_
   ZKP_HIP(hipGetLastError());
 }
 
+// Marlin, second round (ahp/prover.rs:246-305) on the product domain D:   out = r_alpha * (eta_c z_a z_b + eta_a z_a + eta_b z_b) - t * z
+// from the evaluations over D of r_alpha, z_a, z_b, t, z (round 4: m(X) = eta_c z_a z_b + ... is formed pointwise instead of as
+// coefficients, which needed a product of its own: three transforms of size |D| / 2 and eight element-wise launches less).
+// k: 3 Fr (Montgomery) = eta_a, eta_b, eta_c
+template <class P>
+__global__ __launch_bounds__(256) void marlin_round2_prod_kernel(const uint32_t* __restrict__ ra, const uint32_t* __restrict__ za,
+                                                                 const uint32_t* __restrict__ zb, const uint32_t* __restrict__ t,
+                                                                 const uint32_t* __restrict__ z, const uint32_t* __restrict__ k,
+                                                                 uint32_t* __restrict__ out, size_t n) {
+  using F = Fp<P>;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const F a = F::load(za + i * 8), b = F::load(zb + i * 8);
+  const F m = F::load(k + 16) * (a * b) + F::load(k) * a + F::load(k + 8) * b;
+  (F::load(ra + i * 8) * m - F::load(t + i * 8) * F::load(z + i * 8)).store(out + i * 8);
+}
+void marlin_round2_prod(zkp_ctx* ctx, int curve, const uint64_t* ra, const uint64_t* za, const uint64_t* zb, const uint64_t* t,
+                        const uint64_t* z, const uint64_t* k_host, uint64_t* out, size_t n) {
+  if (n == 0) return;
+  hipStream_t st = ctx->cur->stream;
+  uint32_t* kd = ctx->poly_consts.as<uint32_t>(128) + 64;
+  ZKP_HIP(hipMemcpyAsync(kd, k_host, 3 * 32, hipMemcpyHostToDevice, st));
+  auto launch = [&](auto tag) {
+    using P = decltype(tag);
+    hipLaunchKernelGGL(marlin_round2_prod_kernel<P>, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ra),
+                       reinterpret_cast<const uint32_t*>(za), reinterpret_cast<const uint32_t*>(zb), reinterpret_cast<const uint32_t*>(t),
+                       reinterpret_cast<const uint32_t*>(z), (const uint32_t*)kd, reinterpret_cast<uint32_t*>(out), n);
+  };
+  if (curve == ZKP_BN254) launch(Bn254Fr{});
+  else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});
+  else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+  ZKP_HIP(hipGetLastError());
+}
+
+// Marlin, third round (ahp/prover.rs:340-377): the evaluations over K of   v_H(alpha) v_H(beta) sum_m eta_m val_m / ((beta - row_m)(alpha - col_m))
+// in ONE kernel (round 4; was three batch inversions + ~12 element-wise launches over |K|-element vectors).  Montgomery's trick per lane
+// over a strided chunk of the TRIPLE products d_0 d_1 d_2 (one Fermat inversion per 3 * POLY_CHUNK denominators instead of per
+// POLY_CHUNK); a zero denominator contributes a zero term, exactly as ark's batch_inversion leaves zeros in place.
+// k: 5 Fr (Montgomery) = alpha, beta, eta_m * v_H(alpha) v_H(beta) for m = 0, 1, 2
+struct MarlinOnK {
+  const uint32_t* v[9];       // [m][row, col, val]
+};
+template <class P>
+__global__ __launch_bounds__(256) void marlin_t3_evals_kernel(MarlinOnK in, const uint32_t* __restrict__ k, uint32_t* __restrict__ out,
+                                                              size_t n, size_t lanes) {
+  using F = Fp<P>;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lanes) return;
+  const F alpha = F::load(k), beta = F::load(k + 8);
+  auto dens = [&](size_t i, F* e, bool* z) {
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      const F d = (beta - F::load(in.v[3 * m] + i * 8)) * (alpha - F::load(in.v[3 * m + 1] + i * 8));
+      z[m] = d.is_zero();
+      e[m] = z[m] ? F::one() : d;
+    }
+  };
+  F pref[POLY_CHUNK];
+  F acc = F::one();
+  int cnt = 0;
+  for (size_t i = t; i < n && cnt < POLY_CHUNK; i += lanes, cnt++) {
+    F e[3];
+    bool z[3];
+    dens(i, e, z);
+    pref[cnt] = acc;
+    acc = acc * (e[0] * e[1] * e[2]);
+  }
+  F inv = acc.inv();
+  for (int c = cnt - 1; c >= 0; c--) {
+    const size_t i = t + (size_t)c * lanes;
+    F e[3];
+    bool z[3];
+    dens(i, e, z);
+    const F p12 = e[1] * e[2], p02 = e[0] * e[2], p01 = e[0] * e[1];
+    const F di = inv * pref[c];                                        // 1 / (e0 e1 e2)
+    inv = inv * (e[0] * p12);
+    F r = F::zero();
+    if (!z[0]) r = r + F::load(k + 16) * (F::load(in.v[2] + i * 8) * (di * p12));
+    if (!z[1]) r = r + F::load(k + 24) * (F::load(in.v[5] + i * 8) * (di * p02));
+    if (!z[2]) r = r + F::load(k + 32) * (F::load(in.v[8] + i * 8) * (di * p01));
+    r.store(out + i * 8);
+  }
+}
+void marlin_t3_evals(zkp_ctx* ctx, int curve, const uint64_t* const* on_k, const uint64_t* k_host, uint64_t* out, size_t n) {
+  if (n == 0) return;
+  hipStream_t st = ctx->cur->stream;
+  uint32_t* kd = ctx->poly_consts.as<uint32_t>(128) + 64;
+  ZKP_HIP(hipMemcpyAsync(kd, k_host, 5 * 32, hipMemcpyHostToDevice, st));
+  MarlinOnK in;
+  for (int j = 0; j < 9; j++) in.v[j] = reinterpret_cast<const uint32_t*>(on_k[j]);
+  const size_t lanes = (n + POLY_CHUNK - 1) / POLY_CHUNK;
+  auto launch = [&](auto tag) {
+    using P = decltype(tag);
+    hipLaunchKernelGGL(marlin_t3_evals_kernel<P>, dim3((lanes + 255) / 256), dim3(256), 0, st, in, (const uint32_t*)kd,
+                       reinterpret_cast<uint32_t*>(out), n, lanes);
+  };
+  if (curve == ZKP_BN254) launch(Bn254Fr{});
+  else if (curve == ZKP_BLS12_381) launch(Bls381Fr{});
+  else throw StatusError{ZKP_ERR_UNSUPPORTED_CURVE};
+  ZKP_HIP(hipGetLastError());
+}
+
 // Marlin, third round (ahp/prover.rs:380-417), evaluations over the domain B in ONE pass (round 4; was 24 element-wise launches over
 // 2^23-element vectors):   den_m = row_col_m - alpha row_m - beta col_m + alpha beta,
 //     a = v_H(alpha) v_H(beta) sum_m eta_m val_m den_{m+1} den_{m+2},   b = den_0 den_1 den_2,   out = a - b * t
