@@ -8,9 +8,9 @@ OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $ROOT/bench.py --no-cpu-baseline --no-marlin > $OUT/stats_bench.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $ROOT/bench.py --no-cpu-baseline --no-marlin --no-extra-configs > $OUT/stats_bench.json 2> $OUT/stats.err
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o pmc -- python $ROOT/bench.py --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline --no-marlin > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o pmc -- python $ROOT/bench.py --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline --no-marlin --no-extra-configs > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
 cd $ROOT
 DB=$(find $OUT/stats -name "*.db" | head -1)
