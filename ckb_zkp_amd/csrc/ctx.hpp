@@ -118,7 +118,8 @@ struct zkp_lane {
   zkp::DevBuf ntt_scratch;
   hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b1 = nullptr;
   // pinned host landing zone of the async proof read-back
-  uint32_t* host_proof = nullptr;                               // 256 words proof + 4 words flags
+  uint32_t* host_proof = nullptr;                               // 256 words proof + 4 words flags; host tail: A | B | C as XYZZ
+  bool host_tail = false;                                       // how the pending proof's points came back (prove_finish)
   bool busy = false;
 };
 

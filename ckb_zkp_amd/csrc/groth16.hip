@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "field_dev.hpp"
+#include "host_field.hpp"
 #include "internal.hpp"
 #include "msm_vtbl.hpp"
 
@@ -464,6 +465,9 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   zkp_groth16_pk::PerLane& PL = pk->lane[ctx->cur_idx];
   hipStream_t st = ctx->cur->stream;
   const bool prof = ctx->profiling;
+  // ZKP_HOST_AFFINE=0: into_affine of the proof points on the device (rounds 1-3) instead of the host
+  static const bool host_tail_on = !(getenv("ZKP_HOST_AFFINE") && atoi(getenv("ZKP_HOST_AFFINE")) == 0);
+  const bool host_tail = host_tail_on && !partial_out;
   zkp_groth16_timing tm{};
   struct ProfEvents {                                   // destroyed on every exit path (msm_run may throw)
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -558,7 +562,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
       if (b_l1) run(2, pk->hB2, Sd + 4 * pk->q_lo[2], pk->q_n[2], 2, -1, l1);
       // proof.b needs B2 only: its into_affine runs on B2's stream as soon as the MSM is done instead of in the tail of the proof
       static const bool g2_early = !(getenv("ZKP_G2_EARLY") && atoi(getenv("ZKP_G2_EARLY")) == 0);
-      if (!partial_out && g2_early) {
+      if (!partial_out && g2_early && !host_tail) {
         v2->assemble_g2(ctx->cur->ws[2].stream, res, slot, proof_dev, flags_dev, 2 * v1->fN);
         g2_done_in_fan = true;
       }
@@ -567,7 +571,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
       run(4, pk->hL, Sd + 4 * pk->q_lo[4], pk->q_n[4], 1, pk->share_al_sort ? 1 : -1, l1);   // A's sort / level-1 pass, still in this workspace
       if (!partial_out) {
         ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_a, 0));
-        v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, proof_dev, flags_dev);
+        v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, host_tail ? nullptr : proof_dev, flags_dev);
       }
     } else {
     // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H | ws3: L, then part 1 after A, B1
@@ -582,7 +586,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     // A and B1 exist so they hide under the remaining MSMs
     if (!partial_out) {
       ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_b1, 0));
-      v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, proof_dev, flags_dev);
+      v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, host_tail ? nullptr : proof_dev, flags_dev);
     }
     }
     l_done_in_fan = lat || l_own;
@@ -623,14 +627,24 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
 
   tic();
   // proof layout (32-bit words): A = 2*fN1 | B = 2*fN2 | C = 2*fN1
-  if (!fan) v1->assemble_g1_part1(st, res, slot, rs, proof_dev, flags_dev);
-  v1->assemble_g1_part2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN + 2 * v2->fN);
-  if (!g2_done_in_fan) v2->assemble_g2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN);
+  if (!fan) v1->assemble_g1_part1(st, res, slot, rs, host_tail ? nullptr : proof_dev, flags_dev);
+  v1->assemble_g1_part2(st, res, slot, host_tail ? nullptr : proof_dev, flags_dev, 2 * v1->fN + 2 * v2->fN);
+  if (!g2_done_in_fan && !host_tail) v2->assemble_g2(st, res, slot, proof_dev, flags_dev, 2 * v1->fN);
   ZKP_HIP(hipGetLastError());
   toc(&tm.ms_assemble);
   const size_t proof_words = 4 * (size_t)v1->fN + 2 * (size_t)v2->fN;
-  ZKP_HIP(hipMemcpyAsync(ctx->cur->host_proof, proof_dev, proof_words * 4, hipMemcpyDeviceToHost, st));
-  ZKP_HIP(hipMemcpyAsync(ctx->cur->host_proof + 256, flags_dev, 12, hipMemcpyDeviceToHost, st));
+  if (host_tail) {
+    // the three proof points go back as XYZZ (A = slot 0, B = slot 2, C = slot 5); prove_finish makes them affine on the host
+    // with one inversion (host_field.hpp) — three single-lane Fermat chains (0.25-0.32 ms each) leave the tail of the proof
+    uint32_t* hp = ctx->cur->host_proof;
+    ZKP_HIP(hipMemcpyAsync(hp, res, 16 * (size_t)v1->fN, hipMemcpyDeviceToHost, st));
+    ZKP_HIP(hipMemcpyAsync(hp + 4 * v1->fN, res + 2 * slot, 16 * (size_t)v2->fN, hipMemcpyDeviceToHost, st));
+    ZKP_HIP(hipMemcpyAsync(hp + 4 * v1->fN + 4 * v2->fN, res + 5 * slot, 16 * (size_t)v1->fN, hipMemcpyDeviceToHost, st));
+  } else {
+    ZKP_HIP(hipMemcpyAsync(ctx->cur->host_proof, proof_dev, proof_words * 4, hipMemcpyDeviceToHost, st));
+    ZKP_HIP(hipMemcpyAsync(ctx->cur->host_proof + 256, flags_dev, 12, hipMemcpyDeviceToHost, st));
+  }
+  ctx->cur->host_tail = host_tail;
   ctx->cur->busy = true;
   if (prof) {
     ZKP_HIP(hipEventRecord(eT1, st));
@@ -712,8 +726,15 @@ static void prove_finish(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t* proof_out, 
   const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
   const size_t proof_words = 4 * (size_t)v1->fN + 2 * (size_t)v2->fN;
   ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
-  memcpy(proof_out, ctx->cur->host_proof, proof_words * 4);
-  for (int i = 0; i < 3; i++) inf_out[i] = (uint8_t)ctx->cur->host_proof[256 + i];
+  if (ctx->cur->host_tail) {
+    const hostf::HostField Fq = hostf::fq_field(pk->curve);
+    const uint32_t* hp = ctx->cur->host_proof;
+    hostf::groth16_points_into_affine(Fq, hp, hp + 4 * v1->fN, hp + 4 * v1->fN + 4 * v2->fN,
+                                      reinterpret_cast<uint32_t*>(proof_out), inf_out);
+  } else {
+    memcpy(proof_out, ctx->cur->host_proof, proof_words * 4);
+    for (int i = 0; i < 3; i++) inf_out[i] = (uint8_t)ctx->cur->host_proof[256 + i];
+  }
   ctx->cur->busy = false;
 }
 

@@ -716,12 +716,21 @@ __global__ __launch_bounds__(128) void assemble_g1_part1_kernel(char* __restrict
   glv_decompose<G>(k.v, k1, &neg1, k2, &neg2);                 // k P = k1 P + k2 phi(P)
   if (lane == 0) {
     XYZZ<F> p = XYZZ<F>::load(res + (size_t)chain * slot);
-    Affine<F> a = p.to_affine();
-    if (chain == 0) {
-      a.store(out);                                            // proof.a
-      flags[0] = p.is_inf() ? 1 : 0;
+    F X, Y, Z;
+    if (out) {
+      Affine<F> a = p.to_affine();
+      if (chain == 0) {
+        a.store(out);                                          // proof.a
+        flags[0] = p.is_inf() ? 1 : 0;
+      }
+      X = a.x, Y = a.y, Z = p.is_inf() ? F::zero() : F::one();
+    } else {
+      // host tail (round 4): proof.a becomes affine on the host from the XYZZ slot; the doubling chain starts from the Jacobian
+      // form (X ZZ^2 : Y ZZZ^2 : ZZZ) of the same point — four products instead of a 254-step Fermat inversion in front of it
+      X = p.x * p.zz.sqr();
+      Y = p.y * p.zzz.sqr();
+      Z = p.is_inf() ? F::zero() : p.zzz;
     }
-    F X = a.x, Y = a.y, Z = p.is_inf() ? F::zero() : F::one();
     for (int b = 0; b < NB; b++) {
       X.store(D + (size_t)b * JB);
       Y.store(D + (size_t)b * JB + 4 * F::N);
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(128) void assemble_g1_part1_kernel(char* __restrict
   }
 }
 // part 2 — C = T + h_acc + l'  (l' includes -rs*delta)
-__global__ __launch_bounds__(64) void assemble_g1_part2_kernel(const char* __restrict__ res, size_t slot,
+__global__ __launch_bounds__(64) void assemble_g1_part2_kernel(char* __restrict__ res, size_t slot,
                                                                uint32_t* __restrict__ out,
                                                                uint32_t* __restrict__ flags, int c_off_words) {
   using F = CfgF;
@@ -770,6 +779,10 @@ __global__ __launch_bounds__(64) void assemble_g1_part2_kernel(const char* __res
   XYZZ<F> acc = XYZZ<F>::load(res + 5 * slot);
   acc.add(XYZZ<F>::load(res + 3 * slot));
   acc.add(XYZZ<F>::load(res + 4 * slot));
+  if (!out) {                                                  // host tail: C leaves as XYZZ (slot 5), the host inverts
+    acc.store(res + 5 * slot);
+    return;
+  }
   Affine<F> c = acc.to_affine();
   c.store(out + c_off_words);
   flags[2] = acc.is_inf() ? 1 : 0;
@@ -864,7 +877,7 @@ void l_assemble_g1_p1(hipStream_t s, char* res, size_t slot, const uint32_t* rs,
   const size_t lds = 2 * (size_t)GlvConst<CfgFq>::BITS * 3 * 4 * F::N + 2 * 64 * XB;
   hipLaunchKernelGGL(assemble_g1_part1_kernel, dim3(1), dim3(128), lds, s, res, slot, rs, out, flags);
 }
-void l_assemble_g1_p2(hipStream_t s, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int c_off_words) {
+void l_assemble_g1_p2(hipStream_t s, char* res, size_t slot, uint32_t* out, uint32_t* flags, int c_off_words) {
   hipLaunchKernelGGL(assemble_g1_part2_kernel, dim3(1), dim3(64), 0, s, res, slot, out, flags, c_off_words);
 }
 #else

@@ -77,7 +77,7 @@ struct MsmVtbl {
   // part 1 needs only g_a (slot 0) and g1_b (slot 1): proof.a = affine(g_a); T = s*g_a + r*g1_b -> slot 5.
   // part 2: C = T + h_acc (slot 3) + l' (slot 4) -> affine.  Split so part 1 overlaps the remaining MSMs.
   void (*assemble_g1_part1)(hipStream_t, char* res, size_t slot, const uint32_t* rs, uint32_t* out, uint32_t* flags);
-  void (*assemble_g1_part2)(hipStream_t, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int c_off_words);
+  void (*assemble_g1_part2)(hipStream_t, char* res, size_t slot, uint32_t* out, uint32_t* flags, int c_off_words);
   void (*assemble_g2)(hipStream_t, const char* res, size_t slot, uint32_t* out, uint32_t* flags, int out_off_words);
   // the top of the pairwise pyramid in one launch: levels from the one with `count` (<= PAIR_TOP_MAX; 1024: 129.4, 2048: 130.1, 4096: 129.5 proofs/s) entries at `base` down to
   // the root, each level stored directly behind its predecessor
