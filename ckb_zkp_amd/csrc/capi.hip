@@ -83,25 +83,11 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
     ZKP_HIP(hipEventCreate(&ctx->ev1));
     ZKP_HIP(hipEventCreate(&ctx->ev2));
     ZKP_HIP(hipEventCreate(&ctx->ev3));
-    // ZKP_STREAM_PRIO="m,w1,w2,w3": HIP stream priority per role (main = witness map -> H, ws1 = A -> L, ws2 = B2 (G2), ws3 = B1 ->
-    // s*g_a + r*g1_b); -1 = high, 0 = normal, 1 = low, clamped to the device's range.  Default: see prio_default below.
-    int prio[zkp_lane::N_WS] = {0, 0, 0, 0};
-    {
-      int lo = 0, hi = 0;                                  // numerically: hi <= lo (greatest priority = smallest number)
-      ZKP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      const char* e = getenv("ZKP_STREAM_PRIO");
-      const char* prio_default = "0,0,0,0";
-      const char* p = e ? e : prio_default;
-      for (int i = 0; i < zkp_lane::N_WS && *p; i++) {
-        prio[i] = (int)strtol(p, const_cast<char**>(&p), 10);
-        if (*p == ',') p++;
-        if (prio[i] < hi) prio[i] = hi;
-        if (prio[i] > lo) prio[i] = lo;
-      }
-    }
+    // (HIP stream priorities per role — high for the G2 chain and the B1 -> s*g_a + r*g1_b chain, whose reduction tails end a single
+    //  proof — were measured in round 4 and lose everywhere: 8.2 -> 8.7-14 ms per single proof, 143 -> 90-133 pipelined proofs/s.)
     for (int l = 0; l < zkp_ctx::N_LANES; l++) {
       zkp_lane& L = ctx->lanes[l];
-      ZKP_HIP(hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, prio[0]));
+      ZKP_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
       ZKP_HIP(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
       ZKP_HIP(hipEventCreateWithFlags(&L.ev_a, hipEventDisableTiming));
       ZKP_HIP(hipEventCreateWithFlags(&L.ev_b1, hipEventDisableTiming));
@@ -112,7 +98,7 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
         ZKP_HIP(hipEventCreateWithFlags(&L.ws[i].l1_done, hipEventDisableTiming));
         ZKP_HIP(hipEventCreateWithFlags(&L.ws[i].acc_done, hipEventDisableTiming));
         if (i > 0) {
-          ZKP_HIP(hipStreamCreateWithPriority(&L.ws[i].stream, hipStreamNonBlocking, prio[i]));
+          ZKP_HIP(hipStreamCreateWithFlags(&L.ws[i].stream, hipStreamNonBlocking));
           L.ws[i].own_stream = true;
         }
       }

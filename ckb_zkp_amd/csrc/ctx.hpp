@@ -113,7 +113,8 @@ struct Groth16Timing {
 struct zkp_lane {
   hipStream_t stream = nullptr;
   bool own_stream = true;
-  static constexpr int N_WS = 4;                                // ws[3]: assembly stream (no scratch)
+  static constexpr int N_WS = 4;                                // main stream + three MSM workspace streams
+  static constexpr int N_WS_MSM = N_WS;                         // workspaces the batched MSM entry points / Marlin rotate over
   zkp::MsmWorkspace ws[N_WS];                                   // ws[0].stream aliases `stream`
   zkp::DevBuf ntt_scratch;
   hipEvent_t ev_fork = nullptr, ev_a = nullptr, ev_b1 = nullptr;
@@ -158,4 +159,16 @@ struct zkp_ctx {
   std::vector<zkp_ctx*> devs;
   // variable-base reduction plans (msm.hip var_plan), owned by the context and released with it
   std::map<std::pair<int, int>, std::shared_ptr<void>> var_plans;
+  // ZKP_TIMELINE=1 (diagnostics): events recorded on the streams of ONE blocking proof at phase boundaries, printed to stderr by
+  // prove_finish as offsets from the first — where the chains of a proof end when no tracer slows the host's launches
+  bool tl_on = false;
+  std::string tl_tag;
+  std::vector<std::pair<std::string, hipEvent_t>> tl;
+  void mark(hipStream_t st, const char* what) {
+    if (!tl_on) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    tl.emplace_back(tl_tag + what, e);
+  }
 };

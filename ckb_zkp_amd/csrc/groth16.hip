@@ -516,6 +516,8 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   auto run = [&](int idx, uint64_t handle, const uint64_t* sc, size_t n, int w, int sort_src = -1, int l1_src = -1) {
     float ms = 0.f, ms_sc = 0.f;
     uint64_t e = 0;
+    static const char* const names[5] = {"A", "B1", "B2", "H", "L"};
+    ctx->tl_tag = names[idx];
     tic();
 #ifdef ZKP_ABLATION   // timing ablation builds only (ZKP_BUILD_DEFS=-DZKP_ABLATION -> variants/<tag>/): WRONG proofs, never in the shipped library
     static const int skip_k8 = [] { const char* e = getenv("ZKP_DEBUG_SKIP_K8_MASK"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
@@ -536,6 +538,8 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     }
     tm.msm_accumulate_launches += 1;
   };
+  ctx->tl_tag.clear();
+  ctx->mark(st, "start");
   if (fan) {
     ZKP_HIP(hipEventRecord(ctx->cur->ev_fork, st));                       // S is complete
     for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[w].stream, ctx->cur->ev_fork, 0));
@@ -544,7 +548,14 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     // them, as in round 1).  Making the other MSMs' accumulate kernels wait for it — a kernel timeline shows machine-filling
     // accumulates from three streams leaving its kernels few wave slots for milliseconds — was measured too: 10.3 ms, not kept.
     static const bool wm_first = !(getenv("ZKP_WM_FIRST") && atoi(getenv("ZKP_WM_FIRST")) == 0);
-    if (wm_first) h = witness_map_dev<FrP>(ctx, pk, S);
+    if (wm_first) {
+      h = witness_map_dev<FrP>(ctx, pk, S);
+      ctx->mark(st, "wm");
+    }
+    // (Round 4, measured with ZKP_TIMELINE=1 and removed again: holding the accumulate kernels of A / B1 / B2 / L until the witness map
+    //  is done — the map ends at 5.4 ms of an 8.2 ms proof when they start at 0.9 ms — and giving L a workspace of its own so that its
+    //  accumulate need not wait for A's reduction chain: 8.6-8.8 / 8.6-8.9 / 9.3-9.6 ms (gate / workspace / both) against 8.0-8.4.  The
+    //  machine-filling accumulates only change places; what ends last is still one accumulate + its reduction.  profiles/r04_latency_*.)
     static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
     static const int lat_env = [] { const char* e = getenv("ZKP_LATENCY_PLAN"); return e ? atoi(e) : -1; }();
     (void)latency_plan;
@@ -572,6 +583,8 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
       if (!partial_out) {
         ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[3].stream, ctx->cur->ev_a, 0));
         v1->assemble_g1_part1(ctx->cur->ws[3].stream, res, slot, rs, host_tail ? nullptr : proof_dev, flags_dev);
+        ctx->tl_tag.clear();
+        ctx->mark(ctx->cur->ws[3].stream, "part1");
       }
     } else {
     // stream plan (longest chain first): ws2: B2 | ws1: A -> B1 | main: witness_map -> H | ws3: L, then part 1 after A, B1
@@ -644,6 +657,8 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     ZKP_HIP(hipMemcpyAsync(ctx->cur->host_proof, proof_dev, proof_words * 4, hipMemcpyDeviceToHost, st));
     ZKP_HIP(hipMemcpyAsync(ctx->cur->host_proof + 256, flags_dev, 12, hipMemcpyDeviceToHost, st));
   }
+  ctx->tl_tag.clear();
+  ctx->mark(st, "copied");
   ctx->cur->host_tail = host_tail;
   ctx->cur->busy = true;
   if (prof) {
@@ -726,6 +741,21 @@ static void prove_finish(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t* proof_out, 
   const MsmVtbl* v2 = msm_vtbl(pk->curve, 2);
   const size_t proof_words = 4 * (size_t)v1->fN + 2 * (size_t)v2->fN;
   ZKP_HIP(hipStreamSynchronize(ctx->cur->stream));
+  if (!ctx->tl.empty()) {
+    std::string line = "[zkp timeline ms]";
+    for (auto& m : ctx->tl) {
+      float ms = 0.f;
+      (void)hipEventSynchronize(m.second);
+      (void)hipEventElapsedTime(&ms, ctx->tl[0].second, m.second);
+      char buf[64];
+      snprintf(buf, sizeof buf, " %s=%.2f", m.first.c_str(), ms);
+      line += buf;
+      if (&m != &ctx->tl[0]) (void)hipEventDestroy(m.second);
+    }
+    (void)hipEventDestroy(ctx->tl[0].second);
+    ctx->tl.clear();
+    fprintf(stderr, "%s\n", line.c_str());
+  }
   if (ctx->cur->host_tail) {
     const hostf::HostField Fq = hostf::fq_field(pk->curve);
     const uint32_t* hp = ctx->cur->host_proof;
@@ -818,8 +848,11 @@ void groth16_prove(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z, bool z_o
   ZKP_REQUIRE(pk->shard_world == 0, ZKP_ERR_BAD_ARG);     // a sharded key yields partial sums only
   ctx->cur = &ctx->lanes[0];
   ctx->cur_idx = 0;
+  static const bool timeline = getenv("ZKP_TIMELINE") && atoi(getenv("ZKP_TIMELINE")) != 0;
+  ctx->tl_on = timeline && !ctx->profiling;
   if (pk->curve == ZKP_BN254) prove_enqueue<Bn254Fr>(ctx, pk, z, z_on_device, r, s, true);
   else prove_enqueue<Bls381Fr>(ctx, pk, z, z_on_device, r, s, true);
+  ctx->tl_on = false;
   prove_finish(ctx, pk, proof_out, inf_out);
 }
 

@@ -554,7 +554,7 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   auto start_early = [&](int label, const DVec& v, size_t offset = 0, bool shifted = false, int kind = 0) -> int {
     if (!early_on || (int)early.size() >= EARLY_MAX || v.n == 0) return -1;
     zkp_lane* L = ctx->cur;
-    const int w = 1 + (int)(early.size() % (zkp_lane::N_WS - 1));
+    const int w = 1 + (int)(early.size() % (zkp_lane::N_WS_MSM - 1));
     hipStream_t ws_st = L->ws[w].stream;
     const uint64_t handle = kind == 0 ? powers_g : powers_gamma_g;
     ZKP_HIP(hipEventRecord(L->ev_fork, st));                         // v is complete on the prover's stream

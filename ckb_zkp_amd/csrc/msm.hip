@@ -1015,6 +1015,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       ZKP_HIP(hipEventElapsedTime(ms_scan, ctx->ev2, ctx->ev3));
     }
     if (!reuse && !l1_reuse) ZKP_HIP(hipEventRecord(ws.l1_done, st));
+    if (!reuse && !l1_reuse) ctx->mark(st, ":l1");
     if (!reuse)
       hipLaunchKernelGGL(sort_bin_kernel, dim3(nbins1), dim3(SORT_BIN_THREADS), ((size_t)4 << LB) + 4 * (size_t)SORT_BIN_STAGE, st,
                          kv, offs, nblocks, LB, vals, start, end, (l1_reuse || grp) ? be->filter_bit : -1);
@@ -1040,6 +1041,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       hipLaunchKernelGGL(task_order_kernel, dim3((max_tasks + 255) / 256), dim3(256), 0, st, task_start, task_len, task_dst,
                          toff + nb, tmeta, desc);
       ZKP_HIP(hipEventRecord(ws.sorted, st));
+      ctx->mark(st, ":sorted");
     }
     // level l of the reduction pyramid lives at element offset lvl_off[l] of `buckets` (level 0 = buckets);
     // all-zero bytes are a valid identity (zz == 0), so empty buckets need no kernel
@@ -1059,8 +1061,10 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     const bool timed = ms_accumulate && ctx->profiling;
     if (timed) ZKP_HIP(hipEventRecord(ctx->ev2, st));
     static const uint32_t force_redo = getenv("ZKP_DEBUG_FORCE_REDO") && atoi(getenv("ZKP_DEBUG_FORCE_REDO")) != 0 ? 2u : 0u;   // tests
+    ctx->mark(st, ":acc0");
     vt->accumulate(st, be->table, sorted_vals, desc, toff + nb, max_tasks, buckets, task_partial,
                    ws.redo.as<uint32_t>((size_t)max_tasks + 1), init | force_redo);
+    ctx->mark(st, ":acc1");
     if (timed) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
       ZKP_HIP(hipEventSynchronize(ctx->ev3));
@@ -1182,6 +1186,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       vt->segsum(st, partial, &p2, Obuf, L);
     }
     vt->final(st, Obuf, L, root, (char*)out_dev_xyzz, out_jac);
+    ctx->mark(st, ":reduced");
   }
   ZKP_HIP(hipGetLastError());
   if (out_xyz_host) {
@@ -1208,7 +1213,7 @@ void msm_run_multi(zkp_ctx* ctx, size_t count, const uint64_t* handles, const si
     ZKP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), count * jw * 4 + 4096));
     ctx->pinned_cap = count * jw * 4 + 4096;
   }
-  constexpr int NW = zkp_lane::N_WS;                              // MSM workspaces (stream + scratch) per lane
+  constexpr int NW = zkp_lane::N_WS_MSM;                          // MSM workspaces (stream + scratch) per lane
   static const int NL = [] { const char* e = getenv("ZKP_BATCH_LANES"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > zkp_ctx::N_LANES ? zkp_ctx::N_LANES : v); }();
   // job k runs on lane (k / NW) % NL, workspace k % NW: up to NL * NW MSMs in flight, one hardware queue each
   auto stream_of = [&](int li, int w) { return w == 0 ? ctx->lanes[li].stream : ctx->lanes[li].ws[w].stream; };

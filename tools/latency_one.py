@@ -22,7 +22,7 @@ def fr():
 ts = []
 for i in range(n):
     ctx.sync()
-    time.sleep(0.02)                      # a visible idle gap in front of every proof
+    time.sleep(float(os.environ.get("GAP_S", "0")))   # GAP_S=0.02: a visible idle gap in front of every proof (traces)
     t0 = time.perf_counter()
     pk.prove_raw(z_dev, fr(), fr(), z_on_device=True)
     ts.append((time.perf_counter() - t0) * 1e3)

@@ -5,7 +5,7 @@ ROOT=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace -d $OUT/trace -o t -- python $ROOT/tools/latency_one.py $CURVE $LG 6 > $OUT/latency.txt 2> $OUT/latency.err
+GAP_S=0.02 rocprofv3 --kernel-trace -d $OUT/trace -o t -- python $ROOT/tools/latency_one.py $CURVE $LG 6 > $OUT/latency.txt 2> $OUT/latency.err
 cd $ROOT
 DB=$(find $OUT/trace -name "*.db" | head -1)
 python tools/rocpd_list.py $DB $WIN 0 > $OUT/list.txt 2>&1
