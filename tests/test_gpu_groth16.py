@@ -360,3 +360,55 @@ def test_l_reuses_a_sort_when_identity_patterns_agree(ctx, capfd, monkeypatch):
             assert proof.c == G1.mul(G1.gen, Cc)
     finally:
         pk.free()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_identity_proof_points_through_the_host_tail(ctx, curve):
+    """The three proof points leave the device as XYZZ and become affine on the host (host_field.hpp, one inversion for all three):
+    the identity must come out as ark's (0, 0) + flag, alone and next to ordinary points.  (i) a key whose G2 side is the identity
+    everywhere: B = O while A and C are those of the ordinary key (C does not touch G2, prover.rs:192-210); (ii) an all-identity
+    key: A = B = C = O.  ark's `Parameters::deserialize` accepts such keys (a useless key, not a malformed one)."""
+    import dataclasses
+
+    import numpy as np
+
+    S = 20
+    inst = mimc_chain_instance(curve, S)
+    params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    c = params.curve
+    z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+    rm, sm = codec.fr_to_mont([0x1234567], c)[0], codec.fr_to_mont([0x7654321], c)[0]
+
+    def ident(q):
+        return (np.zeros_like(q[0]), np.ones_like(q[1]))
+
+    pk = groth16.ProvingKey(ctx, params, inst)
+    try:
+        out0, inf0 = pk.prove_raw(z, rm, sm)
+        p0 = pk.decode_proof(out0, inf0)
+    finally:
+        pk.free()
+    assert list(inf0) == [0, 0, 0]
+    g2_off = dataclasses.replace(params, beta_g2=np.zeros_like(params.beta_g2), delta_g2=np.zeros_like(params.delta_g2),
+                                 b_g2_query=ident(params.b_g2_query))
+    pk = groth16.ProvingKey(ctx, g2_off, inst)
+    try:
+        out, inf = pk.prove_raw(z, rm, sm)
+        p = pk.decode_proof(out, inf)
+    finally:
+        pk.free()
+    assert list(inf) == [0, 1, 0] and p.a == p0.a and p.c == p0.c and p.b is None
+    fq = c.fq_limbs
+    assert not out[2 * fq:6 * fq].any()                                   # the identity is written as zeros
+    all_off = dataclasses.replace(g2_off, alpha_g1=np.zeros_like(params.alpha_g1), beta_g1=np.zeros_like(params.beta_g1),
+                                  delta_g1=np.zeros_like(params.delta_g1), a_query=ident(params.a_query),
+                                  b_g1_query=ident(params.b_g1_query), h_query=ident(params.h_query),
+                                  l_query=ident(params.l_query))
+    pk = groth16.ProvingKey(ctx, all_off, inst)
+    try:
+        out, inf = pk.prove_raw(z, rm, sm)
+        outs, infs = pk.prove_batch_raw([ctx.to_device(z)] * 3, np.stack([rm] * 3), np.stack([sm] * 3))
+    finally:
+        pk.free()
+    assert list(inf) == [1, 1, 1] and not out.any()
+    assert not outs.any() and infs.tolist() == [[1, 1, 1]] * 3
