@@ -555,7 +555,9 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     // (Round 4, measured with ZKP_TIMELINE=1 and removed again: holding the accumulate kernels of A / B1 / B2 / L until the witness map
     //  is done — the map ends at 5.4 ms of an 8.2 ms proof when they start at 0.9 ms — and giving L a workspace of its own so that its
     //  accumulate need not wait for A's reduction chain: 8.6-8.8 / 8.6-8.9 / 9.3-9.6 ms (gate / workspace / both) against 8.0-8.4.  The
-    //  machine-filling accumulates only change places; what ends last is still one accumulate + its reduction.  profiles/r04_latency_*.)
+    //  machine-filling accumulates only change places; what ends last is still one accumulate + its reduction.  A third plan — main: map ->
+    //  H (sorted, accumulated, reduction deferred) -> L on top of H's buckets; B2 at once; A / B1 accumulates held until H is sorted —
+    //  proved correct and ran 9.2-9.7 ms.  profiles/r04_latency_experiments.txt.)
     static const bool l_own = !(getenv("ZKP_L_OWN_STREAM") && atoi(getenv("ZKP_L_OWN_STREAM")) == 0);
     static const int lat_env = [] { const char* e = getenv("ZKP_LATENCY_PLAN"); return e ? atoi(e) : -1; }();
     (void)latency_plan;
