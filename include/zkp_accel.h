@@ -44,6 +44,9 @@ typedef enum { ZKP_NTT_FFT = 0, ZKP_NTT_IFFT = 1, ZKP_NTT_COSET_FFT = 2, ZKP_NTT
 typedef struct zkp_ctx zkp_ctx; /* opaque: device, stream, twiddle tables, scratch, resident bases */
 
 const char* zkp_status_string(int32_t status);
+/* "zkp_accel <major.minor> (gfx950)".  0.4 (round 4): ZKP_ERR_INVALID_POINT for malformed / out-of-subgroup points (0.2 used
+ * ZKP_ERR_BAD_ARG), zkp_groth16_multi_info, zkp_bench_hbm_copy; since 0.3 a bucket-chained key returns slot L of
+ * zkp_groth16_prove_partials_dev as the identity and slot H as h + l (their sum is what prover.rs:189-196 consumes). */
 const char* zkp_version(void);
 
 /* ---- context & device memory ------------------------------------------------------------------ */
