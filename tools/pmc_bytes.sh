@@ -9,7 +9,7 @@ cd /tmp
 i=0
 for C in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $C -d $OUT/p$i -o pmc -- python $ROOT/bench.py --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline --no-marlin > $OUT/p$i.json 2> $OUT/p$i.err
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/p$i -o pmc -- python $ROOT/bench.py --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline --no-marlin --no-extra-configs > $OUT/p$i.json 2> $OUT/p$i.err
 done
 cd $ROOT
 python tools/rocpd_counts.py $(find $OUT -name "*.db") > $OUT/counts.txt 2>&1
