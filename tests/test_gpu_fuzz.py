@@ -94,3 +94,96 @@ def test_ntt_fuzz_against_cpu_port(ctx, curve):
         x = codec.fr_to_mont(v, c).reshape(-1, 4)
         for op in (NTT_FFT, NTT_IFFT, NTT_COSET_FFT, NTT_COSET_IFFT):
             assert np.array_equal(ctx.ntt(c, x, op), cpu_oracle.ntt(c.cid, x, op, threads=4)), (curve, case, k, kind, op)
+
+
+class _RandomCircuit:
+    """Random R1CS through the reference's ConstraintSystem interface (r1cs/src/constraint_system.rs:10-93): rows with 0-4 terms,
+    coefficients from {1, -1, small, full width}, repeated variables inside a row, public inputs beyond the constant, and a constraint
+    count that lands below / on / above a power of two.  Most rows are satisfied (c = a fresh variable holding a*b); a few are not —
+    the prover's formulas (prover.rs:124-211, r1cs_to_qap.rs:113-172) are defined either way and both sides must agree."""
+
+    def __init__(self, curve, seed, n_inputs, n_constraints, assign=True):
+        self.c, self.seed, self.ni, self.nc, self.assign = get_curve(curve), seed, n_inputs, n_constraints, assign
+
+    def generate_constraints(self, cs):
+        import random
+        rnd = random.Random(self.seed)
+        r = self.c.r
+        vals = {cs.one(): 1}
+        vs = [cs.one()]
+        for _ in range(self.ni):
+            v = rnd.randrange(r)
+            x = cs.alloc_input(lambda v=v: v)
+            vals[x] = v
+            vs.append(x)
+        for _ in range(3):
+            v = rnd.choice([0, 1, rnd.randrange(r)])
+            x = cs.alloc(lambda v=v: v)
+            vals[x] = v
+            vs.append(x)
+
+        def coeff():
+            return rnd.choice([1, 1, r - 1, rnd.randrange(1, 1000), rnd.randrange(r)])
+
+        def row():
+            return [(coeff(), rnd.choice(vs)) for _ in range(rnd.choice([0, 1, 1, 2, 2, 3, 4]))]
+
+        def value(terms):
+            return sum(k * vals[v] for k, v in terms) % r
+
+        def lc_of(terms):
+            def f(lc):
+                for k, v in terms:
+                    lc = lc + (k, v)
+                return lc
+            return f
+
+        for i in range(self.nc):
+            ta, tb = row(), row()
+            prod = value(ta) * value(tb) % r
+            kind = rnd.random()
+            if kind < 0.75:                                   # c = one fresh variable (unit coefficient: the skip-the-product path)
+                x = cs.alloc(lambda v=prod: v)
+                vals[x] = prod
+                vs.append(x)
+                tc = [(1, x)]
+            elif kind < 0.9:                                  # c = k * fresh + existing terms, still satisfied
+                k = rnd.randrange(1, r)
+                rest = row()
+                want = (prod - value(rest)) * pow(k, -1, r) % r
+                x = cs.alloc(lambda v=want: v)
+                vals[x] = want
+                vs.append(x)
+                tc = [(k, x)] + rest
+            else:                                             # arbitrary c: not satisfied
+                tc = row()
+            cs.enforce(lc_of(ta), lc_of(tb), lc_of(tc))
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_groth16_fuzz_against_cpu_port(ctx, curve):
+    """Random circuits: device proof and witness map == oracle/cpu (same key, witness, r, s), bit for bit."""
+    from ckb_zkp_amd import groth16
+    from ckb_zkp_amd.r1cs import ConstraintSystem, R1csInstance
+    c = get_curve(curve)
+    rng = np.random.default_rng(0xC1C + c.cid)
+    toxic = dict(alpha=0x1234567, beta=0x89ABCDE, gamma=0xF012345, delta=0x6789ABC, tau=0xDEF0123456789)
+    shapes = [(1, 1), (0, 1), (2, 2), (1, 3), (3, 4), (0, 7), (1, 8), (2, 13), (1, 15), (1, 16), (4, 17), (1, 30), (0, 31), (2, 64),
+              (1, 100), (3, 127), (0, 128), (1, 129), (2, 250), (1, 511), (1, 600)]
+    for case, (ni, nc) in enumerate(shapes):
+        cs = ConstraintSystem(c, True)
+        _RandomCircuit(curve, 1000 + case, ni, nc).generate_constraints(cs)
+        inst = R1csInstance.from_cs(cs)
+        params = groth16.generate_parameters(ctx, c, inst, **toxic)
+        pk = groth16.ProvingKey(ctx, params, inst)
+        try:
+            z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+            assert np.array_equal(pk.witness_map(z), cpu_oracle.witness_map(params, inst, z, threads=4)), (curve, case, ni, nc)
+            for _ in range(2):
+                rm = codec.fr_to_mont([int.from_bytes(rng.bytes(40), "little") % c.r], c)[0]
+                sm = codec.fr_to_mont([int.from_bytes(rng.bytes(40), "little") % c.r], c)[0]
+                out, inf = pk.prove_raw(z, rm, sm)
+                o_out, o_inf, _ = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=4)
+                assert np.array_equal(out, o_out) and np.array_equal(inf, o_inf), (curve, case, ni, nc)
+        finally:
+            pk.free()
