@@ -102,8 +102,8 @@ class _RandomCircuit:
     count that lands below / on / above a power of two.  Most rows are satisfied (c = a fresh variable holding a*b); a few are not —
     the prover's formulas (prover.rs:124-211, r1cs_to_qap.rs:113-172) are defined either way and both sides must agree."""
 
-    def __init__(self, curve, seed, n_inputs, n_constraints, assign=True):
-        self.c, self.seed, self.ni, self.nc, self.assign = get_curve(curve), seed, n_inputs, n_constraints, assign
+    def __init__(self, curve, seed, n_inputs, n_constraints, unsatisfied=True):
+        self.c, self.seed, self.ni, self.nc, self.unsat = get_curve(curve), seed, n_inputs, n_constraints, unsatisfied
 
     def generate_constraints(self, cs):
         import random
@@ -141,7 +141,7 @@ class _RandomCircuit:
         for i in range(self.nc):
             ta, tb = row(), row()
             prod = value(ta) * value(tb) % r
-            kind = rnd.random()
+            kind = rnd.random() * (1.0 if self.unsat else 0.9)
             if kind < 0.75:                                   # c = one fresh variable (unit coefficient: the skip-the-product path)
                 x = cs.alloc(lambda v=prod: v)
                 vals[x] = prod
@@ -187,3 +187,50 @@ def test_groth16_fuzz_against_cpu_port(ctx, curve):
                 assert np.array_equal(out, o_out) and np.array_equal(inf, o_inf), (curve, case, ni, nc)
         finally:
             pk.free()
+
+
+@pytest.mark.parametrize("curve,seed,ni,nc", [("bn254", 1, 1, 5), ("bn254", 2, 0, 9), ("bls12_381", 3, 1, 6), ("bn254", 4, 3, 14), ("bls12_381", 5, 0, 3), ("bn254", 6, 1, 30), ("bls12_381", 7, 3, 21)])
+def test_marlin_fuzz_against_oracle(ctx, curve, seed, ni, nc):
+    """Random (satisfied) circuits through zkp_marlin_index_upload / _index_commit / _prove against oracle/pyref's create_random_proof:
+    index commitments, transcript-derived challenges, commitments, 21 evaluations, both opening proofs; the oracle's verifier accepts.
+    (1 + ni must be a power of two: the AHP indexes the public inputs by a subdomain of H, marlin/src/ahp/prover.rs:86-147.)"""
+    import random
+
+    from ckb_zkp_amd import kzg10
+    from ckb_zkp_amd import marlin as marlin_native
+    from ckb_zkp_amd.r1cs import ConstraintSystem, R1csInstance
+    from oracle.pyref import kzg10 as okzg
+    from oracle.pyref import marlin as om
+    c = get_curve(curve)
+    circ = _RandomCircuit(curve, 7000 + seed, ni, nc, unsatisfied=False)
+    cs = ConstraintSystem(c, True)
+    circ.generate_constraints(cs)
+    inst = R1csInstance.from_cs(cs)
+    oidx = om.index(OC[curve], circ)
+    nidx = marlin_native.NativeIndex(ctx, inst)
+    assert (nidx.xs, nidx.hs, nidx.ks, nidx.bs, nidx.max_degree, nidx.num_non_zeros) == \
+        (oidx["dx"].size, oidx["dh"].size, oidx["dk"].size, oidx["db"].size, oidx["max_degree"], oidx["num_non_zeros"])
+    beta_srs = 0x2468ACE13579BDF + seed
+    pp = okzg.setup(OC[curve], nidx.max_degree, beta_srs)
+    ck = kzg10.setup(ctx, curve, nidx.max_degree, beta_srs)
+    try:
+        ic = om.index_commitments(oidx, pp)
+        assert nidx.commit_index(ck) == ic
+        rnd = random.Random(seed)
+        R = dict(w=[rnd.randrange(c.r)], z_a=[rnd.randrange(c.r)], z_b=[rnd.randrange(c.r)],
+                 mask=[rnd.randrange(c.r) for _ in range(3 * nidx.hs)],
+                 blind={l: [rnd.randrange(c.r), rnd.randrange(c.r)] for l in ("w", "z_a", "z_b", "g_1")},
+                 blind_shifted={"g_1": [rnd.randrange(c.r), rnd.randrange(c.r)]})
+        x, w = inst.z[:inst.num_inputs], inst.z[inst.num_inputs:]
+        ivk = om.index_verifier_key(oidx, pp, ic)
+        p = marlin_native.prove_native(ctx, nidx, ck, ivk, x, w, R)
+        o = om.create_random_proof(oidx, pp, ic, circ, R)
+        assert p["challenges"] == o["challenges"]
+        assert p["commitments"] == o["commitments"] and p["evaluations"] == o["evaluations"]
+        assert p["opening_proofs"] == o["opening_proofs"]
+        wire = dict(commitments=p["commitments"], evaluations=p["evaluations"], opening_proofs=p["opening_proofs"])
+        assert om.verify_random_proof(oidx, pp, ic, wire, x[1:])
+    finally:
+        nidx.free()
+        ck.powers_of_g.free()
+        ck.powers_of_gamma_g.free()
