@@ -2,6 +2,7 @@
 // msm_acc.hip): table pre-computation, log-depth bucket reduction, point utilities, Groth16 assembly.
 // Compiled once per (curve, group): -DZKP_CFG_CURVE={0,1} -DZKP_CFG_GROUP={1,2}.  See msm.hip for the design.
 #include "bucket_dev.hpp"
+#include "coop_dev.hpp"
 #include "ec_dev.hpp"
 #include "msm_vtbl.hpp"
 
@@ -77,9 +78,20 @@ __global__ __launch_bounds__(PAIR_TOP_THREADS) void pair_top_kernel(char* __rest
   char* in = base;
   for (; cnt > 1; cnt >>= 1) {
     char* out = in + (size_t)cnt * BkPoint<F>::BYTES;
-    for (uint32_t k = threadIdx.x; k < cnt / 2; k += PAIR_TOP_THREADS)
-      BkPoint<F>::add_mem(in + (size_t)(2 * k) * BkPoint<F>::BYTES, in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES,
-                          out + (size_t)k * BkPoint<F>::BYTES);
+    bool coop = false;
+    if constexpr (QuadCoop<F>::ON) coop = cnt / 2 <= PAIR_TOP_THREADS / 4;       // fewer additions than quads: four lanes per addition
+    if constexpr (QuadCoop<F>::ON) {
+      if (coop) {
+        const uint32_t k = threadIdx.x >> 2;
+        if (k < cnt / 2)
+          quad_add_mem<typename QuadCoop<F>::P>(in + (size_t)(2 * k) * BkPoint<F>::BYTES, in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES,
+                                           out + (size_t)k * BkPoint<F>::BYTES, threadIdx.x & 3);
+      }
+    }
+    if (!coop)
+      for (uint32_t k = threadIdx.x; k < cnt / 2; k += PAIR_TOP_THREADS)
+        BkPoint<F>::add_mem(in + (size_t)(2 * k) * BkPoint<F>::BYTES, in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES,
+                            out + (size_t)k * BkPoint<F>::BYTES);
     __threadfence_block();
     __syncthreads();
     in = out;
@@ -105,7 +117,15 @@ __global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ ba
       BkPoint<F>::add_mem(my, base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * BkPoint<F>::BYTES, my);
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) BkPoint<F>::add_mem(my, smem + (threadIdx.x + s) * BkPoint<F>::BYTES, my);
+      bool coop = false;
+      if constexpr (QuadCoop<F>::ON) {
+        coop = s <= 64;                                                         // 64 quads: four lanes per addition from here on
+        if (coop && (int)(threadIdx.x >> 2) < s) {
+          char* mine = smem + (threadIdx.x >> 2) * BkPoint<F>::BYTES;
+          quad_add_mem<typename QuadCoop<F>::P>(mine, smem + ((threadIdx.x >> 2) + s) * BkPoint<F>::BYTES, mine, threadIdx.x & 3);
+        }
+      }
+      if (!coop && (int)threadIdx.x < s) BkPoint<F>::add_mem(my, smem + (threadIdx.x + s) * BkPoint<F>::BYTES, my);
       __syncthreads();
     }
     if (threadIdx.x == 0) BkPoint<F>::copy_point(partial + (size_t)blockIdx.x * BkPoint<F>::BYTES, my);
@@ -200,11 +220,36 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
 
 // out = sum_l 2^l * O[l] + root ; one wave
 template <class F>
-__global__ __launch_bounds__(64) void final_kernel(const char* __restrict__ O, int L, const char* __restrict__ root,
+__global__ __launch_bounds__(128) void final_kernel(const char* __restrict__ O, int L, const char* __restrict__ root,
                                                    char* __restrict__ out_xyzz, uint32_t* __restrict__ out_jac) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int t = threadIdx.x;
+  if constexpr (QuadCoop<F>::ON) {
+    // G1 (round 4): 128 lanes = 32 quads, quad q owns point q (levels 0..L-1, the root at L): q cooperative doublings, then a tree
+    // of cooperative additions — 18 x 3 + 5 x 5.5 product latencies instead of 18 x 9.75 + 6 x 14.5
+    const int q = t >> 2, role = t & 3;
+    char* my = smem + q * BkPoint<F>::BYTES;
+    if (role == 0) {
+      if (q < L) BkPoint<F>::copy_point(my, O + (size_t)q * BkPoint<F>::BYTES);
+      else if (q == L) BkPoint<F>::copy_point(my, root);
+      else BkPoint<F>::inf().store(my);
+    }
+    __syncthreads();
+    if (q < L)
+      for (int k = 0; k < q; k++) quad_dbl_mem<typename QuadCoop<F>::P>(my, my, role);
+    __syncthreads();
+    for (int s = 16; s > 0; s >>= 1) {
+      if (q < s) quad_add_mem<typename QuadCoop<F>::P>(my, smem + (q + s) * BkPoint<F>::BYTES, my, role);
+      __syncthreads();
+    }
+    if (t == 0) {
+      const XYZZ<F> res = BkPoint<F>::load(my).to_sat();
+      if (out_xyzz) res.store(out_xyzz);
+      if (out_jac) res.store_jacobian(out_jac);
+    }
+    return;
+  }
   if constexpr (BkPoint<F>::MEM_ADD) {
     // G2: the lane's point lives in its LDS slot, additions / doublings stream their operands (bucket_dev.hpp)
     char* my = smem + t * BkPoint<F>::BYTES;
@@ -828,7 +873,8 @@ void l_segsum(hipStream_t s, const char* base, const SegPlan* plan, char* partia
   hipLaunchKernelGGL(segsum_kernel<F>, dim3(blocks), dim3(256), 256 * BB, s, base, *plan, partial);
 }
 void l_final(hipStream_t s, const char* O, int L, const char* root, char* out_xyzz, uint32_t* out_jac) {
-  hipLaunchKernelGGL(final_kernel<F>, dim3(1), dim3(64), 64 * BB, s, O, L, root, out_xyzz, out_jac);
+  constexpr int threads = QuadCoop<F>::ON ? 128 : 64;            // G1: 32 quads (coop_dev.hpp)
+  hipLaunchKernelGGL(final_kernel<F>, dim3(1), dim3(threads), 64 * BB, s, O, L, root, out_xyzz, out_jac);
 }
 void l_identity(hipStream_t s, char* out_xyzz, uint32_t* out_jac) {
   hipLaunchKernelGGL(write_identity_kernel<F>, dim3(1), dim3(64), 0, s, out_xyzz, out_jac);
