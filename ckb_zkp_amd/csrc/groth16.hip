@@ -56,6 +56,8 @@ struct zkp_groth16_pk {
   bool share_al_sort = false;    // L (stored index-aligned with z) reuses A's bucket sort: same scalars, same identity pattern
   bool share_l1 = false;         // A, L and (b_in_l1) B2 (+B1) share ONE level-1 sort pass over z (each filters its identities at level 2)
   bool b_in_l1 = false;          // the B queries have A's window configuration and take part in the shared pass
+  bool c_folded = false;         // hL holds L - C^T G (fold_c_into_l): the prover skips C z and the c chain of the witness map
+  bool h_lagrange = false;       // hH holds the H query in EVALUATION form over the coset (lagrange_h below): the prover skips the last transform
   // Base-sharded key (BASELINE configs[4]): this rank holds elements [q_lo, q_lo + q_n) of every
   // (extended) query; world == 0 means the whole key.  Index order: A, B1, B2, H, L.
   int shard_rank = 0, shard_world = 0;
@@ -113,6 +115,16 @@ __global__ __launch_bounds__(256) void qap_pointwise_kernel(uint32_t* __restrict
   if (i >= N) return;
   F x = F::load(a + (size_t)i * 8) * F::load(b + (size_t)i * 8) - F::load(c + (size_t)i * 8);
   (x * F::load(zinv)).store(a + (size_t)i * 8);
+}
+
+// a[i] = a[i]*b[i] * zinv: the pointwise step of a key with C folded into its L query (fold_c_into_l)
+template <class P>
+__global__ __launch_bounds__(256) void qap_pointwise_ab_kernel(uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                               const uint32_t* __restrict__ zinv, uint32_t N) {
+  using F = Fp<P>;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  (F::load(a + (size_t)i * 8) * F::load(b + (size_t)i * 8) * F::load(zinv)).store(a + (size_t)i * 8);
 }
 
 // consts[0] = (g^N - 1)^-1
@@ -192,6 +204,154 @@ static uint64_t upload_ext(zkp_ctx* ctx, int curve, int group, const uint64_t* q
   }
   if (flags_out) *flags_out = fl;
   return bases_upload(ctx, curve, group, xy.data(), fl.data(), cnt, c_hint, cap_hint, lgk);
+}
+
+// The H query in evaluation form (round 4).  h = coset_ifft(v) (r1cs_to_qap.rs:169) is linear, h_i = g^-i / N sum_j w^-ij v_j, so
+//     sum_i h_i H_i = sum_j v_j H'_j     with     H'_j = sum_i w^-ij (g^-i / N) H_i
+// — a group-element transform of the key, done once at upload (N log N / 2 scalar multiplications on the device, 0.5 s at 2^20),
+// after which the prover feeds the pointwise values v = (a b - c) / Z(g) on the coset straight to the H MSM: 18 instead of 21
+// transform passes per proof and one transform less on the witness map -> H chain.  The proof is the same group element; terms
+// beyond min(h_len, N) are the identity (prover.rs:186-187 truncates there).  ZKP_H_LAGRANGE=0: the coefficient-form key.
+// (the devices of an in-process multi-GPU key are uploaded one after the other from the same descriptor: one transform serves all)
+static thread_local bool lagrange_keep_cache = false;
+static thread_local struct LagrangeCache {
+  const void* q = nullptr;
+  size_t used = 0;
+  int log_n = -1, curve = -1;
+  std::vector<uint64_t> xy;
+  std::vector<uint8_t> inf;
+  void clear() {
+    q = nullptr;
+    std::vector<uint64_t>().swap(xy);
+    std::vector<uint8_t>().swap(inf);
+  }
+} lagrange_cache;
+// mode 1: G_k = (zinv / N) sum_i w^-ik H_i instead (the inverse transform of H itself, scaled by zinv = 1 / Z(g)): the bases of
+// the C part of h, see fold_c_into_l below.
+static void lagrange_h(zkp_ctx* ctx, int curve, const uint64_t* h_query, const uint8_t* h_inf, size_t h_used, int log_n,
+                       std::vector<uint64_t>* xy_out, std::vector<uint8_t>* inf_out, int mode = 0) {
+  using namespace hostf;
+  const HostField F = fr_field(curve);
+  const size_t N = (size_t)1 << log_n, fq = curve == ZKP_BN254 ? 4 : 6;
+  const MsmVtbl* v1 = msm_vtbl(curve, 1);
+  auto ld = [&](const uint32_t* p) {
+    HostField::E e{};
+    memcpy(e.data(), p, 32);
+    return e;
+  };
+  const int adicity = curve == ZKP_BN254 ? consts::Bn254Fr::TWO_ADICITY : consts::Bls381Fr::TWO_ADICITY;
+  HostField::E wi = ld(curve == ZKP_BN254 ? consts::Bn254Fr::ROOT_INV : consts::Bls381Fr::ROOT_INV);
+  const HostField::E gi = ld(curve == ZKP_BN254 ? consts::Bn254Fr::GEN_INV : consts::Bls381Fr::GEN_INV);
+  wi = F.pow2k(wi, adicity - log_n);                                   // w_N^-1
+  std::vector<uint32_t> scal(N * 8), tw(std::max<size_t>(N / 2, 1) * 8);
+  HostField::E acc = F.inverse(F.from_u64((uint64_t)N));               // g^-i / N
+  if (mode == 1) {                                                     // zinv / N, zinv = 1 / (g^N - 1)
+    const HostField::E g = ld(curve == ZKP_BN254 ? consts::Bn254Fr::GEN : consts::Bls381Fr::GEN);
+    acc = F.mul(acc, F.inverse(F.sub(F.pow2k(g, log_n), F.one_())));
+  }
+  for (size_t i = 0; i < N; i++) {
+    const HostField::E c = F.to_canonical(acc);
+    memcpy(&scal[i * 8], c.data(), 32);
+    if (mode == 0) acc = F.mul(acc, gi);
+  }
+  acc = F.one_();
+  for (size_t e = 0; e < N / 2; e++) {
+    const HostField::E c = F.to_canonical(acc);
+    memcpy(&tw[e * 8], c.data(), 32);
+    acc = F.mul(acc, wi);
+  }
+  hipStream_t st = ctx->cur->stream;
+  DevBuf d_xy, d_inf, d_scal, d_tw, d_X, d_oxy, d_oinf;
+  const size_t ab = v1->aff_bytes;
+  char* xy = d_xy.as<char>(std::max<size_t>(h_used, 1) * ab);
+  uint8_t* inf = d_inf.as<uint8_t>(std::max<size_t>(h_used, 1));
+  ZKP_REQUIRE(ab == 2 * fq * 8, ZKP_ERR_BAD_ARG);
+  if (h_used) ZKP_HIP(hipMemcpyAsync(xy, h_query, h_used * ab, hipMemcpyHostToDevice, st));
+  if (h_used && h_inf) ZKP_HIP(hipMemcpyAsync(inf, h_inf, h_used, hipMemcpyHostToDevice, st));
+  else ZKP_HIP(hipMemsetAsync(inf, 0, std::max<size_t>(h_used, 1), st));
+  uint32_t* dscal = d_scal.as<uint32_t>(scal.size());
+  uint32_t* dtw = d_tw.as<uint32_t>(tw.size());
+  ZKP_HIP(hipMemcpyAsync(dscal, scal.data(), scal.size() * 4, hipMemcpyHostToDevice, st));
+  ZKP_HIP(hipMemcpyAsync(dtw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice, st));
+  char* X = d_X.as<char>(N * v1->xyzz_bytes);
+  char* oxy = d_oxy.as<char>(N * ab);
+  uint8_t* oinf = d_oinf.as<uint8_t>(N);
+  v1->gfft(st, xy, inf, h_used, dscal, dtw, (uint32_t)log_n, X, oxy, oinf);
+  ZKP_HIP(hipGetLastError());
+  xy_out->resize(N * 2 * fq);
+  inf_out->resize(N);
+  ZKP_HIP(hipMemcpyAsync(xy_out->data(), oxy, N * ab, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(inf_out->data(), oinf, N, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipStreamSynchronize(st));
+}
+
+// The C matrix folded into the L query (round 4).  The quotient's coefficients are h = coset_ifft(a_c b_c zinv) - zinv C(X) (the
+// coset evaluations c_c of C(X) = interpolant of C z go through coset_ifft unchanged), so
+//     sum_i h_i H_i = sum_j (a_c b_c zinv)_j H'_j  -  sum_k (C z)_k G_k,      G_k = (zinv / N) sum_i w^-ik H_i
+// and the second sum is LINEAR in the assignment: sum_m z_m D_m with D_m = sum_k C_km G_k.  With L'_m = L_m - D_m (inputs: -D_m,
+// in the slots that are the identity in the index-aligned L table) the prover needs neither C z nor the ifft -> coset_fft chain
+// of c (r1cs_to_qap.rs:155-162): 12 instead of 18 transform passes per proof, for every assignment, satisfying or not.
+static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz, const std::vector<uint64_t>& g_xy,
+                          const std::vector<uint8_t>& g_inf, std::vector<uint64_t>* l_xy, std::vector<uint8_t>* l_inf) {
+  using namespace hostf;
+  const HostField F = fr_field(d->curve);
+  const MsmVtbl* v1 = msm_vtbl(d->curve, 1);
+  const size_t fq = d->curve == ZKP_BN254 ? 4 : 6, ab = v1->aff_bytes, ni = d->num_inputs;
+  const size_t nnz = d->ct.row_ptr[d->num_constraints];
+  // CSC of C: column = variable (inputs ++ aux), rows ascending
+  std::vector<uint32_t> col_ptr(nz + 1, 0), rows(std::max<size_t>(nnz, 1)), coeff(std::max<size_t>(nnz, 1) * 8, 0);
+  std::vector<uint8_t> kind(std::max<size_t>(nnz, 1), 0);
+  for (size_t e = 0; e < nnz; e++) {
+    ZKP_REQUIRE(d->ct.col[e] < nz, ZKP_ERR_BAD_ARG);
+    col_ptr[d->ct.col[e] + 1]++;
+  }
+  for (size_t m = 0; m < nz; m++) col_ptr[m + 1] += col_ptr[m];
+  std::vector<uint32_t> cur(col_ptr.begin(), col_ptr.end() - 1);
+  HostField::E one = F.one_(), minus_one = F.neg(one);
+  for (uint32_t k = 0; k < d->num_constraints; k++)
+    for (uint32_t e = d->ct.row_ptr[k]; e < d->ct.row_ptr[k + 1]; e++) {
+      const uint32_t pos = cur[d->ct.col[e]]++;
+      rows[pos] = k;
+      HostField::E c{};
+      memcpy(c.data(), d->ct.coeff + (size_t)e * 4, 32);
+      if (c == one) kind[pos] = 1;
+      else if (c == minus_one) kind[pos] = 2;
+      else {
+        const HostField::E cc = F.to_canonical(c);
+        memcpy(&coeff[(size_t)pos * 8], cc.data(), 32);
+      }
+    }
+  // the L query index-aligned with the assignment (leading identities for the inputs)
+  std::vector<uint64_t> lq(nz * 2 * fq, 0);
+  std::vector<uint8_t> li(nz, 1);
+  for (size_t m = ni; m < nz; m++) {
+    li[m] = d->l_inf ? d->l_inf[m - ni] : 0;
+    if (!li[m]) memcpy(&lq[m * 2 * fq], d->l_query + (m - ni) * 2 * fq, ab);
+  }
+  hipStream_t st = ctx->cur->stream;
+  DevBuf b_l, b_li, b_cp, b_rows, b_kind, b_coeff, b_g, b_gi, b_o, b_oi;
+  auto up = [&](DevBuf& b, const void* p, size_t bytes) {
+    void* dp = b.get(std::max<size_t>(bytes, 16));
+    ZKP_HIP(hipMemcpyAsync(dp, p, bytes, hipMemcpyHostToDevice, st));
+    return dp;
+  };
+  const char* dl = (const char*)up(b_l, lq.data(), lq.size() * 8);
+  const uint8_t* dli = (const uint8_t*)up(b_li, li.data(), li.size());
+  const uint32_t* dcp = (const uint32_t*)up(b_cp, col_ptr.data(), col_ptr.size() * 4);
+  const uint32_t* drows = (const uint32_t*)up(b_rows, rows.data(), rows.size() * 4);
+  const uint8_t* dkind = (const uint8_t*)up(b_kind, kind.data(), kind.size());
+  const uint32_t* dcoeff = (const uint32_t*)up(b_coeff, coeff.data(), coeff.size() * 4);
+  const char* dg = (const char*)up(b_g, g_xy.data(), g_xy.size() * 8);
+  const uint8_t* dgi = (const uint8_t*)up(b_gi, g_inf.data(), g_inf.size());
+  char* o = (char*)b_o.get(nz * ab);
+  uint8_t* oi = (uint8_t*)b_oi.get(nz);
+  v1->lfold(st, dl, dli, nz, dcp, drows, dkind, dcoeff, dg, dgi, o, oi);
+  ZKP_HIP(hipGetLastError());
+  l_xy->resize(nz * 2 * fq);
+  l_inf->resize(nz);
+  ZKP_HIP(hipMemcpyAsync(l_xy->data(), o, nz * ab, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipMemcpyAsync(l_inf->data(), oi, nz, hipMemcpyDeviceToHost, st));
+  ZKP_HIP(hipStreamSynchronize(st));
 }
 
 zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, int rank, int world) {
@@ -285,8 +445,33 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
                             (d->b_g1_inf && d->b_g2_inf && memcmp(d->b_g1_inf, d->b_g2_inf, d->b_g1_len) == 0);
       pk->share_b_sort = on && same_inf && bases_same_shape(ctx, pk->hB1, pk->hB2);
     }
+    static const bool lagrange_on = !(getenv("ZKP_H_LAGRANGE") && atoi(getenv("ZKP_H_LAGRANGE")) == 0);
+    if (lagrange_on && d->h_query && h_used > 0 && pk->log_n >= 1) {
+      LagrangeCache& cache = lagrange_cache;
+      if (!(lagrange_keep_cache && cache.q == d->h_query && cache.used == h_used && cache.log_n == pk->log_n && cache.curve == d->curve)) {
+        lagrange_h(ctx, d->curve, d->h_query, d->h_inf, h_used, pk->log_n, &cache.xy, &cache.inf);
+        cache.q = d->h_query;
+        cache.used = h_used;
+        cache.log_n = pk->log_n;
+        cache.curve = d->curve;
+      }
+      shard_bounds(pk->N, rank, world, &pk->q_lo[3], &pk->q_n[3]);
+      pk->hH = bases_upload(ctx, d->curve, 1, cache.xy.data() + pk->q_lo[3] * 2 * fq, cache.inf.data() + pk->q_lo[3],
+                            pk->q_n[3], 0, 0, lgk);
+      pk->h_lagrange = true;
+      if (!lagrange_keep_cache) cache.clear();
+    } else
     pk->hH = bases_upload(ctx, d->curve, 1, d->h_query ? d->h_query + pk->q_lo[3] * 2 * fq : nullptr,
                           d->h_inf ? d->h_inf + pk->q_lo[3] : nullptr, world > 0 ? pk->q_n[3] : (size_t)d->h_len, 0, 0, lgk);
+    static const bool cfold_on = !(getenv("ZKP_C_FOLD") && atoi(getenv("ZKP_C_FOLD")) == 0);
+    if (pk->h_lagrange && cfold_on && world == 0 && d->l_query) {
+      std::vector<uint64_t> gxy, lxy;
+      std::vector<uint8_t> ginf, linf;
+      lagrange_h(ctx, d->curve, d->h_query, d->h_inf, h_used, pk->log_n, &gxy, &ginf, 1);
+      fold_c_into_l(ctx, d, pk->nz, gxy, ginf, &lxy, &linf);
+      pk->hL = upload_ext(ctx, d->curve, 1, lxy.data(), linf.data(), pk->nz, 2 * fq, tL, pk->q_lo[4], pk->q_n[4], 0, &fL, 0, 0, lgk);
+      pk->c_folded = true;
+    } else
     pk->hL = upload_ext(ctx, d->curve, 1, d->l_query, d->l_inf, d->l_len, 2 * fq, tL, pk->q_lo[4], pk->q_n[4],
                         d->num_inputs, &fL, 0, 0, lgk);
     {
@@ -401,25 +586,28 @@ void groth16_pk_info(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t info[8]) {
 }
 
 // z_dev: nz Fr (device).  Leaves h (N Fr, Montgomery) in pk->abc[0..N)
+// coeffs: h in coefficient form wanted (zkp_groth16_witness_map; the prover of a coefficient-form key); false with an evaluation-form
+// key: the pointwise values v on the coset, the scalars of its H MSM
 template <class P>
-static uint32_t* witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint32_t* z_dev) {
+static uint32_t* witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint32_t* z_dev, bool coeffs = true) {
   const uint32_t N = (uint32_t)pk->N;
   uint32_t* a = pk->lane[ctx->cur_idx].abc.as<uint32_t>(3 * pk->N * 8);
   uint32_t* b = a + pk->N * 8;
   uint32_t* c = b + pk->N * 8;
   uint32_t* bufs[3] = {a, b, c};
   hipStream_t st = ctx->cur->stream;
-  for (int k = 0; k < 3; k++)
+  const int nchain = (!coeffs && pk->c_folded) ? 2 : 3;            // C folded into the L query: no C z, no c chain
+  for (int k = 0; k < nchain; k++)
     hipLaunchKernelGGL(csr_eval_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, st, pk->m[k].row_ptr, pk->m[k].col,
                        pk->m[k].coeff, z_dev, pk->num_constraints, N, pk->num_inputs, k == 0 ? 1 : 0, bufs[k]);
   // One launch for a, b, c (grid.y = 3) shortens the witness map in isolation (1.49 -> 1.35 ms at 2^20) but its 3x larger
   // launches delay the MSM streams of the other lane: 79 vs 85 proofs/s pipelined.  Off unless ZKP_NTT_BATCH=1.
   static const bool batch = getenv("ZKP_NTT_BATCH") && atoi(getenv("ZKP_NTT_BATCH")) != 0;
   if (batch) {
-    ntt_run_batch(ctx, pk->curve, bufs, 3, pk->log_n, ZKP_NTT_IFFT);
-    ntt_run_batch(ctx, pk->curve, bufs, 3, pk->log_n, ZKP_NTT_COSET_FFT);
+    ntt_run_batch(ctx, pk->curve, bufs, nchain, pk->log_n, ZKP_NTT_IFFT);
+    ntt_run_batch(ctx, pk->curve, bufs, nchain, pk->log_n, ZKP_NTT_COSET_FFT);
   } else {
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < nchain; k++) {
       // ifft -> coset_fft as one chain of passes (1/N folded into the coset table, no odd-pass copies); falls back to the two
       // separate transforms above the full-table domain limit
       if (!ntt_ifft_coset_fft(ctx, pk->curve, bufs[k], pk->log_n)) {
@@ -427,6 +615,12 @@ static uint32_t* witness_map_dev(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint32_
         ntt_run(ctx, pk->curve, bufs[k], pk->log_n, ZKP_NTT_COSET_FFT);
       }
     }
+  }
+  if (!coeffs) {
+    if (pk->c_folded) hipLaunchKernelGGL(qap_pointwise_ab_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, st, a, b, pk->consts.as<uint32_t>(64), N);
+    else hipLaunchKernelGGL(qap_pointwise_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, st, a, b, c, pk->consts.as<uint32_t>(64), N);
+    ZKP_HIP(hipGetLastError());
+    return a;
   }
   // (a*b - c) / Z(g) fused into the first pass of coset_ifft; h lands in a or b
   if (uint32_t* hq = ntt_qap_coset_ifft(ctx, pk->curve, a, b, c, pk->consts.as<uint32_t>(64), pk->log_n)) {
@@ -549,7 +743,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     // accumulates from three streams leaving its kernels few wave slots for milliseconds — was measured too: 10.3 ms, not kept.
     static const bool wm_first = !(getenv("ZKP_WM_FIRST") && atoi(getenv("ZKP_WM_FIRST")) == 0);
     if (wm_first) {
-      h = witness_map_dev<FrP>(ctx, pk, S);
+      h = witness_map_dev<FrP>(ctx, pk, S, !pk->h_lagrange);
       ctx->mark(st, "wm");
     }
     // (Round 4, measured with ZKP_TIMELINE=1 and removed again: holding the accumulate kernels of A / B1 / B2 / L until the witness map
@@ -607,7 +801,7 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
     l_done_in_fan = lat || l_own;
   }
   tic();
-  if (!h) h = witness_map_dev<FrP>(ctx, pk, S);
+  if (!h) h = witness_map_dev<FrP>(ctx, pk, S, !pk->h_lagrange);
   toc(&tm.ms_witness_map);
   if (!fan) {
     run(0, pk->hA, Sd + 4 * pk->q_lo[0], pk->q_n[0], 0);
@@ -1036,6 +1230,12 @@ uint32_t* witness_tail(zkp_ctx* ctx, zkp_groth16_pk* pk) {
   uint32_t* a = pk->lane[ctx->cur_idx].abc.as<uint32_t>(3 * pk->N * 8);
   uint32_t* b = a + pk->N * 8;
   uint32_t* c = b + pk->N * 8;
+  if (pk->h_lagrange) {                                      // evaluation-form key: the H MSM takes the pointwise values
+    hipLaunchKernelGGL(qap_pointwise_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, ctx->cur->stream, a, b, c,
+                       pk->consts.as<uint32_t>(64), N);
+    ZKP_HIP(hipGetLastError());
+    return a;
+  }
   if (uint32_t* hq = ntt_qap_coset_ifft(ctx, pk->curve, a, b, c, pk->consts.as<uint32_t>(64), pk->log_n)) return hq;
   hipLaunchKernelGGL(qap_pointwise_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, ctx->cur->stream, a, b, c,
                      pk->consts.as<uint32_t>(64), N);
@@ -1102,7 +1302,7 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
     hipLaunchKernelGGL(scalar_tail_kernel<FrP>, dim3(1), dim3(64), 0, st, S[k] + pk->nz * 8, rs);
     ZKP_HIP(hipEventRecord(ctx->cur->ev_fork, st));
     for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[w].stream, ctx->cur->ev_fork, 0));
-    if (!split) h[k] = witness_map_dev<FrP>(ctx, pk, S[k]);
+    if (!split) h[k] = witness_map_dev<FrP>(ctx, pk, S[k], !pk->h_lagrange);
     else if (k < 3) {
       witness_chain<FrP>(ctx, pk, S[k], k);
       ZKP_HIP(hipEventRecord(M->ev_chain[k], st));
@@ -1205,6 +1405,13 @@ zkp_groth16_pk_multi* groth16_pk_upload_multi(zkp_ctx* root, const zkp_groth16_p
   std::unique_ptr<zkp_groth16_pk_multi> M(new zkp_groth16_pk_multi());
   M->mode = mode;
   M->curve = d->curve;
+  struct KeepLagrange {
+    KeepLagrange() { lagrange_keep_cache = true; }
+    ~KeepLagrange() {
+      lagrange_keep_cache = false;
+      lagrange_cache.clear();
+    }
+  } keep_lagrange;
   try {
     for (int k = 0; k < n; k++) {
       zkp_ctx* ctx = root->devs[k];

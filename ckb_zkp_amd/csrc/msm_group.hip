@@ -635,6 +635,104 @@ __global__ __launch_bounds__(128) void fixed_base_kernel(const uint32_t* base, c
 }
 
 
+// ------------------------------------------------------------------------------------------- group-element transform
+// The H query in EVALUATION form (groth16.hip, round 4): H'_j = (1/N) sum_i w^(-ij) g^(-i) H_i, so that
+// sum_j v_j H'_j = sum_i h_i H_i for h = coset_ifft(v) — the last transform of the witness map (r1cs_to_qap.rs:169) moves into the key.
+// A radix-2 decimation-in-time transform over group elements: butterflies (u, q) -> (u + t q, u - t q) with t a scalar; one-time
+// work per key (N log N / 2 scalar multiplications), plain double-and-add on the saturated formulas of ec_dev.hpp.
+// X[bitrev(i)] = scal[i] * P_i   (scal: canonical 8-word scalars; P_i affine, identity beyond n_in)
+template <class F, int BITS>
+__global__ __launch_bounds__(128) void gfft_scale_kernel(const char* __restrict__ xy, const uint8_t* __restrict__ inf, size_t n_in,
+                                                         const uint32_t* __restrict__ scal, uint32_t log_n, char* __restrict__ X) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> log_n) return;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  if (i < n_in && !(inf && inf[i])) {
+    const Affine<F> p = Affine<F>::load(xy + i * Affine<F>::BYTES);
+    uint32_t k[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) k[l] = scal[i * 8 + l];
+    for (int bit = BITS; bit >= 0; bit--) {
+      acc = acc.dbl();
+      if ((k[bit >> 5] >> (bit & 31)) & 1) acc.madd(p);
+    }
+  }
+  const size_t r = log_n ? (size_t)(__brevll((unsigned long long)i) >> (64 - log_n)) : 0;
+  acc.store(X + r * XYZZ<F>::BYTES);
+}
+// stage s (1-based, block size m = 2^s): X[lo], X[hi] <- X[lo] + t X[hi], X[lo] - t X[hi], t = tw[j * N / m]
+template <class F, int BITS>
+__global__ __launch_bounds__(128) void gfft_stage_kernel(char* __restrict__ X, const uint32_t* __restrict__ tw, uint32_t log_n,
+                                                         uint32_t s) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >> (log_n - 1)) return;
+  const size_t half = (size_t)1 << (s - 1), j = b & (half - 1), lo = ((b >> (s - 1)) << s) + j, hi = lo + half;
+  const size_t e = j << (log_n - s);
+  const XYZZ<F> q = XYZZ<F>::load(X + hi * XYZZ<F>::BYTES);
+  XYZZ<F> t = q;
+  if (e != 0 && !q.is_inf()) {
+    uint32_t k[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) k[l] = tw[e * 8 + l];
+    t = XYZZ<F>::inf();
+    for (int bit = BITS; bit >= 0; bit--) {
+      t = t.dbl();
+      if ((k[bit >> 5] >> (bit & 31)) & 1) t.add(q);
+    }
+  }
+  XYZZ<F> u = XYZZ<F>::load(X + lo * XYZZ<F>::BYTES), v = u;
+  u.add(t);
+  v.add(t.neg());
+  u.store(X + lo * XYZZ<F>::BYTES);
+  v.store(X + hi * XYZZ<F>::BYTES);
+}
+template <class F>
+__global__ __launch_bounds__(128) void gfft_affine_kernel(const char* __restrict__ X, size_t n, char* __restrict__ xy,
+                                                          uint8_t* __restrict__ inf) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const XYZZ<F> p = XYZZ<F>::load(X + i * XYZZ<F>::BYTES);
+  p.to_affine().store(xy + i * Affine<F>::BYTES);
+  inf[i] = p.is_inf() ? 1 : 0;
+}
+// out_m = L_m - sum_{e in column m of C} coeff_e * G_{row_e}: the C matrix folded into the L query (groth16.hip).  One lane per
+// variable; kind[e]: 1 = coefficient +1, 2 = coefficient -1, 0 = coeff[e] (canonical, 8 words) by double-and-add.  One-time work.
+template <class F, int BITS>
+__global__ __launch_bounds__(128) void lfold_kernel(const char* __restrict__ L_xy, const uint8_t* __restrict__ L_inf, size_t n_vars,
+                                                    const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ rows,
+                                                    const uint8_t* __restrict__ kind, const uint32_t* __restrict__ coeff,
+                                                    const char* __restrict__ G_xy, const uint8_t* __restrict__ G_inf,
+                                                    char* __restrict__ out_xy, uint8_t* __restrict__ out_inf) {
+  const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_vars) return;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t e = col_ptr[m]; e < col_ptr[m + 1]; e++) {
+    const uint32_t k = rows[e];
+    if (G_inf[k]) continue;
+    Affine<F> g = Affine<F>::load(G_xy + (size_t)k * Affine<F>::BYTES);
+    if (kind[e] == 1) {
+      acc.madd(g);
+    } else if (kind[e] == 2) {
+      g.y = g.y.neg();
+      acc.madd(g);
+    } else {
+      uint32_t c[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) c[l] = coeff[(size_t)e * 8 + l];
+      XYZZ<F> t = XYZZ<F>::inf();
+      for (int bit = BITS; bit >= 0; bit--) {
+        t = t.dbl();
+        if ((c[bit >> 5] >> (bit & 31)) & 1) t.madd(g);
+      }
+      acc.add(t);
+    }
+  }
+  XYZZ<F> r = L_inf[m] ? XYZZ<F>::inf() : XYZZ<F>::from_affine(Affine<F>::load(L_xy + m * Affine<F>::BYTES));
+  r.add(acc.neg());
+  r.to_affine().store(out_xy + m * Affine<F>::BYTES);
+  out_inf[m] = r.is_inf() ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------- Groth16 assembly
 // (prover.rs:192-210 after the folding described in groth16.hip)
 namespace ZKP_CFG_SYM(cfg) {
@@ -888,6 +986,20 @@ void l_segsum_desc(hipStream_t s, const char* base, const SegDesc* descs, uint32
 void l_final_var(hipStream_t s, const char* R, const char* roots, int c, int W, char* out_xyzz, uint32_t* out_jac) {
   hipLaunchKernelGGL(final_var_kernel<F>, dim3(1), dim3(256), 256 * BB, s, R, roots, c, W, out_xyzz, out_jac);
 }
+void l_gfft(hipStream_t s, const char* xy, const uint8_t* inf, size_t n_in, const uint32_t* scal, const uint32_t* tw, uint32_t log_n,
+            char* X, char* out_xy, uint8_t* out_inf) {
+  const size_t N = (size_t)1 << log_n;
+  hipLaunchKernelGGL((gfft_scale_kernel<F, CFG_BITS>), dim3((N + 127) / 128), dim3(128), 0, s, xy, inf, n_in, scal, log_n, X);
+  for (uint32_t st = 1; st <= log_n; st++)
+    hipLaunchKernelGGL((gfft_stage_kernel<F, CFG_BITS>), dim3((N / 2 + 127) / 128), dim3(128), 0, s, X, tw, log_n, st);
+  hipLaunchKernelGGL(gfft_affine_kernel<F>, dim3((N + 127) / 128), dim3(128), 0, s, X, N, out_xy, out_inf);
+}
+void l_lfold(hipStream_t s, const char* L_xy, const uint8_t* L_inf, size_t n_vars, const uint32_t* col_ptr, const uint32_t* rows,
+             const uint8_t* kind, const uint32_t* coeff, const char* G_xy, const uint8_t* G_inf, char* out_xy, uint8_t* out_inf) {
+  if (n_vars)
+    hipLaunchKernelGGL((lfold_kernel<F, CFG_BITS>), dim3((n_vars + 127) / 128), dim3(128), 0, s, L_xy, L_inf, n_vars, col_ptr, rows,
+                       kind, coeff, G_xy, G_inf, out_xy, out_inf);
+}
 void l_fold_slots(hipStream_t s, const char* gathered, size_t rank_stride, int world, size_t slot, uint32_t mask,
                   char* res) {
   hipLaunchKernelGGL(fold_slots_kernel<F>, dim3(1), dim3(64), 0, s, gathered, rank_stride, world, slot, mask, res);
@@ -943,7 +1055,7 @@ const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
 #else
       nullptr, nullptr, l_assemble_g2,
 #endif
-      l_pair_top,
+      l_pair_top, l_gfft, l_lfold,
   };
   return &v;
 }

@@ -82,6 +82,14 @@ struct MsmVtbl {
   // the top of the pairwise pyramid in one launch: levels from the one with `count` (<= PAIR_TOP_MAX; 1024: 129.4, 2048: 130.1, 4096: 129.5 proofs/s) entries at `base` down to
   // the root, each level stored directly behind its predecessor
   void (*pair_top)(hipStream_t, char* base, uint32_t count);
+  // group-element transform of a base vector (msm_group.hip "group-element transform"; groth16.hip: the H query in evaluation form):
+  // out_j = sum_i tw^(ij) (scal_i * P_i), i, j < 2^log_n; scal / tw: canonical 8-word scalars (tw: 2^(log_n-1) powers);
+  // X: 2^log_n XYZZ points of scratch
+  void (*gfft)(hipStream_t, const char* xy, const uint8_t* inf, size_t n_in, const uint32_t* scal, const uint32_t* tw, uint32_t log_n,
+               char* X, char* out_xy, uint8_t* out_inf);
+  // out_m = L_m - sum over column m of a sparse matrix (CSC: col_ptr / rows / kind / coeff) of coeff * G_row, m < n_vars
+  void (*lfold)(hipStream_t, const char* L_xy, const uint8_t* L_inf, size_t n_vars, const uint32_t* col_ptr, const uint32_t* rows,
+                const uint8_t* kind, const uint32_t* coeff, const char* G_xy, const uint8_t* G_inf, char* out_xy, uint8_t* out_inf);
 };
 constexpr uint32_t PAIR_TOP_MAX = 2048;
 
