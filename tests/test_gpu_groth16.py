@@ -258,12 +258,15 @@ print("PROOFS", outs.tobytes().hex(), infs.tobytes().hex())
 def test_schedule_switches_do_not_change_the_proof():
     """Every scheduling shortcut of the prover — bucket chaining (H accumulates into L's buckets, one reduction for l' + h_acc),
     the shared level-1 pass, shared sorts, the staged scatter, the three-stream plan, window groups, the unsaturated NTT pass and its
-    full-size tables / fused chains — is an optimisation only: proofs are
+    full-size tables / fused chains, the evaluation-form key (transformed H query, C folded into the L query), the host-side
+    into_affine — is an optimisation only: proofs are
     byte-identical with each one switched off (own processes: the switches are read once per process)."""
     base = _proofs_in_subprocess(_SWITCH_CODE)
     for sw in ({"ZKP_CHAIN_LH": "0"}, {"ZKP_SHARE_L1": "0"}, {"ZKP_SHARE_B_SORT": "0", "ZKP_SHARE_AL_SORT": "0"},
                {"ZKP_SORT_STAGED": "0"}, {"ZKP_SINGLE_STREAM": "1"}, {"ZKP_LATENCY_PLAN": "0"}, {"ZKP_TABLE_K": "2"},
                {"ZKP_NTT_V2": "0"}, {"ZKP_NTT_FULL": "0"}, {"ZKP_NTT_FUSE": "0"},
+               # the key in coefficient form (no transformed H query, C not folded into L), H alone transformed, host / device into_affine
+               {"ZKP_H_LAGRANGE": "0"}, {"ZKP_C_FOLD": "0"}, {"ZKP_HOST_AFFINE": "0"},
                # every eighth accumulate task through the exact (redo) kernel: on top of chained buckets, and without chaining
                {"ZKP_DEBUG_FORCE_REDO": "1"}, {"ZKP_DEBUG_FORCE_REDO": "1", "ZKP_CHAIN_LH": "0"}):
         assert _proofs_in_subprocess(_SWITCH_CODE, **sw) == base, sw
