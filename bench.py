@@ -6,7 +6,8 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic input: one complete Groth16 proof
-(sparse A/B/C·z, 7 NTTs + pointwise = witness_map, five MSMs incl. the G2 one, assembly -> 3 affine points)
+(sparse A/B·z, 4 NTTs + pointwise on the evaluation-form key — the reference's witness_map is 7 NTTs; the last transform and the C
+chain live in the transformed H / L queries, same proof bytes —, five MSMs incl. the G2 one, assembly -> 3 affine points)
 with the proving key, the circuit matrices and the witness z already resident in HBM.  Multi-GPU: one process
 per GPU, every rank proves independent proofs with the same resident key (weak scaling, no data-path
 collective); `value` = proofs of all ranks / max-over-ranks time.
@@ -871,7 +872,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery integers)",
             "data": "synthetic (MiMC-chain R1CS, PRF witness, proving key generated from a fixed trapdoor)",
             "config": {"workload": f"Groth16 prove, MiMC-chain R1CS, {inst.num_constraints()} constraints "
-                                   f"(domain 2^{args.log_n}), {inst.num_aux} aux, {c.name}, G1 x4 + G2 x1 MSM + 7 NTT",
+                                   f"(domain 2^{args.log_n}), {inst.num_aux} aux, {c.name}, G1 x4 + G2 x1 MSM + 4 NTT (7 in the reference: evaluation-form key)",
                        "curve": c.name, "log_domain": args.log_n, "parallelism": f"independent proofs x{world}",
                        "table_plan": table_plan,
                        "pipelining": "none" if args.no_pipeline else f"{os.environ.get('ZKP_LANES', '8 (4 above 2^22)')} proofs in flight per GPU (zkp_groth16_prove_batch_dev), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}"},
