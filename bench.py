@@ -657,7 +657,8 @@ def main():
         return bench_sharded(args, ctx, c, inst, params, codec.fr_to_mont(inst.z, c).reshape(-1, 4), rank, world, local)
     t0 = time.time()
     pk = groth16.ProvingKey(ctx, params, inst)
-    log(f"key upload + window-table precompute: {time.time()-t0:.1f}s ; domain=2^{pk.domain_size.bit_length()-1}")
+    key_upload_s = round(time.time() - t0, 2)
+    log(f"key upload + window-table precompute + evaluation-form transforms: {key_upload_s:.1f}s ; domain=2^{pk.domain_size.bit_length()-1}")
     z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
     z_dev = ctx.to_device(z)                                    # inputs resident in HBM before the timed region
     rand_fr = make_rand_fr(c, 1234 + rank)
@@ -875,6 +876,10 @@ def main():
                                    f"(domain 2^{args.log_n}), {inst.num_aux} aux, {c.name}, G1 x4 + G2 x1 MSM + 4 NTT (7 in the reference: evaluation-form key)",
                        "curve": c.name, "log_domain": args.log_n, "parallelism": f"independent proofs x{world}",
                        "table_plan": table_plan,
+                       "key_upload_s": key_upload_s,
+                       "key_form": "evaluation form unless ZKP_H_LAGRANGE=0 / ZKP_C_FOLD=0: H query transformed and C folded into the L "
+                                   "query once at upload (outside the timed region, like the window tables); 4 instead of 7 transforms per "
+                                   "proof, same proof bytes for every assignment (DESIGN.md section 5)",
                        "pipelining": "none" if args.no_pipeline else f"{os.environ.get('ZKP_LANES', '8 (4 above 2^22)')} proofs in flight per GPU (zkp_groth16_prove_batch_dev), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "hbm_peak_measured": hbm_meas,
             "roofline_ntt": roofline_ntt, "roofline_scan": roofline_scan, "valu_roof": valu_roof,
