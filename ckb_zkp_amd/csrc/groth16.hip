@@ -273,7 +273,7 @@ static void lagrange_h(zkp_ctx* ctx, int curve, const uint64_t* h_query, const u
   uint32_t* dtw = d_tw.as<uint32_t>(tw.size());
   ZKP_HIP(hipMemcpyAsync(dscal, scal.data(), scal.size() * 4, hipMemcpyHostToDevice, st));
   ZKP_HIP(hipMemcpyAsync(dtw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice, st));
-  char* X = d_X.as<char>(N * v1->xyzz_bytes);
+  char* X = d_X.as<char>(N * v1->bucket_bytes);           // stage points in the bucket (unsaturated) layout
   char* oxy = d_oxy.as<char>(N * ab);
   uint8_t* oinf = d_oinf.as<uint8_t>(N);
   v1->gfft(st, xy, inf, h_used, dscal, dtw, (uint32_t)log_n, X, oxy, oinf);

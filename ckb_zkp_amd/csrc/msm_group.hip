@@ -640,25 +640,58 @@ __global__ __launch_bounds__(128) void fixed_base_kernel(const uint32_t* base, c
 // sum_j v_j H'_j = sum_i h_i H_i for h = coset_ifft(v) — the last transform of the witness map (r1cs_to_qap.rs:169) moves into the key.
 // A radix-2 decimation-in-time transform over group elements: butterflies (u, q) -> (u + t q, u - t q) with t a scalar; one-time
 // work per key (N log N / 2 scalar multiplications), plain double-and-add on the saturated formulas of ec_dev.hpp.
+// Points travel through the stages in the unsaturated layout (BkPoint, bucket_dev.hpp: 205 instead of ~330 VALU instructions per
+// product); scalar multiplications take two bits at a time against {q, 2q, 3q} (every lane of a wave adds in every step anyway, so
+// sparse digit forms do not help; a fixed window does): 128 x (2 doublings + 1 addition) instead of 255 x (1 + 1).
+#if ZKP_CFG_GROUP == 1
+template <class F>
+ZKP_DEV BkPoint<F> bk_select3(uint32_t d, const BkPoint<F>& a1, const BkPoint<F>& a2, const BkPoint<F>& a3) {
+  using U = typename BkPoint<F>::U;
+  BkPoint<F> r;
+#pragma unroll
+  for (int i = 0; i < U::L; i++) {
+    r.v.x.f.v[i] = d == 1 ? a1.v.x.f.v[i] : d == 2 ? a2.v.x.f.v[i] : a3.v.x.f.v[i];
+    r.v.y.f.v[i] = d == 1 ? a1.v.y.f.v[i] : d == 2 ? a2.v.y.f.v[i] : a3.v.y.f.v[i];
+    r.v.zz.f.v[i] = d == 1 ? a1.v.zz.f.v[i] : d == 2 ? a2.v.zz.f.v[i] : a3.v.zz.f.v[i];
+    r.v.zzz.f.v[i] = d == 1 ? a1.v.zzz.f.v[i] : d == 2 ? a2.v.zzz.f.v[i] : a3.v.zzz.f.v[i];
+  }
+  r.v.inf = d == 1 ? a1.v.inf : d == 2 ? a2.v.inf : a3.v.inf;
+  return r;
+}
+// k * q, k: canonical scalar of <= BITS + 1 bits
+template <class F, int BITS>
+ZKP_DEV BkPoint<F> bk_scalar_mul(const BkPoint<F>& q, const uint32_t* k) {
+  BkPoint<F> q2 = q.dbl(), q3 = q2;
+  q3.add(q);
+  BkPoint<F> acc = BkPoint<F>::inf();
+  for (int bit = BITS | 1; bit >= 1; bit -= 2) {
+    acc = acc.dbl().dbl();
+    const uint32_t d = (bit < 256 ? ((k[bit >> 5] >> (bit & 31)) & 1) << 1 : 0) | ((k[(bit - 1) >> 5] >> ((bit - 1) & 31)) & 1);
+    if (d) acc.add(bk_select3<F>(d, q, q2, q3));
+  }
+  return acc;
+}
+template <class F>
+ZKP_DEV BkPoint<F> bk_neg(const BkPoint<F>& p) {
+  BkPoint<F> r = p;
+  if (!p.v.inf) r.v.y = ub_neg<4>(p.v.y);
+  return r;
+}
 // X[bitrev(i)] = scal[i] * P_i   (scal: canonical 8-word scalars; P_i affine, identity beyond n_in)
 template <class F, int BITS>
 __global__ __launch_bounds__(128) void gfft_scale_kernel(const char* __restrict__ xy, const uint8_t* __restrict__ inf, size_t n_in,
                                                          const uint32_t* __restrict__ scal, uint32_t log_n, char* __restrict__ X) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >> log_n) return;
-  XYZZ<F> acc = XYZZ<F>::inf();
+  BkPoint<F> acc = BkPoint<F>::inf();
   if (i < n_in && !(inf && inf[i])) {
-    const Affine<F> p = Affine<F>::load(xy + i * Affine<F>::BYTES);
     uint32_t k[8];
 #pragma unroll
     for (int l = 0; l < 8; l++) k[l] = scal[i * 8 + l];
-    for (int bit = BITS; bit >= 0; bit--) {
-      acc = acc.dbl();
-      if ((k[bit >> 5] >> (bit & 31)) & 1) acc.madd(p);
-    }
+    acc = bk_scalar_mul<F, BITS>(BkPoint<F>::from_sat(XYZZ<F>::from_affine(Affine<F>::load(xy + i * Affine<F>::BYTES))), k);
   }
   const size_t r = log_n ? (size_t)(__brevll((unsigned long long)i) >> (64 - log_n)) : 0;
-  acc.store(X + r * XYZZ<F>::BYTES);
+  acc.store(X + r * BkPoint<F>::BYTES);
 }
 // stage s (1-based, block size m = 2^s): X[lo], X[hi] <- X[lo] + t X[hi], X[lo] - t X[hi], t = tw[j * N / m]
 template <class F, int BITS>
@@ -668,35 +701,33 @@ __global__ __launch_bounds__(128) void gfft_stage_kernel(char* __restrict__ X, c
   if (b >> (log_n - 1)) return;
   const size_t half = (size_t)1 << (s - 1), j = b & (half - 1), lo = ((b >> (s - 1)) << s) + j, hi = lo + half;
   const size_t e = j << (log_n - s);
-  const XYZZ<F> q = XYZZ<F>::load(X + hi * XYZZ<F>::BYTES);
-  XYZZ<F> t = q;
-  if (e != 0 && !q.is_inf()) {
+  BkPoint<F> t = BkPoint<F>::load(X + hi * BkPoint<F>::BYTES);
+  if (e != 0 && !t.is_inf()) {
     uint32_t k[8];
 #pragma unroll
     for (int l = 0; l < 8; l++) k[l] = tw[e * 8 + l];
-    t = XYZZ<F>::inf();
-    for (int bit = BITS; bit >= 0; bit--) {
-      t = t.dbl();
-      if ((k[bit >> 5] >> (bit & 31)) & 1) t.add(q);
-    }
+    t = bk_scalar_mul<F, BITS>(t, k);
   }
-  XYZZ<F> u = XYZZ<F>::load(X + lo * XYZZ<F>::BYTES), v = u;
+  BkPoint<F> u = BkPoint<F>::load(X + lo * BkPoint<F>::BYTES), v = u;
   u.add(t);
-  v.add(t.neg());
-  u.store(X + lo * XYZZ<F>::BYTES);
-  v.store(X + hi * XYZZ<F>::BYTES);
+  v.add(bk_neg<F>(t));
+  u.store(X + lo * BkPoint<F>::BYTES);
+  v.store(X + hi * BkPoint<F>::BYTES);
 }
 template <class F>
 __global__ __launch_bounds__(128) void gfft_affine_kernel(const char* __restrict__ X, size_t n, char* __restrict__ xy,
                                                           uint8_t* __restrict__ inf) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const XYZZ<F> p = XYZZ<F>::load(X + i * XYZZ<F>::BYTES);
+  const XYZZ<F> p = BkPoint<F>::load(X + i * BkPoint<F>::BYTES).to_sat();
   p.to_affine().store(xy + i * Affine<F>::BYTES);
   inf[i] = p.is_inf() ? 1 : 0;
 }
+#endif
+
 // out_m = L_m - sum_{e in column m of C} coeff_e * G_{row_e}: the C matrix folded into the L query (groth16.hip).  One lane per
 // variable; kind[e]: 1 = coefficient +1, 2 = coefficient -1, 0 = coeff[e] (canonical, 8 words) by double-and-add.  One-time work.
+#if ZKP_CFG_GROUP == 1
 template <class F, int BITS>
 __global__ __launch_bounds__(128) void lfold_kernel(const char* __restrict__ L_xy, const uint8_t* __restrict__ L_inf, size_t n_vars,
                                                     const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ rows,
@@ -732,6 +763,7 @@ __global__ __launch_bounds__(128) void lfold_kernel(const char* __restrict__ L_x
   r.to_affine().store(out_xy + m * Affine<F>::BYTES);
   out_inf[m] = r.is_inf() ? 1 : 0;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------- Groth16 assembly
 // (prover.rs:192-210 after the folding described in groth16.hip)
@@ -986,6 +1018,7 @@ void l_segsum_desc(hipStream_t s, const char* base, const SegDesc* descs, uint32
 void l_final_var(hipStream_t s, const char* R, const char* roots, int c, int W, char* out_xyzz, uint32_t* out_jac) {
   hipLaunchKernelGGL(final_var_kernel<F>, dim3(1), dim3(256), 256 * BB, s, R, roots, c, W, out_xyzz, out_jac);
 }
+#if ZKP_CFG_GROUP == 1
 void l_gfft(hipStream_t s, const char* xy, const uint8_t* inf, size_t n_in, const uint32_t* scal, const uint32_t* tw, uint32_t log_n,
             char* X, char* out_xy, uint8_t* out_inf) {
   const size_t N = (size_t)1 << log_n;
@@ -1000,6 +1033,7 @@ void l_lfold(hipStream_t s, const char* L_xy, const uint8_t* L_inf, size_t n_var
     hipLaunchKernelGGL((lfold_kernel<F, CFG_BITS>), dim3((n_vars + 127) / 128), dim3(128), 0, s, L_xy, L_inf, n_vars, col_ptr, rows,
                        kind, coeff, G_xy, G_inf, out_xy, out_inf);
 }
+#endif
 void l_fold_slots(hipStream_t s, const char* gathered, size_t rank_stride, int world, size_t slot, uint32_t mask,
                   char* res) {
   hipLaunchKernelGGL(fold_slots_kernel<F>, dim3(1), dim3(64), 0, s, gathered, rank_stride, world, slot, mask, res);
@@ -1055,7 +1089,12 @@ const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
 #else
       nullptr, nullptr, l_assemble_g2,
 #endif
-      l_pair_top, l_gfft, l_lfold,
+      l_pair_top,
+#if ZKP_CFG_GROUP == 1
+      l_gfft, l_lfold,
+#else
+      nullptr, nullptr,
+#endif
   };
   return &v;
 }
