@@ -2,6 +2,8 @@
 patterns, adversarial scalar classes — HIP through the C ABI against oracle/cpu (the C++ restatement of ark-ec's window-parallel
 Pippenger and ark-poly's radix-2 transforms), both as group elements / field elements, bit for bit.  Complements the hand-picked
 edge sets of test_gpu_msm.py / test_gpu_ntt.py; 480 MSM cases (+ 120 through the variable-base entry point) and 480 transforms, ≈ 25 s on the GPU box."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,7 @@ from oracle.pyref.curves import Group
 from tests.util import OC, jac_limbs_to_affine_oracle, to_abi_points
 
 pytestmark = pytest.mark.gpu
+SEED = int(os.environ.get("ZKP_FUZZ_SEED", "0"))        # 0 = the committed cases; any other value: a fresh set (soak runs)
 
 
 def _scalars(rng, c, n, kind):
@@ -37,7 +40,7 @@ def _scalars(rng, c, n, kind):
 @pytest.mark.parametrize("curve,group,cases", [("bn254", 1, 240), ("bn254", 2, 96), ("bls12_381", 1, 96), ("bls12_381", 2, 48)])
 def test_msm_fuzz_against_cpu_port(ctx, curve, group, cases):
     c = get_curve(curve)
-    rng = np.random.default_rng(0xF00D + 17 * group + c.cid)
+    rng = np.random.default_rng(0xF00D + 17 * group + c.cid + 1000003 * SEED)
     w = 2 * c.fq_limbs * group
     nmax = 20000
     # one pool of bases k_i * G built on the device (checked against the oracle elsewhere), with duplicates and a few P / -P pairs
@@ -77,7 +80,7 @@ def test_msm_fuzz_against_cpu_port(ctx, curve, group, cases):
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 def test_ntt_fuzz_against_cpu_port(ctx, curve):
     c = get_curve(curve)
-    rng = np.random.default_rng(0xBEEF + c.cid)
+    rng = np.random.default_rng(0xBEEF + c.cid + 1000003 * SEED)
     for case in range(120):
         k = int(rng.integers(0, 19))
         n = 1 << k
@@ -166,13 +169,13 @@ def test_groth16_fuzz_against_cpu_port(ctx, curve):
     from ckb_zkp_amd import groth16
     from ckb_zkp_amd.r1cs import ConstraintSystem, R1csInstance
     c = get_curve(curve)
-    rng = np.random.default_rng(0xC1C + c.cid)
+    rng = np.random.default_rng(0xC1C + c.cid + 1000003 * SEED)
     toxic = dict(alpha=0x1234567, beta=0x89ABCDE, gamma=0xF012345, delta=0x6789ABC, tau=0xDEF0123456789)
     shapes = [(1, 1), (0, 1), (2, 2), (1, 3), (3, 4), (0, 7), (1, 8), (2, 13), (1, 15), (1, 16), (4, 17), (1, 30), (0, 31), (2, 64),
               (1, 100), (3, 127), (0, 128), (1, 129), (2, 250), (1, 511), (1, 600)]
     for case, (ni, nc) in enumerate(shapes):
         cs = ConstraintSystem(c, True)
-        _RandomCircuit(curve, 1000 + case, ni, nc).generate_constraints(cs)
+        _RandomCircuit(curve, 1000 + case + 7919 * SEED, ni, nc).generate_constraints(cs)
         inst = R1csInstance.from_cs(cs)
         params = groth16.generate_parameters(ctx, c, inst, **toxic)
         pk = groth16.ProvingKey(ctx, params, inst)
