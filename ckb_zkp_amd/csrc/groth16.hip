@@ -127,6 +127,16 @@ __global__ __launch_bounds__(256) void qap_pointwise_ab_kernel(uint32_t* __restr
   (F::load(a + (size_t)i * 8) * F::load(b + (size_t)i * 8) * F::load(zinv)).store(a + (size_t)i * 8);
 }
 
+// out[i] = canonical(mult * base^i), 8 words each: the scalar tables of the key transforms (lagrange_h)
+template <class P>
+__global__ __launch_bounds__(256) void pow_canon_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ base,
+                                                        const uint32_t* __restrict__ mult, uint32_t count) {
+  using F = Fp<P>;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  (F::load(base).pow_u64(i) * F::load(mult)).from_mont().store(out + (size_t)i * 8);
+}
+
 // consts[0] = (g^N - 1)^-1
 template <class P>
 __global__ void qap_consts_kernel(uint32_t* consts, int log_n) {
@@ -243,23 +253,20 @@ static void lagrange_h(zkp_ctx* ctx, int curve, const uint64_t* h_query, const u
   HostField::E wi = ld(curve == ZKP_BN254 ? consts::Bn254Fr::ROOT_INV : consts::Bls381Fr::ROOT_INV);
   const HostField::E gi = ld(curve == ZKP_BN254 ? consts::Bn254Fr::GEN_INV : consts::Bls381Fr::GEN_INV);
   wi = F.pow2k(wi, adicity - log_n);                                   // w_N^-1
-  std::vector<uint32_t> scal(N * 8), tw(std::max<size_t>(N / 2, 1) * 8);
-  HostField::E acc = F.inverse(F.from_u64((uint64_t)N));               // g^-i / N
-  if (mode == 1) {                                                     // zinv / N, zinv = 1 / (g^N - 1)
+  // scal_i = g^-i / N (mode 1: zinv / N for every i), tw_e = w^-e: generated on the device (canonical words) from four Montgomery constants
+  HostField::E mult = F.inverse(F.from_u64((uint64_t)N));
+  HostField::E sbase = gi;
+  if (mode == 1) {                                                     // zinv = 1 / (g^N - 1)
     const HostField::E g = ld(curve == ZKP_BN254 ? consts::Bn254Fr::GEN : consts::Bls381Fr::GEN);
-    acc = F.mul(acc, F.inverse(F.sub(F.pow2k(g, log_n), F.one_())));
+    mult = F.mul(mult, F.inverse(F.sub(F.pow2k(g, log_n), F.one_())));
+    sbase = F.one_();
   }
-  for (size_t i = 0; i < N; i++) {
-    const HostField::E c = F.to_canonical(acc);
-    memcpy(&scal[i * 8], c.data(), 32);
-    if (mode == 0) acc = F.mul(acc, gi);
-  }
-  acc = F.one_();
-  for (size_t e = 0; e < N / 2; e++) {
-    const HostField::E c = F.to_canonical(acc);
-    memcpy(&tw[e * 8], c.data(), 32);
-    acc = F.mul(acc, wi);
-  }
+  const HostField::E one = F.one_();
+  uint32_t hconst[4 * 8];
+  memcpy(hconst, sbase.data(), 32);
+  memcpy(hconst + 8, mult.data(), 32);
+  memcpy(hconst + 16, wi.data(), 32);
+  memcpy(hconst + 24, one.data(), 32);
   hipStream_t st = ctx->cur->stream;
   DevBuf d_xy, d_inf, d_scal, d_tw, d_X, d_oxy, d_oinf;
   const size_t ab = v1->aff_bytes;
@@ -269,10 +276,18 @@ static void lagrange_h(zkp_ctx* ctx, int curve, const uint64_t* h_query, const u
   if (h_used) ZKP_HIP(hipMemcpyAsync(xy, h_query, h_used * ab, hipMemcpyHostToDevice, st));
   if (h_used && h_inf) ZKP_HIP(hipMemcpyAsync(inf, h_inf, h_used, hipMemcpyHostToDevice, st));
   else ZKP_HIP(hipMemsetAsync(inf, 0, std::max<size_t>(h_used, 1), st));
-  uint32_t* dscal = d_scal.as<uint32_t>(scal.size());
-  uint32_t* dtw = d_tw.as<uint32_t>(tw.size());
-  ZKP_HIP(hipMemcpyAsync(dscal, scal.data(), scal.size() * 4, hipMemcpyHostToDevice, st));
-  ZKP_HIP(hipMemcpyAsync(dtw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice, st));
+  const size_t ntw = std::max<size_t>(N / 2, 1);
+  uint32_t* dscal = d_scal.as<uint32_t>(N * 8 + 32);
+  uint32_t* dtw = d_tw.as<uint32_t>(ntw * 8);
+  uint32_t* dconst = dscal + N * 8;
+  ZKP_HIP(hipMemcpyAsync(dconst, hconst, sizeof hconst, hipMemcpyHostToDevice, st));
+  if (curve == ZKP_BN254) {
+    hipLaunchKernelGGL(pow_canon_kernel<Bn254Fr>, dim3((N + 255) / 256), dim3(256), 0, st, dscal, dconst, dconst + 8, (uint32_t)N);
+    hipLaunchKernelGGL(pow_canon_kernel<Bn254Fr>, dim3((ntw + 255) / 256), dim3(256), 0, st, dtw, dconst + 16, dconst + 24, (uint32_t)ntw);
+  } else {
+    hipLaunchKernelGGL(pow_canon_kernel<Bls381Fr>, dim3((N + 255) / 256), dim3(256), 0, st, dscal, dconst, dconst + 8, (uint32_t)N);
+    hipLaunchKernelGGL(pow_canon_kernel<Bls381Fr>, dim3((ntw + 255) / 256), dim3(256), 0, st, dtw, dconst + 16, dconst + 24, (uint32_t)ntw);
+  }
   char* X = d_X.as<char>(N * v1->bucket_bytes);           // stage points in the bucket (unsaturated) layout
   char* oxy = d_oxy.as<char>(N * ab);
   uint8_t* oinf = d_oinf.as<uint8_t>(N);
@@ -316,10 +331,7 @@ static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz,
       memcpy(c.data(), d->ct.coeff + (size_t)e * 4, 32);
       if (c == one) kind[pos] = 1;
       else if (c == minus_one) kind[pos] = 2;
-      else {
-        const HostField::E cc = F.to_canonical(c);
-        memcpy(&coeff[(size_t)pos * 8], cc.data(), 32);
-      }
+      else memcpy(&coeff[(size_t)pos * 8], c.data(), 32);          // Montgomery words; the kernel converts
     }
   // the L query index-aligned with the assignment (leading identities for the inputs)
   std::vector<uint64_t> lq(nz * 2 * fq, 0);

@@ -726,7 +726,7 @@ __global__ __launch_bounds__(128) void gfft_affine_kernel(const char* __restrict
 #endif
 
 // out_m = L_m - sum_{e in column m of C} coeff_e * G_{row_e}: the C matrix folded into the L query (groth16.hip).  One lane per
-// variable; kind[e]: 1 = coefficient +1, 2 = coefficient -1, 0 = coeff[e] (canonical, 8 words) by double-and-add.  One-time work.
+// variable; kind[e]: 1 = coefficient +1, 2 = coefficient -1, 0 = coeff[e] (Montgomery, 8 words) by double-and-add.  One-time work.
 #if ZKP_CFG_GROUP == 1
 template <class F, int BITS>
 __global__ __launch_bounds__(128) void lfold_kernel(const char* __restrict__ L_xy, const uint8_t* __restrict__ L_inf, size_t n_vars,
@@ -747,9 +747,10 @@ __global__ __launch_bounds__(128) void lfold_kernel(const char* __restrict__ L_x
       g.y = g.y.neg();
       acc.madd(g);
     } else {
+      const Fp<CfgFr> cm = Fp<CfgFr>::load(coeff + (size_t)e * 8).from_mont();       // coefficients arrive as the matrix holds them
       uint32_t c[8];
 #pragma unroll
-      for (int l = 0; l < 8; l++) c[l] = coeff[(size_t)e * 8 + l];
+      for (int l = 0; l < 8; l++) c[l] = cm.v[l];
       XYZZ<F> t = XYZZ<F>::inf();
       for (int bit = BITS; bit >= 0; bit--) {
         t = t.dbl();
