@@ -84,8 +84,8 @@ __global__ __launch_bounds__(PAIR_TOP_THREADS) void pair_top_kernel(char* __rest
       if (coop) {
         const uint32_t k = threadIdx.x >> 2;
         if (k < cnt / 2)
-          quad_add_mem<typename QuadCoop<F>::P>(in + (size_t)(2 * k) * BkPoint<F>::BYTES, in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES,
-                                           out + (size_t)k * BkPoint<F>::BYTES, threadIdx.x & 3);
+          quad_add_any<F>(in + (size_t)(2 * k) * BkPoint<F>::BYTES, in + (size_t)(2 * k + 1) * BkPoint<F>::BYTES,
+                          out + (size_t)k * BkPoint<F>::BYTES, threadIdx.x & 3);
       }
     }
     if (!coop)
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ ba
         coop = s <= 64;                                                         // 64 quads: four lanes per addition from here on
         if (coop && (int)(threadIdx.x >> 2) < s) {
           char* mine = smem + (threadIdx.x >> 2) * BkPoint<F>::BYTES;
-          quad_add_mem<typename QuadCoop<F>::P>(mine, smem + ((threadIdx.x >> 2) + s) * BkPoint<F>::BYTES, mine, threadIdx.x & 3);
+          quad_add_any<F>(mine, smem + ((threadIdx.x >> 2) + s) * BkPoint<F>::BYTES, mine, threadIdx.x & 3);
         }
       }
       if (!coop && (int)threadIdx.x < s) BkPoint<F>::add_mem(my, smem + (threadIdx.x + s) * BkPoint<F>::BYTES, my);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(128) void final_kernel(const char* __restrict__ O, 
   __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int t = threadIdx.x;
-  if constexpr (QuadCoop<F>::ON) {
+  if constexpr (QuadCoop<F>::ON && QuadCoop<F>::GROUP == 1) {
     // G1 (round 4): 128 lanes = 32 quads, quad q owns point q (levels 0..L-1, the root at L): q cooperative doublings, then a tree
     // of cooperative additions — 18 x 3 + 5 x 5.5 product latencies instead of 18 x 9.75 + 6 x 14.5
     const int q = t >> 2, role = t & 3;
@@ -260,7 +260,15 @@ __global__ __launch_bounds__(128) void final_kernel(const char* __restrict__ O, 
       for (int k = 0; k < t; k++) BkPoint<F>::dbl_mem(my, my);
     __syncthreads();
     for (int s = 32; s > 0; s >>= 1) {
-      if (t < s) BkPoint<F>::add_mem(my, smem + (t + s) * BkPoint<F>::BYTES, my);
+      bool coop = false;
+      if constexpr (QuadCoop<F>::ON) {
+        coop = s <= 16;                                              // 16 quads
+        if (coop && (t >> 2) < s) {
+          char* mine = smem + (t >> 2) * BkPoint<F>::BYTES;
+          quad_add_any<F>(mine, smem + ((t >> 2) + s) * BkPoint<F>::BYTES, mine, t & 3);
+        }
+      }
+      if (!coop && t < s) BkPoint<F>::add_mem(my, smem + (t + s) * BkPoint<F>::BYTES, my);
       __syncthreads();
     }
     if (t == 0) {
@@ -1004,7 +1012,7 @@ void l_segsum(hipStream_t s, const char* base, const SegPlan* plan, char* partia
   hipLaunchKernelGGL(segsum_kernel<F>, dim3(blocks), dim3(256), 256 * BB, s, base, *plan, partial);
 }
 void l_final(hipStream_t s, const char* O, int L, const char* root, char* out_xyzz, uint32_t* out_jac) {
-  constexpr int threads = QuadCoop<F>::ON ? 128 : 64;            // G1: 32 quads (coop_dev.hpp)
+  constexpr int threads = (QuadCoop<F>::ON && QuadCoop<F>::GROUP == 1) ? 128 : 64;            // G1: 32 quads (coop_dev.hpp)
   hipLaunchKernelGGL(final_kernel<F>, dim3(1), dim3(threads), 64 * BB, s, O, L, root, out_xyzz, out_jac);
 }
 void l_identity(hipStream_t s, char* out_xyzz, uint32_t* out_jac) {
