@@ -133,6 +133,7 @@ SIGNATURES = {
     "zkp_g1_subgroup_check": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "zkp_g2_subgroup_check": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "zkp_g2_into_affine": (C.c_int32, [vp, C.c_int, vp, vp, vp]),
+    "zkp_groth16_points_into_affine": (C.c_int32, [C.c_int, vp, vp, vp, vp, vp]),
     "zkp_fixed_base_mul_g1": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, vp, vp]),
     "zkp_fixed_base_mul_g2": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, vp, vp]),
     "zkp_groth16_pk_upload": (C.c_int32, [vp, C.POINTER(Groth16PkDesc), C.POINTER(vp)]),

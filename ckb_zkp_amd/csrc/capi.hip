@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "ctx.hpp"
+#include "host_field.hpp"
 #include "internal.hpp"
 
 using namespace zkp;
@@ -428,6 +429,15 @@ int32_t zkp_g1_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz,
 int32_t zkp_g2_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz, uint64_t* xy, uint8_t* inf) {
   if (!xyz || !xy || !inf) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { point_into_affine(ctx, curve, 2, xyz, xy, inf); });
+}
+int32_t zkp_groth16_points_into_affine(zkp_curve_t curve, const uint64_t* a_xyzz, const uint64_t* b_xyzz, const uint64_t* c_xyzz,
+                                       uint64_t* proof_out, uint8_t* inf_out) {
+  if (!a_xyzz || !b_xyzz || !c_xyzz || !proof_out || !inf_out) return ZKP_ERR_BAD_ARG;
+  if (curve != ZKP_BN254 && curve != ZKP_BLS12_381) return ZKP_ERR_UNSUPPORTED_CURVE;
+  const zkp::hostf::HostField Fq = zkp::hostf::fq_field(curve);
+  zkp::hostf::groth16_points_into_affine(Fq, reinterpret_cast<const uint32_t*>(a_xyzz), reinterpret_cast<const uint32_t*>(b_xyzz),
+                                         reinterpret_cast<const uint32_t*>(c_xyzz), reinterpret_cast<uint32_t*>(proof_out), inf_out);
+  return ZKP_OK;
 }
 static int32_t decompress_any(zkp_ctx* ctx, zkp_curve_t curve, int group, const uint8_t* bytes, size_t n, uint64_t* xy,
                               uint8_t* inf, size_t* bad) {

@@ -45,7 +45,7 @@ typedef struct zkp_ctx zkp_ctx; /* opaque: device, stream, twiddle tables, scrat
 
 const char* zkp_status_string(int32_t status);
 /* "zkp_accel <major.minor> (gfx950)".  0.4 (round 4): ZKP_ERR_INVALID_POINT for malformed / out-of-subgroup points (0.2 used
- * ZKP_ERR_BAD_ARG), zkp_groth16_multi_info, zkp_bench_hbm_copy; since 0.3 a bucket-chained key returns slot L of
+ * ZKP_ERR_BAD_ARG), zkp_groth16_multi_info, zkp_bench_hbm_copy, zkp_groth16_points_into_affine; since 0.3 a bucket-chained key returns slot L of
  * zkp_groth16_prove_partials_dev as the identity and slot H as h + l (their sum is what prover.rs:189-196 consumes). */
 const char* zkp_version(void);
 
@@ -169,6 +169,13 @@ int32_t zkp_g1_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_
                            uint8_t* inf_out);
 int32_t zkp_g2_into_affine(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xyz_host, uint64_t* xy_out,
                            uint8_t* inf_out);
+/* HOST ONLY (no device, ctx may be NULL-free: there is none): the into_affine() of the three proof points (prover.rs:205-209) as
+ * zkp_groth16_prove* runs it since ABI 0.4 — a, c: G1 XYZZ (x = X / ZZ, y = Y / ZZZ; ZZ == 0: the identity; 4 coordinates of
+ * L u64 limbs, Montgomery), b: G2 XYZZ (8 coordinates, (c0, c1) pairs) -> proof_out = A | B | C affine Montgomery words exactly as
+ * zkp_groth16_prove writes them (ark's (0, 0) for the identity), inf_out[3].  One field inversion for all three points. */
+int32_t zkp_groth16_points_into_affine(zkp_curve_t curve, const uint64_t* a_xyzz, const uint64_t* b_xyzz, const uint64_t* c_xyzz,
+                                       uint64_t* proof_out, uint8_t* inf_out);
+
 /* ark-serialize 0.2 COMPRESSED short-Weierstrass points <-> the affine Montgomery arrays of zkp_groth16_pk_desc /
  * zkp_bases_upload_*: what `Parameters::serialize` writes into a .pk file (cli/src/setup.rs:41-45) and `Proof::serialize` into
  * a proof (cli/src/zkp_prove.rs:45-49).  A point is its canonical little-endian x (G2: c0 then c1; 32 / 64 bytes on BN254,

@@ -121,3 +121,61 @@ def test_marlin_array_indexer_matches_constraint_by_constraint_synthesis():
             got = [[(vals[k], int(col[k])) for k in range(ptr[i], ptr[i + 1])] for i in range(n)]
             assert got == want
             assert rows.tolist() == [i for i in range(n) for _ in range(ptr[i + 1] - ptr[i])]
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_host_into_affine_of_the_proof_points_matches_the_oracle(curve):
+    """zkp_groth16_points_into_affine (csrc/host_field.hpp; what zkp_groth16_prove* runs on the host since ABI 0.4): A, C in G1 and B in
+    G2 arrive as XYZZ with random denominators (x = X / ZZ, y = Y / ZZZ, ZZ = Z^2, ZZZ = Z^3) and must leave as ark's affine
+    Montgomery words; the identity (ZZ = 0) as (0, 0) + flag, alone and mixed with ordinary points — one inversion serves all three."""
+    import ctypes as C
+
+    from ckb_zkp_amd import _lib
+    from oracle.pyref.curves import Group
+    lib = _lib.load()
+    c = get_curve(curve)
+    G1, G2 = Group(OC[curve], 1), Group(OC[curve], 2)
+    q, f = c.q, c.fq_limbs
+    R = 1 << (64 * f)
+    rnd = random.Random(0xAFF1 + c.cid)
+
+    def mont(v):
+        return codec.ints_to_limbs([v * R % q], f).reshape(-1)
+
+    def xyzz_g1(pt):
+        if pt is None:
+            return np.concatenate([mont(rnd.randrange(q)), mont(rnd.randrange(q)), mont(0), mont(0)])
+        z = rnd.randrange(1, q)
+        zz, zzz = z * z % q, z * z * z % q
+        return np.concatenate([mont(pt[0] * zz % q), mont(pt[1] * zzz % q), mont(zz), mont(zzz)])
+
+    def fq2_mul(a, b):
+        return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+
+    def xyzz_g2(pt):
+        if pt is None:
+            z0 = (0, 0)
+            return np.concatenate([mont(rnd.randrange(q)), mont(1), mont(2), mont(3), mont(0), mont(0), mont(0), mont(0)])
+        z = (rnd.randrange(q), rnd.randrange(1, q))
+        zz = fq2_mul(z, z)
+        zzz = fq2_mul(zz, z)
+        X, Y = fq2_mul(pt[0], zz), fq2_mul(pt[1], zzz)
+        return np.concatenate([mont(v) for v in (X[0], X[1], Y[0], Y[1], zz[0], zz[1], zzz[0], zzz[1])])
+
+    pa, pc = G1.mul(G1.gen, rnd.randrange(1, c.r)), G1.mul(G1.gen, rnd.randrange(1, c.r))
+    pb = G2.mul(G2.gen, rnd.randrange(1, c.r))
+    for a, b, cc in ((pa, pb, pc), (None, pb, pc), (pa, None, pc), (pa, pb, None), (None, None, None), (pa, pb, pa)):
+        ax, bx, cx = (np.ascontiguousarray(v, dtype=np.uint64) for v in (xyzz_g1(a), xyzz_g2(b), xyzz_g1(cc)))
+        out = np.full(8 * f, 0xDEADBEEF, dtype=np.uint64)
+        inf = np.full(3, 9, dtype=np.uint8)
+        p = lambda v: v.ctypes.data_as(C.c_void_p)
+        assert lib.zkp_groth16_points_into_affine(c.cid, p(ax), p(bx), p(cx), p(out), p(inf)) == 0
+        assert inf.tolist() == [int(a is None), int(b is None), int(cc is None)]
+        assert codec.g1_from_mont(out[:2 * f], [inf[0]], c)[0] == a
+        assert codec.g2_from_mont(out[2 * f:6 * f], [inf[1]], c)[0] == b
+        assert codec.g1_from_mont(out[6 * f:], [inf[2]], c)[0] == cc
+        if a is None:
+            assert not out[:2 * f].any()
+        if b is None:
+            assert not out[2 * f:6 * f].any()
+    assert lib.zkp_groth16_points_into_affine(c.cid, None, None, None, None, None) != 0
