@@ -235,7 +235,7 @@ static thread_local struct LagrangeCache {
     std::vector<uint64_t>().swap(xy);
     std::vector<uint8_t>().swap(inf);
   }
-} lagrange_cache;
+} lagrange_cache, lagrange_cache_g;                       // the transformed H query | the bases of the C part (mode 1)
 // mode 1: G_k = (zinv / N) sum_i w^-ik H_i instead (the inverse transform of H itself, scaled by zinv = 1 / Z(g)): the bases of
 // the C part of h, see fold_c_into_l below.
 static void lagrange_h(zkp_ctx* ctx, int curve, const uint64_t* h_query, const uint8_t* h_inf, size_t h_used, int log_n,
@@ -476,11 +476,19 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
     pk->hH = bases_upload(ctx, d->curve, 1, d->h_query ? d->h_query + pk->q_lo[3] * 2 * fq : nullptr,
                           d->h_inf ? d->h_inf + pk->q_lo[3] : nullptr, world > 0 ? pk->q_n[3] : (size_t)d->h_len, 0, 0, lgk);
     static const bool cfold_on = !(getenv("ZKP_C_FOLD") && atoi(getenv("ZKP_C_FOLD")) == 0);
-    if (pk->h_lagrange && cfold_on && world == 0 && d->l_query) {
-      std::vector<uint64_t> gxy, lxy;
-      std::vector<uint8_t> ginf, linf;
-      lagrange_h(ctx, d->curve, d->h_query, d->h_inf, h_used, pk->log_n, &gxy, &ginf, 1);
-      fold_c_into_l(ctx, d, pk->nz, gxy, ginf, &lxy, &linf);
+    if (pk->h_lagrange && cfold_on && d->l_query) {
+      std::vector<uint64_t> lxy;
+      std::vector<uint8_t> linf;
+      LagrangeCache& gc = lagrange_cache_g;
+      if (!(lagrange_keep_cache && gc.q == d->h_query && gc.used == h_used && gc.log_n == pk->log_n && gc.curve == d->curve)) {
+        lagrange_h(ctx, d->curve, d->h_query, d->h_inf, h_used, pk->log_n, &gc.xy, &gc.inf, 1);
+        gc.q = d->h_query;
+        gc.used = h_used;
+        gc.log_n = pk->log_n;
+        gc.curve = d->curve;
+      }
+      fold_c_into_l(ctx, d, pk->nz, gc.xy, gc.inf, &lxy, &linf);          // the whole L'; upload_ext keeps this rank's slice
+      if (!lagrange_keep_cache) gc.clear();
       pk->hL = upload_ext(ctx, d->curve, 1, lxy.data(), linf.data(), pk->nz, 2 * fq, tL, pk->q_lo[4], pk->q_n[4], 0, &fL, 0, 0, lgk);
       pk->c_folded = true;
     } else
@@ -1243,6 +1251,10 @@ uint32_t* witness_tail(zkp_ctx* ctx, zkp_groth16_pk* pk) {
   uint32_t* b = a + pk->N * 8;
   uint32_t* c = b + pk->N * 8;
   if (pk->h_lagrange) {                                      // evaluation-form key: the H MSM takes the pointwise values
+    if (pk->c_folded)
+      hipLaunchKernelGGL(qap_pointwise_ab_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, ctx->cur->stream, a, b,
+                         pk->consts.as<uint32_t>(64), N);
+    else
     hipLaunchKernelGGL(qap_pointwise_kernel<P>, dim3((N + 255) / 256), dim3(256), 0, ctx->cur->stream, a, b, c,
                        pk->consts.as<uint32_t>(64), N);
     ZKP_HIP(hipGetLastError());
@@ -1315,7 +1327,7 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
     ZKP_HIP(hipEventRecord(ctx->cur->ev_fork, st));
     for (int w = 1; w < zkp_ctx::N_WS; w++) ZKP_HIP(hipStreamWaitEvent(ctx->cur->ws[w].stream, ctx->cur->ev_fork, 0));
     if (!split) h[k] = witness_map_dev<FrP>(ctx, pk, S[k], !pk->h_lagrange);
-    else if (k < 3) {
+    else if (k < (pk->c_folded ? 2 : 3)) {                           // C folded into the L query: no c chain
       witness_chain<FrP>(ctx, pk, S[k], k);
       ZKP_HIP(hipEventRecord(M->ev_chain[k], st));
     }
@@ -1339,7 +1351,8 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
     ZKP_HIP(hipSetDevice(c0->device));
     hipStream_t st0 = c0->cur->stream;
     uint32_t* abc0 = p0->lane[0].abc.as<uint32_t>(3 * p0->N * 8);
-    for (int k = 1; k < 3; k++) {
+    const int nch = p0->c_folded ? 2 : 3;
+    for (int k = 1; k < nch; k++) {
       zkp_groth16_pk* pk = M->pk[k];
       const uint32_t* src = pk->lane[0].abc.as<uint32_t>(3 * pk->N * 8) + (size_t)k * pk->N * 8;
       ZKP_HIP(hipStreamWaitEvent(st0, M->ev_chain[k], 0));
@@ -1354,7 +1367,7 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
       hipStream_t st = ctx->cur->stream;
       h[k] = pk->lane[0].abc.as<uint32_t>(3 * pk->N * 8);        // region a of this device (its own chain, if any, is consumed)
       ZKP_HIP(hipStreamWaitEvent(st, M->ev_h, 0));
-      if (k < 3) ZKP_HIP(hipStreamWaitEvent(st, M->ev_chain[k], 0));
+      if (k < nch) ZKP_HIP(hipStreamWaitEvent(st, M->ev_chain[k], 0));
       copy_between(h[k] + pk->q_lo[3] * 8, ctx->device, h[0] + pk->q_lo[3] * 8, c0->device, pk->q_n[3] * 32, st);
       ZKP_HIP(hipEventRecord(M->ev_h_read[k], st));
     }
@@ -1422,6 +1435,7 @@ zkp_groth16_pk_multi* groth16_pk_upload_multi(zkp_ctx* root, const zkp_groth16_p
     ~KeepLagrange() {
       lagrange_keep_cache = false;
       lagrange_cache.clear();
+      lagrange_cache_g.clear();
     }
   } keep_lagrange;
   try {
