@@ -240,7 +240,7 @@ typedef struct {
 typedef struct zkp_groth16_pk zkp_groth16_pk; /* opaque device-resident proving key */
 
 /* Uploads `Parameters<E>` + the circuit matrices once; every zkp_groth16_prove* call then runs on the resident key.  Besides the
- * window tables the upload derives (round 4, one-time, on the device: + 1.6 s at 2^20, linear in N log N):
+ * window tables the upload derives (round 4, one-time, on the device: + 0.65 s at 2^20, linear in N log N; sharded keys likewise):
  *   - the h_query in EVALUATION form over the coset of r1cs_to_qap.rs:164-169, so that the H MSM of prover.rs:186-187 takes the
  *     pointwise values (a b - c) / Z(g) and the closing coset_ifft is not run;
  *   - the l_query with the C matrix folded in (L'_m = L_m - sum_k C_km G_k), so that neither C z nor the ifft / coset_fft of c

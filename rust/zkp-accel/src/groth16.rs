@@ -111,7 +111,7 @@ where
 /// Since ABI 0.4 the upload also puts the key into *evaluation form* on the device (h_query transformed over the coset of
 /// `r1cs_to_qap.rs:164-169`, the C matrix folded into l_query): a proof then runs 4 of the 7 transforms of `witness_map`
 /// and no `C z`, and returns the same `Proof` for every assignment.  The borrowed `Parameters` are not modified; the
-/// upload takes ~1 s longer per 2^20 constraints.  `ZKP_H_LAGRANGE=0` / `ZKP_C_FOLD=0` in the environment keep the key as given.
+/// upload takes ~0.7 s longer per 2^20 constraints.  `ZKP_H_LAGRANGE=0` / `ZKP_C_FOLD=0` in the environment keep the key as given.
 pub struct DeviceProvingKey<'c, G1: AccelGroup, G2: AccelGroup>
 where
     G1::BaseField: AbiField,
