@@ -19,6 +19,9 @@
 #include <atomic>
 #include <chrono>
 #include <functional>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -472,6 +475,8 @@ static void ntt_entry(uint64_t* data, int log_n, int op, int threads) {
   }
 }
 
+#include "marlin_oracle.inc"
+
 extern "C" {
 
 int oracle_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
@@ -536,6 +541,56 @@ int oracle_fixed_base_mul(int curve, int group, const uint64_t* base_xy, const u
   else if (curve == ZKP_BLS12_381 && group == 2) run(Fp2<Bls381FqP>{});
   else return -1;
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ Marlin (marlin_oracle.inc)
+void* oracle_marlin_new(const oracle_marlin_desc* d, int threads) {
+  try {
+    auto* h = new MarlinHandle{d->curve};
+    if (d->curve == ZKP_BN254) h->bn = new MarlinOracle<Bn254FrP, Bn254FqP>(d, threads);
+    else if (d->curve == ZKP_BLS12_381) h->bls = new MarlinOracle<Bls381FrP, Bls381FqP>(d, threads);
+    else { delete h; return nullptr; }
+    return h;
+  } catch (const std::exception& e) { fprintf(stderr, "oracle marlin: %s\n", e.what()); return nullptr; }
+}
+void oracle_marlin_free(void* hv) { delete (MarlinHandle*)hv; }
+// out: |X|, |H|, |K|, |B|, max_degree, num_non_zeros, n (square dimension), padding variables
+int oracle_marlin_info(void* hv, uint64_t* out) {
+  auto* h = (MarlinHandle*)hv;
+  MARLIN_DISPATCH(h, (out[0] = o->dx->n, out[1] = o->dh->n, out[2] = o->dk->n, out[3] = o->db->n, out[4] = o->max_degree,
+                      out[5] = o->nnz, out[6] = o->n, out[7] = o->pad_aux));
+  return 0;
+}
+int oracle_marlin_set_options(void* hv, int threads, int concurrent_commits) {
+  auto* h = (MarlinHandle*)hv;
+  MARLIN_DISPATCH(h, (o->threads = threads > 0 ? threads : 1, o->concurrent_commits = concurrent_commits != 0));
+  return 0;
+}
+// committer key: powers_of_g / powers_of_gamma_g, affine Montgomery (an input, as `ipk.committer_key` is to create_random_proof)
+int oracle_marlin_set_srs(void* hv, const uint64_t* g_xy, const uint8_t* g_inf, size_t ng, const uint64_t* gg_xy,
+                          const uint8_t* gg_inf, size_t ngg) {
+  auto* h = (MarlinHandle*)hv;
+  MARLIN_DISPATCH(h, o->set_srs(g_xy, g_inf, ng, gg_xy, gg_inf, ngg));
+  return 0;
+}
+int oracle_marlin_index_commit(void* hv, uint64_t* xy, uint8_t* inf) { auto* h = (MarlinHandle*)hv; MARLIN_DISPATCH(h, o->index_commit(xy, inf)); return 0; }
+int oracle_marlin_round1(void* hv, const uint64_t* x, const uint64_t* w, size_t nw, const oracle_marlin_rand* R, uint64_t* xy, uint8_t* inf) {
+  auto* h = (MarlinHandle*)hv; MARLIN_DISPATCH(h, o->round1(x, w, nw, R, xy, inf)); return 0;
+}
+int oracle_marlin_round2(void* hv, const uint64_t* ch, uint64_t* xy, uint8_t* inf) { auto* h = (MarlinHandle*)hv; MARLIN_DISPATCH(h, o->round2(ch, xy, inf)); return 0; }
+int oracle_marlin_round3(void* hv, const uint64_t* beta, uint64_t* xy, uint8_t* inf) { auto* h = (MarlinHandle*)hv; MARLIN_DISPATCH(h, o->round3(beta, xy, inf)); return 0; }
+int oracle_marlin_evaluate(void* hv, const uint64_t* gamma, uint64_t* out) { auto* h = (MarlinHandle*)hv; MARLIN_DISPATCH(h, o->evaluate_all(gamma, out)); return 0; }
+// -> number of opening proofs (points in increasing into_repr order), < 0 on error
+int oracle_marlin_open(void* hv, const uint64_t* xi, uint64_t* w_xy, uint8_t* w_inf, uint64_t* rand_v, uint8_t* has_rand) {
+  auto* h = (MarlinHandle*)hv; int nproofs = 0; MARLIN_DISPATCH(h, nproofs = o->open_all(xi, w_xy, w_inf, rand_v, has_rand)); return nproofs;
+}
+// seconds: round-1 polynomials, commits, round-2 polynomials, commits, round-3 polynomials, commits, evaluations, openings
+int oracle_marlin_phase_seconds(void* hv, double* out) { auto* h = (MarlinHandle*)hv; MARLIN_DISPATCH(h, memcpy(out, o->phase_s, sizeof(o->phase_s))); return 0; }
+// polynomial by id (0..8: w z_a z_b mask t g_1 h_1 g_2 h_2; 9..20: a/b/c x row col val row_col): length, and the coefficients when out != NULL
+long oracle_marlin_poly(void* hv, int id, uint64_t* out) {
+  auto* h = (MarlinHandle*)hv; long len = -1;
+  MARLIN_DISPATCH(h, { auto* p = o->poly_by_id(id); if (p) { len = (long)p->size(); if (out) memcpy(out, p->data(), 32 * p->size()); } });
+  return len;
 }
 
 }  // extern "C"
