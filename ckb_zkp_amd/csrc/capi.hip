@@ -15,6 +15,7 @@ namespace {
 template <class Fn>
 int32_t guarded(zkp_ctx* ctx, Fn&& fn) {
   if (!ctx) return ZKP_ERR_BAD_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);          // one call at a time per context (ctx.hpp)
   try {
     ZKP_HIP(hipSetDevice(ctx->device));
     fn();
@@ -51,7 +52,7 @@ const char* zkp_status_string(int32_t s) {
 }
 
 // 0.2: ZKP_ERR_INVALID_POINT; partials slot 4 (L) = identity, slot 3 (H) = h + l (bucket chaining)
-const char* zkp_version(void) { return "zkp_accel 0.4 (gfx950)"; }
+const char* zkp_version(void) { return "zkp_accel 0.5 (gfx950)"; }
 
 int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
   if (!out) return ZKP_ERR_BAD_ARG;

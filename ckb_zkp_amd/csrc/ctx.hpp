@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -126,6 +127,10 @@ struct zkp_lane {
 
 struct zkp_ctx {
   int device = 0;
+  // Every C-ABI entry point that takes this context holds this lock for the whole call (capi.hip guarded()): two host threads entering
+  // ONE context are serialised instead of interleaving its lanes / scratch (since ABI 0.5; the documented contract stays "one ctx per
+  // prover thread" — that is what runs concurrently).  Recursive: internal helpers may re-enter through a public entry point.
+  std::recursive_mutex mu;
   static constexpr int N_LANES = 8;        // allocated; zkp_groth16_prove_batch_dev uses 8 (domains <= 2^22) or 4 of them unless ZKP_LANES says otherwise
   static constexpr int N_WS = zkp_lane::N_WS;
   zkp_lane lanes[N_LANES];

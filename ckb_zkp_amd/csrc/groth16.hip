@@ -603,6 +603,7 @@ void groth16_pk_info(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t info[8]) {
   info[4] = a[3];
   info[5] = b[0];
   info[6] = (pk->share_b_sort ? 1 : 0) | (pk->share_al_sort ? 2 : 0) | (pk->share_l1 ? 4 : 0);
+  info[7] = (pk->h_lagrange ? 1 : 0) | (pk->c_folded ? 2 : 0) | (pk->chain_lh ? 4 : 0);       // key form (slots L / H)
 }
 
 // z_dev: nz Fr (device).  Leaves h (N Fr, Montgomery) in pk->abc[0..N)
@@ -1292,9 +1293,11 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
   const auto t_call = std::chrono::steady_clock::now();
   // Exchange: RCCL all-gather (the exchange BASELINE.json names) whenever the devices are distinct and librccl loads; peer copies
   // otherwise, said once on stderr.  ZKP_MULTI_EXCHANGE=peer / rccl forces one.
-  static const std::string want = getenv("ZKP_MULTI_EXCHANGE") ? getenv("ZKP_MULTI_EXCHANGE") : "auto";
+  // ZKP_MULTI_EXCHANGE=rccl also takes the RCCL branch with ONE rank (a one-rank ncclCommInitAll + ncclAllGather is legal): the
+  // hand-declared prototypes below get executed on a one-GPU box (tests/test_gpu_multi.py) before any 8-GPU node sees them.
+  const std::string want = getenv("ZKP_MULTI_EXCHANGE") ? getenv("ZKP_MULTI_EXCHANGE") : "auto";    // read per call
   bool use_rccl = false;
-  if (n > 1 && want != "peer") {
+  if ((n > 1 && want != "peer") || (n == 1 && want == "rccl")) {
     use_rccl = rccl().ready(root->devs);
     static bool told = false;
     if (!use_rccl && !told) {

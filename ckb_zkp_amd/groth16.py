@@ -233,7 +233,8 @@ class ProvingKey:
         _lib.check(self.ctx.lib.zkp_groth16_pk_info(self.ctx.h, self.h, info), "zkp_groth16_pk_info")
         return {"window_group": int(info[0]), "table_bytes": int(info[1]), "window_bits": int(info[2]), "windows": int(info[3]),
                 "table_copies": int(info[4]), "window_bits_b": int(info[5]), "b1_reuses_b2_sort": bool(info[6] & 1),
-                "l_reuses_a_sort": bool(info[6] & 2), "shared_level1_pass": bool(info[6] & 4)}
+                "l_reuses_a_sort": bool(info[6] & 2), "shared_level1_pass": bool(info[6] & 4),
+                "h_evaluation_form": bool(info[7] & 1), "c_folded_into_l": bool(info[7] & 2), "l_h_bucket_chained": bool(info[7] & 4)}
 
     def free(self):
         if self.h:

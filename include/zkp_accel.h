@@ -13,7 +13,9 @@
  *   - projective results: ark Jacobian (X, Y, Z), identity = (0, 1, 0) — compare after `into_affine()`;
  *   - `*_dev` variants take DEVICE pointers (hipMalloc / torch tensors) and run on the ctx stream;
  *     host variants copy in/out and synchronise;
- *   - one in-flight call per ctx; create one ctx per prover thread / per GPU (one process per GPU).
+ *   - one in-flight call per ctx; create one ctx per prover thread / per GPU (one process per GPU): contexts on one device run
+ *     concurrently from different host threads (the reference may prove from several rayon threads).  Since 0.5 every entry point
+ *     holds a per-context lock for the whole call, so two threads entering the SAME ctx are serialised, never interleaved.
  */
 #ifndef ZKP_ACCEL_H
 #define ZKP_ACCEL_H
@@ -44,7 +46,9 @@ typedef enum { ZKP_NTT_FFT = 0, ZKP_NTT_IFFT = 1, ZKP_NTT_COSET_FFT = 2, ZKP_NTT
 typedef struct zkp_ctx zkp_ctx; /* opaque: device, stream, twiddle tables, scratch, resident bases */
 
 const char* zkp_status_string(int32_t status);
-/* "zkp_accel <major.minor> (gfx950)".  0.4 (round 4): ZKP_ERR_INVALID_POINT for malformed / out-of-subgroup points (0.2 used
+/* "zkp_accel <major.minor> (gfx950)".  0.5 (round 5): per-context lock (see Conventions); ZKP_MULTI_EXCHANGE=rccl also takes the RCCL
+ * exchange with one rank; slots L / H of zkp_groth16_prove_partials_dev are only defined as a SUM for folded / evaluation-form /
+ * bucket-chained keys (zkp_groth16_pk_info info[7] says which).  0.4 (round 4): ZKP_ERR_INVALID_POINT for malformed / out-of-subgroup points (0.2 used
  * ZKP_ERR_BAD_ARG), zkp_groth16_multi_info, zkp_bench_hbm_copy, zkp_groth16_points_into_affine; since 0.3 a bucket-chained key returns slot L of
  * zkp_groth16_prove_partials_dev as the identity and slot H as h + l (their sum is what prover.rs:189-196 consumes). */
 const char* zkp_version(void);
@@ -258,7 +262,10 @@ int32_t zkp_groth16_domain_size(zkp_groth16_pk* pk, uint64_t* n);
 /* Window-table plan of a resident key: info[0] = window-group size k (1 = one table copy per window; > 1: the tables did not
  * fit ZKP_TABLE_BUDGET_GB / the free device memory and k consecutive windows share a copy), info[1] = bytes of the five
  * queries' tables, info[2..4] = window bits / windows / resident copies of the A query, info[5] = window bits of the B queries,
- * info[6] = sort sharing (bit 0: B1 reuses B2's bucket sort, bit 1: L reuses A's, bit 2: shared level-1 pass), info[7] = 0. */
+ * info[6] = sort sharing (bit 0: B1 reuses B2's bucket sort, bit 1: L reuses A's, bit 2: shared level-1 pass), info[7] = key form (bit 0: H query in evaluation form, bit 1: C folded into the L query, bit 2: L and H
+ * bucket-chained).  With any bit of info[7] set, slots L (3) and H (4) of zkp_groth16_prove_partials_dev are NOT the reference's
+ * l_aux_acc / h_acc individually — only slot 3 + slot 4 equals l_aux_acc + h_acc, which is all prover.rs:189-196 consumes
+ * (ZKP_H_LAGRANGE=0 ZKP_C_FOLD=0 ZKP_CHAIN_LH=0 at upload restores the individual values). */
 int32_t zkp_groth16_pk_info(zkp_ctx* ctx, zkp_groth16_pk* pk, uint64_t info[8]);
 
 /* create_proof(params, circuit, r, s): z = full assignment (Montgomery), r/s Fr Montgomery (4 limbs).

@@ -56,7 +56,8 @@ static void read_csr(FILE* f, zkp_csr* m) {
  * n_proofs) | at, bt, ct (row_ptr, col, coeff each) | alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2 | a, b_g1, b_g2, h, l
  * (xy then identity flags each) | z | r (n_proofs x 4) | s (n_proofs x 4).
  * out: N | h (N x 4) | proof of (r0, s0) by zkp_groth16_prove (8 fq words + 3 flag words) | n_proofs x the same by
- * zkp_groth16_prove_batch | the proof of (r0, s0) once more by a second zkp_groth16_prove after the batch (key reuse) */
+ * zkp_groth16_prove_batch | the proof of (r0, s0) once more by a second zkp_groth16_prove after the batch (key reuse) | the
+ * proof of (r0, s0) by zkp_groth16_prove_multi over three ranks on device 0 (zkp_ctx_create_multi with duplicate ids) */
 static int groth16_mode(const char* in, const char* out) {
   FILE* f = fopen(in, "rb");
   if (!f) return 1;
@@ -119,6 +120,47 @@ static int groth16_mode(const char* in, const char* out) {
   /* error behaviour of the seam: NULL witness, and a freed key must not be usable through a stale context call sequence */
   if (zkp_groth16_prove(ctx, pk, NULL, r, s, one, one_inf) != ZKP_ERR_BAD_ARG) return 3;
   CHECK(zkp_groth16_pk_free(ctx, pk));
+  /* the single-process multi-GPU seam from C (duplicate device ids: three ranks on the one GPU of a test box): a base-sharded
+   * key proves (r0, s0) over all ranks — host witness and one device witness per rank — and must reproduce `one` */
+  uint64_t* multi = (uint64_t*)calloc(pw, 8);
+  uint8_t multi_inf[3] = {9, 9, 9};
+  {
+    const int ids[3] = {0, 0, 0};
+    zkp_ctx* root = NULL;
+    zkp_groth16_pk_multi* mpk = NULL;
+    int32_t ndev = 0;
+    uint64_t minfo[6];
+    CHECK(zkp_ctx_create_multi(&root, ids, 3));
+    CHECK(zkp_ctx_num_devices(root, &ndev));
+    if (ndev != 3) return 3;
+    CHECK(zkp_groth16_pk_upload_multi(root, &d, ZKP_MULTI_SHARD, &mpk));
+    const uint64_t* zh[1] = {z};
+    CHECK(zkp_groth16_prove_multi(root, mpk, zh, 0, r, s, multi, multi_inf));
+    if (memcmp(multi, one, pw * 8) != 0 || memcmp(multi_inf, one_inf, 3) != 0) { fprintf(stderr, "sharded proof != single-GPU proof\n"); return 5; }
+    const size_t nzb = ((size_t)d.num_inputs + d.num_aux) * 32;
+    void* zdev[3];
+    const uint64_t* zd[3];
+    for (int k = 0; k < 3; k++) {
+      zkp_ctx* mem = NULL;
+      CHECK(zkp_ctx_device(root, k, &mem));
+      CHECK(zkp_dev_alloc(mem, nzb, &zdev[k]));
+      CHECK(zkp_h2d(mem, zdev[k], z, nzb));
+      zd[k] = (const uint64_t*)zdev[k];
+    }
+    memset(multi, 0, pw * 8);
+    CHECK(zkp_groth16_prove_multi(root, mpk, zd, 1, r, s, multi, multi_inf));
+    if (memcmp(multi, one, pw * 8) != 0 || memcmp(multi_inf, one_inf, 3) != 0) { fprintf(stderr, "sharded proof (device witnesses) != single-GPU proof\n"); return 5; }
+    CHECK(zkp_groth16_multi_info(root, mpk, minfo));
+    if (minfo[5] != 3 || minfo[0] != 0) return 3;                /* duplicate ids: peer (device-to-device) copies, never RCCL */
+    if (zkp_groth16_prove_batch_multi(root, mpk, 1, zh, 0, r, s, multi, multi_inf) != ZKP_ERR_BAD_ARG) return 3;   /* SHARD key */
+    for (int k = 0; k < 3; k++) {
+      zkp_ctx* mem = NULL;
+      CHECK(zkp_ctx_device(root, k, &mem));
+      CHECK(zkp_dev_free(mem, zdev[k]));
+    }
+    CHECK(zkp_groth16_pk_multi_free(root, mpk));
+    CHECK(zkp_ctx_destroy(root));
+  }
 
   f = fopen(out, "wb");
   if (!f) return 1;
@@ -135,6 +177,9 @@ static int groth16_mode(const char* in, const char* out) {
   }
   fwrite(again, 8, pw, f);
   for (int k = 0; k < 3; k++) w3[k] = again_inf[k];
+  fwrite(w3, 8, 3, f);
+  fwrite(multi, 8, pw, f);
+  for (int k = 0; k < 3; k++) w3[k] = multi_inf[k];
   fwrite(w3, 8, 3, f);
   fclose(f);
   CHECK(zkp_ctx_destroy(ctx));

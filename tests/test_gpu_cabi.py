@@ -100,7 +100,7 @@ def test_c_program_groth16_seam_reproduces_the_golden_proofs(tmp_path, curve):
         assert N == len(e["h"])
         assert codec.fr_from_mont(out[1:1 + 4 * N].reshape(N, 4), c) == [I(v) for v in e["h"]]
         rest = out[1 + 4 * N:].reshape(-1, 8 * f + 3)
-        assert rest.shape[0] == len(rs) + 2
+        assert rest.shape[0] == len(rs) + 3
 
         def dec(row):
             a = codec.g1_from_mont(row[:2 * f].reshape(1, -1), [int(row[8 * f])], c)[0]
@@ -110,7 +110,8 @@ def test_c_program_groth16_seam_reproduces_the_golden_proofs(tmp_path, curve):
         golden = (unpt(e["a"], 1), unpt(e["b"], 2), unpt(e["c"], 1))
         assert dec(rest[0]) == golden                              # zkp_groth16_prove
         assert dec(rest[1]) == golden                              # zkp_groth16_prove_batch, proof 0
-        assert dec(rest[-1]) == golden                             # zkp_groth16_prove again after the batch
+        assert dec(rest[-2]) == golden                             # zkp_groth16_prove again after the batch
+        assert dec(rest[-1]) == golden                             # zkp_groth16_prove_multi, 3 ranks on device 0 (also compared in C)
         for k in range(1, len(rs)):
             op, _ = og.create_proof(opk, ocirc, *rs[k])
             assert dec(rest[1 + k]) == (op.a, op.b, op.c), k      # incl. (r, s) = (0, 0): create_proof_no_zk

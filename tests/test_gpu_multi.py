@@ -84,6 +84,44 @@ print("PROOF", out.tobytes().hex(), inf.tobytes().hex())
     assert res["0"] == res["1"]
 
 
+def test_prove_multi_one_rank_through_rccl(ctx):
+    """VERDICT r4 task 5: the RCCL branch of zkp_groth16_prove_multi (dlsym'd ncclCommInitAll / ncclGroupStart / ncclAllGather /
+    ncclGroupEnd, csrc/groth16.hip) EXECUTED on the one GPU this box has: ZKP_MULTI_EXCHANGE=rccl with a one-rank multi context
+    (a one-rank communicator is legal), the proof equals the plain single-GPU proof and zkp_groth16_multi_info reports
+    exchange = rccl, rccl_ranks = 1.  A child process, so that a misbehaving communicator cannot wedge the suite."""
+    code = r'''
+import numpy as np
+from ckb_zkp_amd import codec, groth16
+from ckb_zkp_amd.api import MultiContext
+from ckb_zkp_amd.circuits import mimc_chain_instance, samples_for_domain
+TOXIC = dict(alpha=11, beta=13, gamma=17, delta=19, tau=23)
+m = MultiContext([0])
+inst = mimc_chain_instance("bn254", samples_for_domain(12))
+params = groth16.generate_parameters(m, "bn254", inst, **TOXIC)
+c = params.curve
+z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+rm, sm = codec.fr_to_mont([0x1234567], c)[0], codec.fr_to_mont([0x7654321], c)[0]
+pk = groth16.ProvingKey(m, params, inst)
+want = pk.prove_raw(z, rm, sm)
+pk.free()
+mpk = groth16.MultiProvingKey(m, params, inst, groth16.MULTI_SHARD)
+for rep in range(3):
+    got = mpk.prove_raw(z, rm, sm)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), rep
+zd = m.member(0).to_device(z)
+got = mpk.prove_raw([zd], rm, sm, z_on_device=True)
+assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+info = mpk.info()
+print("INFO", info["exchange"], info["rccl_ranks"], info["devices"])
+mpk.free()
+m.close()
+'''
+    env = dict(os.environ, ZKP_MULTI_EXCHANGE="rccl", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "INFO rccl 1 1" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_prove_batch_multi_replicated_equals_sequential(ctx, world):
     """Throughput mode through the C boundary: n independent proofs dealt round-robin over `world` ranks (one host thread
