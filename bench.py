@@ -406,7 +406,8 @@ def recorded(name):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     try:
         return json.load(open(path)), "profiles/" + name
-    except (OSError, ValueError):
+    except (OSError, ValueError) as e:
+        log(f"recorded PMC source profiles/{name} unavailable ({e.__class__.__name__}): the fields that quote it stay null")
         return None, None
 
 

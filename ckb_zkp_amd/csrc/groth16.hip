@@ -320,11 +320,48 @@ static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz,
     ZKP_REQUIRE(d->ct.col[e] < nz, ZKP_ERR_BAD_ARG);
     col_ptr[d->ct.col[e] + 1]++;
   }
+  // HEAVY columns: the kernel gives one lane per variable, and that lane walks its column serially — a 255-step
+  // double-and-add per general coefficient.  A dense column (the constant-one variable of packing / x * x_inv = 1 constraints, any
+  // variable with 1e5+ entries of C) would be a single-lane chain of 1e6-1e8 point operations.  Columns above a cost threshold leave
+  // the kernel's CSC and take ONE variable-base MSM each (msm_var_run over the gathered G rows), subtracted on the host below.
+  const size_t heavy_cost = getenv("ZKP_LFOLD_HEAVY_COST") ? (size_t)atoll(getenv("ZKP_LFOLD_HEAVY_COST")) : 50000;
+  HostField::E one = F.one_(), minus_one = F.neg(one);
+  std::vector<uint8_t> heavy(nz, 0);
+  std::vector<uint32_t> heavy_cols;
+  {
+    std::vector<uint64_t> cost(nz, 0);
+    for (size_t e = 0; e < nnz; e++) {
+      HostField::E c{};
+      memcpy(c.data(), d->ct.coeff + e * 4, 32);
+      cost[d->ct.col[e]] += (c == one || c == minus_one) ? 1 : 380;       // 255 doublings + ~125 additions
+    }
+    for (size_t m = 0; m < nz; m++)
+      if (cost[m] > heavy_cost) {
+        heavy[m] = 1;
+        heavy_cols.push_back((uint32_t)m);
+      }
+  }
+  struct HeavyCol { std::vector<uint64_t> xy, sc; std::vector<uint8_t> inf; };
+  std::vector<HeavyCol> hv(heavy_cols.size());
+  if (!heavy_cols.empty()) {
+    std::vector<uint32_t> slot(nz, 0);
+    for (size_t i = 0; i < heavy_cols.size(); i++) slot[heavy_cols[i]] = (uint32_t)i;
+    for (uint32_t k = 0; k < d->num_constraints; k++)
+      for (uint32_t e = d->ct.row_ptr[k]; e < d->ct.row_ptr[k + 1]; e++) {
+        const uint32_t m = d->ct.col[e];
+        if (!heavy[m]) continue;
+        HeavyCol& H = hv[slot[m]];
+        H.xy.insert(H.xy.end(), g_xy.begin() + (size_t)k * 2 * fq, g_xy.begin() + (size_t)(k + 1) * 2 * fq);
+        H.inf.push_back(g_inf[k]);
+        H.sc.insert(H.sc.end(), d->ct.coeff + (size_t)e * 4, d->ct.coeff + (size_t)e * 4 + 4);
+        col_ptr[m + 1]--;                                        // (counts, before the prefix sum below)
+      }
+  }
   for (size_t m = 0; m < nz; m++) col_ptr[m + 1] += col_ptr[m];
   std::vector<uint32_t> cur(col_ptr.begin(), col_ptr.end() - 1);
-  HostField::E one = F.one_(), minus_one = F.neg(one);
   for (uint32_t k = 0; k < d->num_constraints; k++)
     for (uint32_t e = d->ct.row_ptr[k]; e < d->ct.row_ptr[k + 1]; e++) {
+      if (heavy[d->ct.col[e]]) continue;
       const uint32_t pos = cur[d->ct.col[e]]++;
       rows[pos] = k;
       HostField::E c{};
@@ -364,6 +401,35 @@ static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz,
   ZKP_HIP(hipMemcpyAsync(l_xy->data(), o, nz * ab, hipMemcpyDeviceToHost, st));
   ZKP_HIP(hipMemcpyAsync(l_inf->data(), oi, nz, hipMemcpyDeviceToHost, st));
   ZKP_HIP(hipStreamSynchronize(st));
+  if (!heavy_cols.empty()) {                                   // L'_m = L_m - D_m, D_m = one MSM over column m
+    const HostField Q = fq_field(d->curve);
+    const size_t fw = 2 * fq;                                  // u64 words of an affine point
+    std::vector<HostJac> res(heavy_cols.size());
+    std::vector<uint64_t> xyz(3 * fq);
+    for (size_t i = 0; i < heavy_cols.size(); i++) {
+      const uint32_t m = heavy_cols[i];
+      msm_var_run(ctx, d->curve, 1, hv[i].xy.data(), hv[i].inf.data(), hv[i].sc.data(), hv[i].inf.size(), /*montgomery=*/true, xyz.data());
+      HostJac D = host_jac_load(Q, xyz.data());
+      D.y = Q.neg(D.y);
+      HostJac Lm{};
+      if ((*l_inf)[m]) {
+        Lm.x = Q.one_();
+        Lm.y = Q.one_();
+      } else {
+        memcpy(Lm.x.data(), l_xy->data() + (size_t)m * fw, 8 * fq);
+        memcpy(Lm.y.data(), l_xy->data() + (size_t)m * fw + fq, 8 * fq);
+        Lm.z = Q.one_();
+      }
+      res[i] = host_jac_add(Q, Lm, D);
+    }
+    std::vector<uint64_t> axy(heavy_cols.size() * fw);
+    std::vector<uint8_t> ainf(heavy_cols.size());
+    host_into_affine(Q, res, axy.data(), fw, ainf.data());
+    for (size_t i = 0; i < heavy_cols.size(); i++) {
+      memcpy(l_xy->data() + (size_t)heavy_cols[i] * fw, axy.data() + i * fw, 8 * fw);
+      (*l_inf)[heavy_cols[i]] = ainf[i];
+    }
+  }
 }
 
 zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, int rank, int world) {

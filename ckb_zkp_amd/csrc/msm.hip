@@ -838,7 +838,10 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
                   ws_idx, sort_src, ms_scan, l1_src);
     return;
   }
-  const size_t nch = (n + chunk_pts - 1) / chunk_pts, per = ((n + nch - 1) / nch + 255) & ~(size_t)255;
+  // (per is rounded up to a multiple of 256, so the chunk count is recomputed from it: with a ZKP_MSM_CHUNK that is not a multiple
+  //  of 256 the last of the original nch chunks could come out empty — ADVICE r4)
+  const size_t nch0 = (n + chunk_pts - 1) / chunk_pts, per = ((n + nch0 - 1) / nch0 + 255) & ~(size_t)255;
+  const size_t nch = (n + per - 1) / per;
   const int wa = ws_idx, wb = ws_idx ^ 2;                               // partner: 0 <-> 2, 1 <-> 3
   hipStream_t sa = wa == 0 ? ctx->cur->stream : ctx->cur->ws[wa].stream, sb = wb == 0 ? ctx->cur->stream : ctx->cur->ws[wb].stream;
   // the partner's stream joins behind everything this MSM's stream has seen (scalars complete, bucket array of `wa` free)

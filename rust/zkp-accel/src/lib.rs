@@ -24,6 +24,7 @@ use ark_ec::models::short_weierstrass_jacobian::{GroupAffine, GroupProjective};
 use ark_ec::models::SWModelParameters;
 use ark_ff::{BigInteger256, BigInteger384, Fp256, Fp256Parameters, Fp384, Fp384Parameters, QuadExtField, QuadExtParameters, Zero};
 
+pub mod accel_cache;
 pub mod ffi;
 pub mod groth16;
 pub mod marlin;
@@ -80,9 +81,11 @@ fn check(st: i32) -> Result<(), Error> {
     }
 }
 
-/// One device context (`zkp_ctx`): one per prover thread / per GPU.  Not `Sync`: one in-flight call per context.
+/// One device context (`zkp_ctx`): one per prover thread / per GPU is what runs concurrently.  Since ABI 0.5 the library holds a
+/// per-context lock in every entry point, so a `&Ctx` shared between threads (`accel_cache::ctx()`) is safe: calls are serialised.
 pub struct Ctx(pub(crate) *mut ffi::zkp_ctx);
 unsafe impl Send for Ctx {}
+unsafe impl Sync for Ctx {}
 
 impl Ctx {
     /// Export `GPU_MAX_HW_QUEUES=16` in the process environment BEFORE the first HIP call: the library

@@ -192,6 +192,60 @@ def test_groth16_fuzz_against_cpu_port(ctx, curve):
             pk.free()
 
 
+class _DenseColumnCircuit:
+    """x_i * x_i_inv = ONE-ish rows whose C side all reference the SAME two variables (the constant one with unit / -1 / general
+    coefficients, and one witness variable): dense columns of C, the shape ADVICE r4 flagged for the C fold at key upload."""
+
+    def __init__(self, curve, seed, rows):
+        self.c, self.seed, self.rows = get_curve(curve), seed, rows
+
+    def generate_constraints(self, cs):
+        import random
+        rnd = random.Random(self.seed)
+        r = self.c.r
+        hv = rnd.randrange(1, r)
+        hub = cs.alloc(lambda: hv)
+        for i in range(self.rows):
+            a = rnd.randrange(1, r)
+            k1 = rnd.choice([1, r - 1, rnd.randrange(1, r)])
+            k2 = rnd.choice([0, 1, rnd.randrange(1, r)])
+            # a * b = k1 * ONE + k2 * hub  ->  b = (k1 + k2 hub) / a
+            bval = (k1 + k2 * hv) * pow(a, -1, r) % r
+            xa = cs.alloc(lambda v=a: v)
+            xb = cs.alloc(lambda v=bval: v)
+            cs.enforce(lambda lc, xa=xa: lc + (1, xa), lambda lc, xb=xb: lc + (1, xb),
+                       lambda lc, k1=k1, k2=k2: (lc + (k1, cs.one()) + (k2, hub)) if k2 else (lc + (k1, cs.one())))
+
+
+@pytest.mark.parametrize("curve,rows,cost", [("bn254", 300, "3"), ("bls12_381", 90, "3"), ("bn254", 700, "50000")])
+def test_groth16_dense_c_column_takes_the_heavy_fold_path(ctx, curve, rows, cost, monkeypatch):
+    """fold_c_into_l (csrc/groth16.hip): columns of C above ZKP_LFOLD_HEAVY_COST leave the one-lane-per-variable kernel and take one
+    variable-base MSM each; the proof and witness map still equal oracle/cpu's.  cost = 3 forces nearly every column through the MSM
+    path; the default 50000 with 700 rows sends exactly the two dense columns (constant one + hub) there."""
+    from ckb_zkp_amd import groth16
+    from ckb_zkp_amd.r1cs import ConstraintSystem, R1csInstance
+    monkeypatch.setenv("ZKP_LFOLD_HEAVY_COST", cost)
+    c = get_curve(curve)
+    toxic = dict(alpha=0x7654321, beta=0x1ABCDE, gamma=0xF0145, delta=0x67ABC, tau=0xDEF01236789)
+    cs = ConstraintSystem(c, True)
+    _DenseColumnCircuit(curve, 4242 + rows, rows).generate_constraints(cs)
+    inst = R1csInstance.from_cs(cs)
+    params = groth16.generate_parameters(ctx, c, inst, **toxic)
+    pk = groth16.ProvingKey(ctx, params, inst)
+    try:
+        assert pk.table_plan()["c_folded_into_l"]
+        z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+        rng = np.random.default_rng(rows)
+        for _ in range(2):
+            rm = codec.fr_to_mont([int.from_bytes(rng.bytes(40), "little") % c.r], c)[0]
+            sm = codec.fr_to_mont([int.from_bytes(rng.bytes(40), "little") % c.r], c)[0]
+            out, inf = pk.prove_raw(z, rm, sm)
+            o_out, o_inf, _ = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=4)
+            assert np.array_equal(out, o_out) and np.array_equal(inf, o_inf)
+    finally:
+        pk.free()
+
+
 @pytest.mark.parametrize("curve,seed,ni,nc", [("bn254", 1, 1, 5), ("bn254", 2, 0, 9), ("bls12_381", 3, 1, 6), ("bn254", 4, 3, 14), ("bls12_381", 5, 0, 3), ("bn254", 6, 1, 30), ("bls12_381", 7, 3, 21)])
 def test_marlin_fuzz_against_oracle(ctx, curve, seed, ni, nc):
     """Random (satisfied) circuits through zkp_marlin_index_upload / _index_commit / _prove against oracle/pyref's create_random_proof:

@@ -84,3 +84,65 @@ def test_constants_and_descriptor_layout_agree():
         names[0] = names[0].split()[-1].lstrip("*")
         flat += names
     assert flat == r_fields, (flat, r_fields)
+
+
+def _crate_items():
+    """{module path: set of public items}: '' = lib.rs, 'groth16' = groth16.rs, ..."""
+    src = ROOT / "rust" / "zkp-accel" / "src"
+    lib = (src / "lib.rs").read_text()
+    mods = {"": lib}
+    for m in re.findall(r"^pub mod ([a-z_0-9]+);", lib, flags=re.M):
+        assert (src / f"{m}.rs").exists(), m
+        mods[m] = (src / f"{m}.rs").read_text()
+    items = {}
+    for name, text in mods.items():
+        text = re.sub(r"//.*", "", text)
+        found = set(re.findall(r"^\s*pub(?:\(crate\))?\s+(?:unsafe\s+)?(?:fn|struct|enum|trait|type|const|static|mod)\s+([A-Za-z_0-9]+)", text, flags=re.M))
+        for enum, body in re.findall(r"pub enum ([A-Za-z_0-9]+)\s*\{(.*?)\n\}", text, flags=re.S):
+            for v in re.findall(r"^\s*([A-Z][A-Za-z0-9]*)\s*(?:[,({=]|$)", body, flags=re.M):
+                found.add(f"{enum}::{v}")
+        for ty, body in re.findall(r"^impl(?:<[^{]*?>)?\s+([A-Za-z_0-9]+)[^{]*\{(.*?)^\}", text, flags=re.S | re.M):
+            for fn in re.findall(r"pub fn ([a-z_0-9]+)", body):
+                found.add(f"{ty}::{fn}")
+        items[name] = found
+    return items
+
+
+def _resolve(path, items):
+    """zkp_accel::a::b::c -> is it a module, an item of a module, or Type::assoc of an item?"""
+    segs = path.split("::")
+    if segs[0] in items and segs[0] != "":
+        mod, rest = segs[0], segs[1:]
+    else:
+        mod, rest = "", segs
+    if not rest:
+        return True                                  # a module itself
+    return "::".join(rest) in items[mod] or (len(rest) == 1 and rest[0] in items[mod])
+
+
+def test_every_zkp_accel_path_in_the_patches_resolves_to_a_crate_item():
+    """rust/patches/*.diff may only name things rust/zkp-accel defines (the groth16 patch used to call an
+    `accel_cache` module that existed nowhere).  Checked on the added lines AND on the commentary lines of the patches:
+    `zkp_accel::<path>`, `use zkp_accel::<mod>::{..}`, and `<mod>::<item>` after `use zkp_accel::<mod>;`."""
+    items = _crate_items()
+    assert "accel_cache" in items and {"get_or_upload", "ctx", "evict", "try_ctx"} <= items["accel_cache"]
+    for diff in sorted((ROOT / "rust" / "patches").glob("*.diff")):
+        text = diff.read_text()
+        lines = [l[1:] for l in text.splitlines() if l.startswith(("+", "#")) and not l.startswith("+++")]
+        body = "\n".join(lines)
+        imported_mods = set(re.findall(r"use zkp_accel::([a-z_0-9]+);", body))
+        for mod, names in re.findall(r"use zkp_accel::([a-z_0-9]+)::\{([^}]*)\}", body):
+            for n in [x.strip() for x in names.split(",") if x.strip()]:
+                assert _resolve(f"{mod}::{n}", items), (diff.name, mod, n)
+        for path in re.findall(r"zkp_accel::((?:[A-Za-z_0-9]+)(?:::[A-Za-z_0-9]+)*)", body):
+            path = re.sub(r"::$", "", path)
+            if path.split("::")[0] in items and len(path.split("::")) == 1:
+                continue                              # `use zkp_accel::accel_cache;`
+            assert _resolve(path, items), (diff.name, path)
+        for mod in imported_mods:
+            assert mod in items, (diff.name, mod)
+            for n in re.findall(rf"(?<![A-Za-z_0-9:]){mod}::([a-z_0-9]+)\s*\(", body):
+                assert n in items[mod], (diff.name, mod, n)
+    # the seam's call shape: the closure handed to get_or_upload builds the key with DeviceProvingKey::upload(accel_cache::ctx(), ..)
+    g = (ROOT / "rust" / "patches" / "groth16-accel.diff").read_text()
+    assert "use zkp_accel::accel_cache;" in g and "accel_cache::get_or_upload(params" in g and "DeviceProvingKey::upload(accel_cache::ctx()" in g
