@@ -115,12 +115,154 @@ def qap_exponents(inst: R1csInstance, tau: int):
     return a, b, cc, zt, N
 
 
+class LazyInts:
+    """A vector of Fr elements held as Montgomery limbs ((n, 4) uint64) that turns into a list of canonical Python ints on first
+    use as a sequence (trapdoor exponents of large synthetic keys: 2^24 big ints are only built when a test asks for them;
+    `.mont` is the array for callers that want it as it is)."""
+
+    def __init__(self, mont: np.ndarray, c: CurveParams):
+        self.mont, self._c, self._ints = mont, c, None
+
+    def _get(self):
+        if self._ints is None:
+            from .codec import fr_from_mont
+            self._ints = fr_from_mont(self.mont, self._c)
+        return self._ints
+
+    def __len__(self):
+        return self.mont.shape[0]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
+KEYGEN_DEVICE_MIN_LOG = 15      # domains >= 2^15: the exponent vectors are computed with the library's Fr vector kernels
+
+
+def _generate_parameters_dev(ctx: Context, c: CurveParams, inst: R1csInstance, alpha, beta, gamma, delta, tau, g1_k, g2_k, lg):
+    """generate_parameters for LARGE synthetic instances: the same formulas as `qap_exponents` + the loops of
+    `generate_parameters` (generator.rs:135-286: Lagrange coefficients at tau by batch inversion, a_i / b_i / c_i(tau) as transposed
+    sparse products, l = (beta a + alpha b + c) / delta, h_i = Z(tau) tau^i / delta) evaluated with the Fr vector primitives of the C
+    ABI (zkp_fr_vec_op_dev, zkp_fr_batch_inverse_dev, zkp_fr_spmv_dev) instead of Python big-int loops: 2.5 min -> seconds at 2^24.
+    Setup is not the hot path; tests/test_gpu_groth16.py checks this path against the big-int one on the same instance."""
+    r = c.r
+    nc, ni = inst.num_constraints(), inst.num_inputs
+    N = 1 << lg
+    nv = ni + inst.num_aux
+    w = pow(pow(c.fr_generator, (r - 1) >> c.two_adicity, r), 1 << (c.two_adicity - lg), r)
+    zt = (pow(tau, N, r) - 1) % r
+    assert zt != 0, "tau inside the domain"
+    m1 = lambda x: fr_to_mont([x % r], c)[0]
+    R_inv = pow(1 << (64 * c.fr_limbs), -1, r)
+    bufs = []
+
+    def alloc(n):
+        p = ctx.dev_alloc(max(n, 1) * 32)
+        bufs.append(p)
+        return p
+
+    def powers(n, base, first):
+        """first * base^i, i < n (Montgomery), by doubling"""
+        buf = alloc(n)
+        ctx.h2d(buf, m1(first).reshape(1, 4))
+        ln = 1
+        while ln < n:
+            m = min(ln, n - ln)
+            ctx.fr_vec_op(c, 3, buf, None, buf + ln * 32, m, m1(pow(base, ln, r)))
+            ln += m
+        return buf
+
+    def download(buf, n, k=1, off=0):
+        """canonical limbs of k * v[off + i], i < n: scaling by k / R leaves the canonical representation in memory"""
+        tmp = alloc(n)
+        ctx.fr_vec_op(c, 3, buf + off * 32, None, tmp, n, m1(k * R_inv % r))
+        out = np.zeros((n, c.fr_limbs), dtype=np.uint64)
+        if n:
+            ctx.d2h(out, tmp)
+        return out
+
+    def mont_host(buf, n):
+        out = np.zeros((n, c.fr_limbs), dtype=np.uint64)
+        if n:
+            ctx.d2h(out, buf)
+        return out
+
+    try:
+        els = powers(N, w, 1)
+        u = alloc(N)                                                   # u_i = Z(tau) w^i / (N (tau - w^i))
+        ctx.fr_vec_op(c, 3, els, None, u, N, m1(r - 1))
+        ctx.fr_vec_op(c, 5, u, None, u, N, m1(tau))
+        ctx.fr_batch_inverse(c, u, N)
+        ctx.fr_vec_op(c, 0, u, els, u, N)
+        ctx.fr_vec_op(c, 3, u, None, u, N, m1(zt * pow(N, -1, r) % r))
+        rows_of = None
+        vecs = []
+        for which in "abc":
+            row_ptr, col, coeff = inst.csr(which)
+            row_ptr = np.asarray(row_ptr, dtype=np.int64)
+            col = np.asarray(col, dtype=np.int64)
+            rows_of = np.repeat(np.arange(nc, dtype=np.int64), np.diff(row_ptr))
+            order = np.argsort(col, kind="stable")
+            tptr = np.zeros(nv + 1, dtype=np.uint32)
+            np.cumsum(np.bincount(col, minlength=nv), out=tptr[1:])
+            d_ptr = ctx.to_device(tptr)
+            d_col = ctx.to_device(np.ascontiguousarray(rows_of[order] if len(col) else np.zeros(1), dtype=np.uint32))
+            d_cf = ctx.to_device(np.ascontiguousarray(np.asarray(coeff, dtype=np.uint64).reshape(-1, 4)[order] if len(col) else np.zeros((1, 4)), dtype=np.uint64))
+            bufs.extend([d_ptr, d_col, d_cf])
+            acc = alloc(nv)
+            ctx.fr_spmv(c, d_ptr, d_col, d_cf, nv, u, acc)              # acc_j = sum_{k: col_k = j} coeff_k u_{row_k}
+            vecs.append(acc)
+        a, b, cc = vecs
+        ctx.fr_vec_op(c, 1, a, u + nc * 32, a, ni)                     # a_i += u_{nc + i}, i < num_inputs (r1cs_to_qap.rs:83-85)
+        t = alloc(nv)                                                  # beta a + alpha b + c
+        ctx.fr_vec_op(c, 3, a, None, t, nv, m1(beta))
+        ctx.fr_vec_op(c, 4, t, b, t, nv, m1(alpha))
+        ctx.fr_vec_op(c, 1, t, cc, t, nv)
+        gi, di = pow(gamma, -1, r), pow(delta, -1, r)
+        lvec = alloc(nv)
+        ctx.fr_vec_op(c, 3, t, None, lvec, nv, m1(di))
+        hvec = powers(N - 1, tau, zt * di % r)
+        g1_base, _ = g1_to_mont([c.g1], c)
+        g2_base, _ = g2_to_mont([c.g2], c)
+        mul1 = lambda sc: ctx.fixed_base_mul(c, 1, g1_base, sc)
+        mul2 = lambda sc: ctx.fixed_base_mul(c, 2, g2_base, sc)
+        singles1, _ = mul1(fr_canonical([k * g1_k % r for k in (alpha, beta, delta)], c))
+        singles2, _ = mul2(fr_canonical([k * g2_k % r for k in (beta, gamma, delta)], c))
+        b_can1 = download(b, nv, g1_k)
+        params = Parameters(
+            curve=c, num_inputs=ni, num_aux=inst.num_aux, num_constraints=nc,
+            alpha_g1=singles1[0], beta_g1=singles1[1], delta_g1=singles1[2],
+            beta_g2=singles2[0], gamma_g2=singles2[1], delta_g2=singles2[2],
+            gamma_abc_g1=mul1(download(t, ni, gi * g1_k % r)), a_query=mul1(download(a, nv, g1_k)), b_g1_query=mul1(b_can1),
+            b_g2_query=mul2(b_can1 if g1_k == g2_k else download(b, nv, g2_k)),
+            h_query=mul1(download(hvec, N - 1, g1_k)), l_query=mul1(download(lvec, nv - ni, g1_k, off=ni)),
+            toxic=dict(alpha=alpha, beta=beta, gamma=gamma, delta=delta, tau=tau, g1_k=g1_k, g2_k=g2_k,
+                       a=LazyInts(mont_host(a, nv), c), b=LazyInts(mont_host(b, nv), c), c=LazyInts(mont_host(cc, nv), c),
+                       l=LazyInts(mont_host(lvec, nv), c), h=LazyInts(mont_host(hvec, N - 1), c), zt=zt))
+    finally:
+        ctx.sync()
+        for p_ in bufs:
+            ctx.dev_free(p_)
+    return params
+
+
 def generate_parameters(ctx: Context, curve, circuit, alpha: int, beta: int, gamma: int, delta: int, tau: int,
-                        g1_k: int = 1, g2_k: int = 1) -> Parameters:
-    """generator.rs:135-286 with the toxic waste (and the generator multiples) as explicit inputs."""
+                        g1_k: int = 1, g2_k: int = 1, keygen: str = "auto") -> Parameters:
+    """generator.rs:135-286 with the toxic waste (and the generator multiples) as explicit inputs.
+    keygen: "host" = Python big-int exponents, "device" = the library's Fr vector kernels (`_generate_parameters_dev`),
+    "auto" = device from 2^KEYGEN_DEVICE_MIN_LOG constraints on."""
     c = get_curve(curve)
     r = c.r
     inst = _as_instance(c, circuit, assign=False)
+    lg_dom = _domain_log(c, inst.num_constraints() + (inst.num_inputs - 1) + 1)
+    if keygen == "device" or (keygen == "auto" and lg_dom >= KEYGEN_DEVICE_MIN_LOG and pow(tau, 1 << lg_dom, r) != 1):
+        return _generate_parameters_dev(ctx, c, inst, alpha % r, beta % r, gamma % r, delta % r, tau % r, g1_k, g2_k, lg_dom)
     a, b, cc, zt, N = qap_exponents(inst, tau)
     ni = inst.num_inputs
     gi, di = pow(gamma, -1, r), pow(delta, -1, r)

@@ -523,6 +523,33 @@ int oracle_groth16_prove(const zkp_groth16_pk_desc* d, const uint64_t* z, const 
   return 0;
 }
 
+// sum_i a_i * b_i over Fr (Montgomery in, Montgomery out): the trapdoor-in-the-exponent checks of the full-size tests
+// (sum_i z_i a_i(tau) over 2^24 terms) without Python big-int loops
+int oracle_fr_dot(int curve, const uint64_t* a, const uint64_t* b, size_t n, int threads, uint64_t* out) {
+  auto run = [&](auto tag) {
+    using F = Fp<decltype(tag)>;
+    int T = std::max(1, std::min(threads, 64));
+    std::vector<F> part(T, F::zero());
+    size_t per = (n + T - 1) / T;
+    auto body = [&](int t) {
+      F acc = F::zero();
+      for (size_t i = std::min(n, t * per), e = std::min(n, i + per); i < e; i++) acc = acc + F::from_limbs(a + 4 * i) * F::from_limbs(b + 4 * i);
+      part[t] = acc;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(body, t);
+    body(0);
+    for (auto& th : pool) th.join();
+    F acc = F::zero();
+    for (auto& p : part) acc = acc + p;
+    acc.to_limbs(out);
+  };
+  if (curve == ZKP_BN254) run(Bn254FrP{});
+  else if (curve == ZKP_BLS12_381) run(Bls381FrP{});
+  else return -1;
+  return 0;
+}
+
 // k_i * P (affine Montgomery out) — for building keys on CPU-only boxes in the `not gpu` tests
 int oracle_fixed_base_mul(int curve, int group, const uint64_t* base_xy, const uint64_t* scalars, size_t n,
                           uint64_t* out_xy, uint8_t* out_inf) {

@@ -70,6 +70,17 @@ def ntt(curve_id: int, data: np.ndarray, op: int, threads: int = 1) -> np.ndarra
     return a
 
 
+def fr_dot(curve, a_mont: np.ndarray, b_mont: np.ndarray, threads: int = 0) -> int:
+    """sum_i a_i b_i mod r as a canonical Python int; curve: oracle.pyref.fields Curve (or anything with .cid and .r)."""
+    a = np.ascontiguousarray(a_mont, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b_mont, dtype=np.uint64).reshape(-1, 4)
+    n = min(a.shape[0], b.shape[0])
+    out = np.zeros(4, dtype=np.uint64)
+    rc = load().oracle_fr_dot(curve.cid, _p(a), _p(b), C.c_size_t(n), threads or hardware_threads(), _p(out))
+    assert rc == 0
+    return int.from_bytes(out.tobytes(), "little") * pow(1 << 256, -1, curve.r) % curve.r
+
+
 def fixed_base_mul(curve_id: int, group: int, base_xy: np.ndarray, scalars: np.ndarray):
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
     n = scalars.shape[0]

@@ -127,9 +127,7 @@ def test_config5_2p24_single_gpu_and_8way_sharded(ctx):
             h_dev = pk.witness_map(z)
             # full-size pin at 2^24: h and the whole proof equal the C++ restatement of the reference (all host threads)
             assert np.array_equal(h_dev, cpu_oracle.witness_map(params, inst, z, threads=thr))
-            h = codec.fr_from_mont(h_dev, c)
-            del h_dev
-            assert h[-1] == 0
+            assert not h_dev[-1].any()                          # deg h <= N - 2
             rm, sm = codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0]
             out1, inf1 = pk.prove_raw(zd, rm, sm, z_on_device=True)
             o_out, o_inf, _ = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=thr)
@@ -137,17 +135,16 @@ def test_config5_2p24_single_gpu_and_8way_sharded(ctx):
             proof = pk.decode_proof(out1, inf1)
         finally:
             pk.free()
-        t, r, ni = params.toxic, c.r, inst.num_inputs
-        A = (t["alpha"] + sum(zi * ai for zi, ai in zip(inst.z, t["a"])) + r_ * t["delta"]) % r
-        B = (t["beta"] + sum(zi * bi for zi, bi in zip(inst.z, t["b"])) + s_ * t["delta"]) % r
-        L = sum(zi * li for zi, li in zip(inst.z[ni:], t["l"][ni:])) % r
-        H = sum(hi * qi for hi, qi in zip(h, t["h"])) % r
-        Cc = (s_ * A + r_ * B - r_ * s_ % r * t["delta"] + L + H) % r
+        # the key's exponents (computed with the library's Fr kernels at this size) re-derived for a sample with Python integers,
+        # then the proof in the exponent (inner products over the full assignment by oracle/cpu)
+        from tests.util import spot_check_qap_exponents, trapdoor_proof_exponents
+        spot_check_qap_exponents(params, inst)
+        A, B, Cc = trapdoor_proof_exponents(params, inst, z, h_dev, r_, s_)
+        del h_dev
         G1, G2 = Group(OC[curve], 1), Group(OC[curve], 2)
         assert proof.a == G1.mul(G1.gen, A)
         assert proof.b == G2.mul(G2.gen, B)
         assert proof.c == G1.mul(G1.gen, Cc)
-        del h, t
         out2, inf2 = _device_sharded_proof(ctx, params, inst, zd, world, r_, s_)
         assert np.array_equal(out1, out2) and np.array_equal(inf1, inf2)
     finally:

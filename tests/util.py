@@ -41,3 +41,61 @@ def random_points(curve, group, n, seed):
 def to_abi_points(curve, group, pts):
     c = get_curve(curve)
     return codec.g1_to_mont(pts, c) if group == 1 else codec.g2_to_mont(pts, c)
+
+
+def spot_check_qap_exponents(params, inst, samples=48, seed=5):
+    """The trapdoor exponents a_i(tau), b_i(tau), c_i(tau), l_i, h_i a synthetic key was built from (generate_parameters, possibly
+    with the library's own Fr kernels for large instances) recomputed for a random sample of indices with plain Python integers from
+    the CSR arrays: u_k = Z(tau) w^k / (N (tau - w^k)), a_i = sum_k A_ki u_k (+ u_{nc+i} for inputs), l = (beta a + alpha b + c) / delta,
+    h_i = Z(tau) tau^i / delta  (groth16/src/r1cs_to_qap.rs:58-110, generator.rs:205-256).  Keeps the trapdoor-in-the-exponent
+    assertions independent of the kernels that produced the key."""
+    c = params.curve
+    r, t = c.r, params.toxic
+    nc, ni, nv = inst.num_constraints(), inst.num_inputs, inst.num_inputs + inst.num_aux
+    N = 1 << max(nc + ni - 1, 0).bit_length()
+    lg = N.bit_length() - 1
+    w = pow(pow(c.fr_generator, (r - 1) >> c.two_adicity, r), 1 << (c.two_adicity - lg), r)
+    tau = t["tau"] % r
+    zt = (pow(tau, N, r) - 1) % r
+    assert zt == t["zt"] % r
+    zn = zt * pow(N, -1, r) % r
+    u = lambda k: zn * pow(w, k, r) % r * pow((tau - pow(w, k, r)) % r, -1, r) % r
+    Ri = pow(1 << (64 * c.fr_limbs), -1, r)
+    rnd = random.Random(seed)
+    idx = sorted({0, 1, ni - 1, ni, nv - 1} | {rnd.randrange(nv) for _ in range(samples)})
+    idx = [i for i in idx if 0 <= i < nv]
+    mont = {k: getattr(t[k], "mont", None) for k in ("a", "b", "c", "l", "h")}
+    get = lambda k, i: (int.from_bytes(mont[k][i].tobytes(), "little") * Ri % r) if mont[k] is not None else t[k][i] % r
+    vals = {}
+    for which in "abc":
+        row_ptr, col, coeff = inst.csr(which)
+        col = np.asarray(col)
+        rows_of = np.repeat(np.arange(nc, dtype=np.int64), np.diff(np.asarray(row_ptr, dtype=np.int64)))
+        for i in idx:
+            acc = u(nc + i) if (which == "a" and i < ni) else 0
+            for e in np.flatnonzero(col == i):
+                acc += int.from_bytes(np.asarray(coeff[e]).tobytes(), "little") * Ri % r * u(int(rows_of[e]))
+            vals[(which, i)] = acc % r
+            assert get(which, i) == vals[(which, i)], (which, i)
+    di = pow(t["delta"], -1, r)
+    for i in idx:
+        assert get("l", i) == (t["beta"] * vals[("a", i)] + t["alpha"] * vals[("b", i)] + vals[("c", i)]) * di % r, ("l", i)
+    for i in {0, 1, 2, N // 2, N - 2} | {rnd.randrange(N - 1) for _ in range(8)}:
+        if 0 <= i < N - 1:
+            assert get("h", i) == zt * di % r * pow(tau, i, r) % r, ("h", i)
+
+
+def trapdoor_proof_exponents(params, inst, z_mont, h_mont, r_, s_):
+    """(A, B, C) of create_proof (groth16/src/prover.rs:164-210) computed IN THE EXPONENT from the toxic waste: the three
+    inner products over the whole assignment / quotient by oracle/cpu's fr_dot (Montgomery arrays in, canonical int out)."""
+    from oracle import cpu_oracle
+    c = params.curve
+    oc = OC[c.name]
+    t, r, ni = params.toxic, c.r, inst.num_inputs
+    mont = lambda k: t[k].mont if hasattr(t[k], "mont") else codec.fr_to_mont(list(t[k]), c).reshape(-1, 4)
+    z_mont = np.asarray(z_mont).reshape(-1, 4)
+    A = (t["alpha"] + cpu_oracle.fr_dot(oc, z_mont, mont("a")) + r_ * t["delta"]) % r
+    B = (t["beta"] + cpu_oracle.fr_dot(oc, z_mont, mont("b")) + s_ * t["delta"]) % r
+    L = cpu_oracle.fr_dot(oc, z_mont[ni:], mont("l")[ni:])
+    H = cpu_oracle.fr_dot(oc, np.asarray(h_mont).reshape(-1, 4), mont("h"))
+    return A, B, (s_ * A + r_ * B - r_ * s_ % r * t["delta"] + L + H) % r
