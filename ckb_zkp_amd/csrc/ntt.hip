@@ -30,7 +30,18 @@
 
 namespace zkp {
 
-constexpr int NTT_SMAX = 7;            // max radix bits per pass
+constexpr int NTT_SMAX = 7;            // max radix bits per pass (default plan)
+// Round 5 experiment (profiles/r05_ntt_two_pass.txt): ZKP_NTT_SMAX=8..10 lets a pass take up to 10 radix bits with the same 1024-element
+// tile (C = 1024 >> S columns per row: 4 / 2 / 1), i.e. 2^20 in two passes (10 + 10) and 2^22 / 2^24 in three (8 + 7 + 7, 8 + 8 + 8).
+// Read once per process (the cached inter-pass tables depend on the plan).
+static int ntt_smax() {
+  static const int v = [] {
+    const char* e = getenv("ZKP_NTT_SMAX");
+    int s = e ? atoi(e) : NTT_SMAX;
+    return s < 4 ? 4 : (s > 10 ? 10 : s);
+  }();
+  return v;
+}
 #ifndef ZKP_NTT_TILE_LOG
 #define ZKP_NTT_TILE_LOG 10
 #endif
@@ -42,7 +53,7 @@ constexpr int NTT_SMAX = 7;            // max radix bits per pass
 //  At 2^23 a pass runs at 74 % of its VALU-instruction bound, at 2^20 at 50 %: per-launch ramp, not the tile shape, is what is left.)
 constexpr int NTT_TILE_LOG = ZKP_NTT_TILE_LOG;       // elements per LDS tile (1024 * 32 B = 32 KiB)
 constexpr int NTT_THREADS = ZKP_NTT_THREADS;
-constexpr int NTT_SUB_LOG = 7;         // sub-FFT twiddle table covers R <= 2^7
+constexpr int NTT_SUB_LOG = 10;        // sub-FFT twiddle table covers R <= 2^10 (the default plan uses R <= 2^7: every 8th entry)
 constexpr int NTT_FULL_MAX_LOG = 24;   // full-size twiddle / coset tables up to this domain size (32 B * N each)
 constexpr int NTT_MAX_BATCH = 4;       // independent transforms per launch (blockIdx.y)
 
@@ -600,7 +611,8 @@ static void ntt_plan(int log_n, int* S, int* P) {
     *P = 0;
     return;
   }
-  int p = (log_n + NTT_SMAX - 1) / NTT_SMAX;
+  const int smax = ntt_smax();
+  int p = (log_n + smax - 1) / smax;
   int base = log_n / p, rem = log_n % p;
   for (int i = 0; i < p; i++) S[i] = base + (i < rem ? 1 : 0);
   *P = p;

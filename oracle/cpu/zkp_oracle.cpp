@@ -550,6 +550,30 @@ int oracle_fr_dot(int curve, const uint64_t* a, const uint64_t* b, size_t n, int
   return 0;
 }
 
+// out[i] = first * base^i (Montgomery), i < n
+int oracle_fr_powers(int curve, const uint64_t* base, const uint64_t* first, size_t n, int threads, uint64_t* out) {
+  auto run = [&](auto tag) {
+    using F = Fp<decltype(tag)>;
+    const F b = F::from_limbs(base), f0 = F::from_limbs(first);
+    int T = std::max(1, std::min(threads, 64));
+    size_t per = (n + T - 1) / T;
+    auto body = [&](int t) {
+      size_t i0 = std::min(n, t * per), i1 = std::min(n, i0 + per);
+      if (i0 >= i1) return;
+      F p = f0 * b.pow64(i0);
+      for (size_t i = i0; i < i1; i++) { p.to_limbs(out + 4 * i); p = p * b; }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(body, t);
+    body(0);
+    for (auto& th : pool) th.join();
+  };
+  if (curve == ZKP_BN254) run(Bn254FrP{});
+  else if (curve == ZKP_BLS12_381) run(Bls381FrP{});
+  else return -1;
+  return 0;
+}
+
 // k_i * P (affine Montgomery out) — for building keys on CPU-only boxes in the `not gpu` tests
 int oracle_fixed_base_mul(int curve, int group, const uint64_t* base_xy, const uint64_t* scalars, size_t n,
                           uint64_t* out_xy, uint8_t* out_inf) {

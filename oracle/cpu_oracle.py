@@ -81,13 +81,33 @@ def fr_dot(curve, a_mont: np.ndarray, b_mont: np.ndarray, threads: int = 0) -> i
     return int.from_bytes(out.tobytes(), "little") * pow(1 << 256, -1, curve.r) % curve.r
 
 
+def _mont1(curve, x: int) -> np.ndarray:
+    return np.frombuffer(((x % curve.r) * (1 << 256) % curve.r).to_bytes(32, "little"), dtype="<u8").copy()
+
+
+def fr_powers(curve, base: int, n: int, first: int = 1, threads: int = 0) -> np.ndarray:
+    """(n, 4) Montgomery: first * base^i"""
+    out = np.zeros((n, 4), dtype=np.uint64)
+    b, f = _mont1(curve, base), _mont1(curve, first)           # kept alive across the call
+    rc = load().oracle_fr_powers(curve.cid, _p(b), _p(f), C.c_size_t(n), threads or hardware_threads(), _p(out))
+    assert rc == 0
+    return out
+
+
+def lagrange_coeffs(curve, log_n: int, tau: int, threads: int = 0) -> np.ndarray:
+    """u_k = L_k(tau) over the radix-2 domain of size 2^log_n, (N, 4) Montgomery: the inverse transform of (tau^j)_j
+    (u_k = 1/N sum_j tau^j w^-jk = Z(tau) w^k / (N (tau - w^k)); r1cs_to_qap.rs:58-110 evaluates the same by batch inversion)"""
+    return ntt(curve.cid, fr_powers(curve, tau, 1 << log_n, threads=threads), 1, threads=threads or hardware_threads())
+
+
 def fixed_base_mul(curve_id: int, group: int, base_xy: np.ndarray, scalars: np.ndarray):
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
     n = scalars.shape[0]
     fq = 4 if curve_id == 0 else 6
     out = np.zeros((n, 2 * fq * group), dtype=np.uint64)
     inf = np.zeros(n, dtype=np.uint8)
-    rc = load().oracle_fixed_base_mul(curve_id, group, _p(np.ascontiguousarray(base_xy, dtype=np.uint64)), _p(scalars),
+    base_xy = np.ascontiguousarray(base_xy, dtype=np.uint64)       # named: a temporary would be freed before the call
+    rc = load().oracle_fixed_base_mul(curve_id, group, _p(base_xy), _p(scalars),
                                       C.c_size_t(n), _p(out), _p(inf))
     assert rc == 0
     return out, inf
@@ -140,8 +160,8 @@ def groth16_prove(params, inst, z_mont, r_mont, s_mont, threads: int = 1):
     inf = np.zeros(3, dtype=np.uint8)
     ph = np.zeros(8, dtype=np.float64)
     z = np.ascontiguousarray(z_mont, dtype=np.uint64)
-    rc = load().oracle_groth16_prove(C.byref(d), _p(z), _p(np.ascontiguousarray(r_mont, dtype=np.uint64)),
-                                     _p(np.ascontiguousarray(s_mont, dtype=np.uint64)), threads, _p(out), _p(inf), _p(ph))
+    r_mont, s_mont = np.ascontiguousarray(r_mont, dtype=np.uint64), np.ascontiguousarray(s_mont, dtype=np.uint64)
+    rc = load().oracle_groth16_prove(C.byref(d), _p(z), _p(r_mont), _p(s_mont), threads, _p(out), _p(inf), _p(ph))
     assert rc == 0
     return out, inf, ph
 

@@ -36,7 +36,8 @@ def _run(ctx, pk, hb, z, rs, sc, vec, curve, out, barrier=None):
         res = []
         for i, (r, s) in enumerate(rs):
             res.append(("proof", pk.prove_raw(z, r, s)))
-            res.append(("msm", hb.msm(sc[: min(len(sc), hb.n) - 17 * i])))
+            xy, inf = hb.msm_affine(sc[: min(len(sc), hb.n) - 17 * i])       # affine: a Jacobian triple is not a canonical form
+            res.append(("msm", np.concatenate([np.asarray(xy, dtype=np.uint64).ravel(), np.asarray([int(inf)], dtype=np.uint64)])))
             res.append(("ntt", ctx.ntt(curve, vec, NTT_COSET_FFT)))
         out.append(res)
     except BaseException as e:                        # surfaced by the main thread

@@ -44,12 +44,16 @@ def to_abi_points(curve, group, pts):
 
 
 def spot_check_qap_exponents(params, inst, samples=48, seed=5):
-    """The trapdoor exponents a_i(tau), b_i(tau), c_i(tau), l_i, h_i a synthetic key was built from (generate_parameters, possibly
-    with the library's own Fr kernels for large instances) recomputed for a random sample of indices with plain Python integers from
-    the CSR arrays: u_k = Z(tau) w^k / (N (tau - w^k)), a_i = sum_k A_ki u_k (+ u_{nc+i} for inputs), l = (beta a + alpha b + c) / delta,
-    h_i = Z(tau) tau^i / delta  (groth16/src/r1cs_to_qap.rs:58-110, generator.rs:205-256).  Keeps the trapdoor-in-the-exponent
-    assertions independent of the kernels that produced the key."""
+    """The trapdoor exponents a_i(tau), b_i(tau), c_i(tau), l_i, h_i a synthetic key was built from (generate_parameters: for large
+    instances with the library's own Fr kernels) recomputed for a sample of variables WITHOUT any product code: the Lagrange
+    coefficients u_k = L_k(tau) by oracle/cpu (inverse transform of the powers of tau; cross-checked against the closed form
+    Z(tau) w^k / (N (tau - w^k)) in Python integers at a few k), a_i = sum_k A_ki u_k (+ u_{nc+i} for inputs) over the CSR arrays by
+    oracle/cpu's fr_dot — the dense column of the constant ONE included — then l = (beta a + alpha b + c) / delta and
+    h_i = Z(tau) tau^i / delta in Python integers (groth16/src/r1cs_to_qap.rs:58-110, generator.rs:205-256).  Keeps the
+    trapdoor-in-the-exponent assertions independent of the kernels that produced the key."""
+    from oracle import cpu_oracle
     c = params.curve
+    oc = OC[c.name]
     r, t = c.r, params.toxic
     nc, ni, nv = inst.num_constraints(), inst.num_inputs, inst.num_inputs + inst.num_aux
     N = 1 << max(nc + ni - 1, 0).bit_length()
@@ -58,23 +62,27 @@ def spot_check_qap_exponents(params, inst, samples=48, seed=5):
     tau = t["tau"] % r
     zt = (pow(tau, N, r) - 1) % r
     assert zt == t["zt"] % r
-    zn = zt * pow(N, -1, r) % r
-    u = lambda k: zn * pow(w, k, r) % r * pow((tau - pow(w, k, r)) % r, -1, r) % r
     Ri = pow(1 << (64 * c.fr_limbs), -1, r)
+    to_int = lambda row: int.from_bytes(np.asarray(row).tobytes(), "little") * Ri % r
+    u = cpu_oracle.lagrange_coeffs(oc, lg, tau)
     rnd = random.Random(seed)
-    idx = sorted({0, 1, ni - 1, ni, nv - 1} | {rnd.randrange(nv) for _ in range(samples)})
-    idx = [i for i in idx if 0 <= i < nv]
+    zn = zt * pow(N, -1, r) % r
+    for k in {0, 1, N - 1} | {rnd.randrange(N) for _ in range(6)}:
+        assert to_int(u[k]) == zn * pow(w, k, r) % r * pow((tau - pow(w, k, r)) % r, -1, r) % r, ("u", k)
+    idx = sorted(i for i in ({0, 1, ni - 1, ni, nv - 1} | {rnd.randrange(nv) for _ in range(samples)}) if 0 <= i < nv)
     mont = {k: getattr(t[k], "mont", None) for k in ("a", "b", "c", "l", "h")}
-    get = lambda k, i: (int.from_bytes(mont[k][i].tobytes(), "little") * Ri % r) if mont[k] is not None else t[k][i] % r
+    get = lambda k, i: to_int(mont[k][i]) if mont[k] is not None else t[k][i] % r
     vals = {}
     for which in "abc":
         row_ptr, col, coeff = inst.csr(which)
         col = np.asarray(col)
+        coeff = np.asarray(coeff, dtype=np.uint64).reshape(-1, 4)
         rows_of = np.repeat(np.arange(nc, dtype=np.int64), np.diff(np.asarray(row_ptr, dtype=np.int64)))
         for i in idx:
-            acc = u(nc + i) if (which == "a" and i < ni) else 0
-            for e in np.flatnonzero(col == i):
-                acc += int.from_bytes(np.asarray(coeff[e]).tobytes(), "little") * Ri % r * u(int(rows_of[e]))
+            e = np.flatnonzero(col == i)
+            acc = cpu_oracle.fr_dot(oc, coeff[e], u[rows_of[e]]) if len(e) else 0
+            if which == "a" and i < ni:
+                acc += to_int(u[nc + i])
             vals[(which, i)] = acc % r
             assert get(which, i) == vals[(which, i)], (which, i)
     di = pow(t["delta"], -1, r)

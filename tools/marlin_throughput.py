@@ -27,13 +27,26 @@ def main():
     ap.add_argument("--samples", type=int, default=87381)
     ap.add_argument("--threads", default="1,2,3")
     ap.add_argument("--proofs", type=int, default=6, help="proofs per thread in the timed region")
+    ap.add_argument("--stream-offset", type=int, default=0,
+                    help="throwaway HIP streams created between two contexts: shifts the hardware queues (stream index mod GPU_MAX_HW_QUEUES) "
+                         "the next context's lane-0 streams land on")
     a = ap.parse_args()
     curve = "bn254"
     c = get_curve(curve)
     log = lambda *m: print("[marlin-tp]", *m, file=sys.stderr, flush=True)
     inst = mimc_chain_instance(curve, a.samples, seed=0x4D41524C)
     tmax = max(int(t) for t in a.threads.split(","))
-    ctxs = [Context(0) for _ in range(tmax)]
+    ctxs = []
+    keep_streams = []
+    for t in range(tmax):
+        if t and a.stream_offset:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            for _ in range(a.stream_offset):
+                st = ctypes.c_void_p()
+                assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0
+                keep_streams.append(st)
+        ctxs.append(Context(0))
     idxs = [M.NativeIndex(cx, inst) for cx in ctxs]
     ck0 = kzg10.setup(ctxs[0], curve, idxs[0].max_degree, 0x1F2E3D4C5B6A79880102030405060708)
     cks = [ck0] + [replace(ck0, powers_of_g=ck0.powers_of_g.share_with(cx), powers_of_gamma_g=ck0.powers_of_gamma_g.share_with(cx))
@@ -72,7 +85,7 @@ def main():
         out[str(T)] = {"threads": T, "proofs": T * a.proofs, "seconds": round(dt, 4), "proofs_per_s": round(T * a.proofs / dt, 3),
                        "ms_per_proof_wall": round(dt / a.proofs * 1e3, 2), "equal_to_sequential": same}
         log(T, out[str(T)])
-    print(json.dumps({"workload": f"Marlin create_random_proof, {inst.num_constraints()} constraints, bn254, T contexts x threads on one MI355X",
+    print(json.dumps({"stream_offset": a.stream_offset, "workload": f"Marlin create_random_proof, {inst.num_constraints()} constraints, bn254, T contexts x threads on one MI355X",
                       "results": out}))
 
 
