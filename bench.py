@@ -258,7 +258,7 @@ def bench_marlin(ctx, curve="bn254", samples=87381, reps=3, verify=True, cpu=Fal
     # Since round 3 the commitments of the mask polynomial and t(X) start DURING their rounds (marlin.hip, early commitments), so
     # the commit phases alone no longer hold all the MSM time: the clock is rounds + commits (conservative: it also holds the NTTs).
     commit_s = (sum(tm["ms_commit"]) + sum(tm["ms_round"])) * 1e-3
-    mpmc, msrc = recorded("r04_pmc_marlin_accumulate.json")
+    mpmc, msrc = recorded("r05_pmc_marlin_accumulate.json")
     roofline = {"bound": "hbm", "kernel": "accumulate_kernel inside the commitment MSMs (PC::commit of the three AHP rounds)",
                 "achieved": round(commit_bytes / commit_s / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(commit_bytes / commit_s / 1e9 / 8000.0, 5),
@@ -505,7 +505,7 @@ def ntt_roofline(ctx, c, log_n, hbm_meas):
                         "frac_of_measured_peak": round(ach * passes / hbm_meas["value"], 4) if hbm_meas else None,
                         "note": "one pass reads and writes the vector once (64*N bytes)"},
            "valu": {"mulmods_per_element": round(mm, 2), "gmulmod_per_s": round(mm * N / (t_ntt * 1e-3) / 1e9, 1)}}
-    pmc, src = recorded("r04_pmc_ntt.json")
+    pmc, src = recorded("r05_pmc_ntt.json")
     if pmc:
         out["valu_busy_recorded"] = dict(pmc, source=src, kind="recorded",
                                          note="SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES per SIMD of ntt_pass2_kernel (tools/pmc_ntt.sh): the share "
@@ -533,12 +533,15 @@ def cpu_port_block(pk, params, inst, z, c, cores, runs, what, rand_fr):
     import statistics
     r_fix, s_fix = rand_fr(), rand_fr()
     d_out, d_inf = pk.prove_raw(z, r_fix, s_fix)
-    ts, c_out, c_inf, ph = [], None, None, None
+    ts, c_out, c_inf, ph, c_h = [], None, None, None, None
     for _ in range(runs):
         t0 = time.perf_counter()
-        c_out, c_inf, ph = cpu_oracle.groth16_prove(params, inst, z, r_fix, s_fix, threads=cores)
+        # (the last run also hands back the quotient h its proof was made from: no separate witness_map pass for the h comparison;
+        #  the extra 32 N-byte copy is inside the timed call — it favours the device by < 0.1 %)
+        c_out, c_inf, ph, c_h = cpu_oracle.groth16_prove(params, inst, z, r_fix, s_fix, threads=cores, want_h=True)
         ts.append(time.perf_counter() - t0)
-    h_eq = bool(np.array_equal(pk.witness_map(z), cpu_oracle.witness_map(params, inst, z, threads=cores)))
+    h_eq = bool(np.array_equal(pk.witness_map(z), c_h))
+    del c_h
     parity = {"device_eq_cpu_port": bool(np.array_equal(d_out, c_out) and np.array_equal(d_inf, c_inf)),
               "witness_map_eq_cpu_port": h_eq, "instance": what,
               "note": "same (r, s): zkp_groth16_prove vs oracle/cpu groth16_prove, proof limbs + identity flags; "
@@ -774,7 +777,7 @@ def main():
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command recorded under profiles/
         traffic, traffic_src = None, None
         here = os.path.dirname(os.path.abspath(__file__))
-        for name in ("r04_pmc_accumulate.json", "r03_pmc_accumulate.json", "r02_pmc_accumulate.json", "r01_pmc_accumulate.json"):
+        for name in ("r05_pmc_accumulate.json", "r04_pmc_accumulate.json", "r03_pmc_accumulate.json", "r02_pmc_accumulate.json", "r01_pmc_accumulate.json"):
             pmc = os.path.join(here, "profiles", name)
             if primary and os.path.exists(pmc):
                 traffic, traffic_src = json.load(open(pmc))["traffic_bytes_per_launch"], "profiles/" + name

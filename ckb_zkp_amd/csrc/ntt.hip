@@ -30,9 +30,10 @@
 
 namespace zkp {
 
-constexpr int NTT_SMAX = 7;            // max radix bits per pass (default plan)
-// Round 5 experiment (profiles/r05_ntt_two_pass.txt): ZKP_NTT_SMAX=8..10 lets a pass take up to 10 radix bits with the same 1024-element
-// tile (C = 1024 >> S columns per row: 4 / 2 / 1), i.e. 2^20 in two passes (10 + 10) and 2^22 / 2^24 in three (8 + 7 + 7, 8 + 8 + 8).
+constexpr int NTT_SMAX = 9;            // max radix bits per pass (default plan)
+// Round 5 (profiles/r05_ntt_two_pass.txt): a pass takes up to 9 radix bits on the same 1024-element tile (C = 1024 >> S columns per
+// row) — 2^22 .. 2^24 in three passes instead of four (-5 .. -8 % per transform), 2^18 in two; 2^20 / 2^21 keep 7+7+6 / 7+7+7.
+// ZKP_NTT_SMAX=7 restores the round-4 plans; 10 gives 2^20 in two passes (10 + 10, one column per row): measured +14 %, killed.
 // Read once per process (the cached inter-pass tables depend on the plan).
 static int ntt_smax() {
   static const int v = [] {

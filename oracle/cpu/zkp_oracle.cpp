@@ -390,7 +390,7 @@ static void store_affine(const Aff<F>& a, uint64_t* out, uint8_t* inf) {
 // prover.rs:124-211 (after synthesis).  r, s, z: Montgomery Fr.
 template <class FrP, class FqP>
 static void create_proof(const zkp_groth16_pk_desc* d, const uint64_t* z_limbs, const uint64_t* r_l, const uint64_t* s_l,
-                         int threads, uint64_t* proof_out, uint8_t* inf_out, double* phase_ms) {
+                         int threads, uint64_t* proof_out, uint8_t* inf_out, double* phase_ms, uint64_t* h_out = nullptr) {
   using Fr = Fp<FrP>; using G1F = Fp<FqP>; using G2F = Fp2<FqP>;
   const size_t ni = d->num_inputs, na = d->num_aux, nz = ni + na;
   std::vector<Fr> z(nz);
@@ -398,6 +398,7 @@ static void create_proof(const zkp_groth16_pk_desc* d, const uint64_t* z_limbs, 
   auto t0 = std::chrono::steady_clock::now();
   std::vector<Fr> h = witness_map<FrP>(d, z.data(), threads);
   auto t1 = std::chrono::steady_clock::now();
+  if (h_out) memcpy(h_out, h.data(), h.size() * 32);          // the quotient this proof was made from (Montgomery), for the caller's own checks
   // into_repr (prover.rs:150-161)
   std::vector<uint64_t> assignment(4 * (nz - 1)), hrep(4 * h.size());
   for (size_t i = 1; i < nz; i++) z[i].from_mont().to_limbs(&assignment[4 * (i - 1)]);
@@ -570,6 +571,15 @@ int oracle_fr_powers(int curve, const uint64_t* base, const uint64_t* first, siz
   };
   if (curve == ZKP_BN254) run(Bn254FrP{});
   else if (curve == ZKP_BLS12_381) run(Bls381FrP{});
+  else return -1;
+  return 0;
+}
+
+// create_proof that also hands back h = witness_map(z) (domain_size Fr, Montgomery): one pass for tests that compare both
+int oracle_groth16_prove_h(const zkp_groth16_pk_desc* d, const uint64_t* z, const uint64_t* r, const uint64_t* s, int threads,
+                           uint64_t* proof_out, uint8_t* inf_out, double* phase_ms, uint64_t* h_out) {
+  if (d->curve == ZKP_BN254) create_proof<Bn254FrP, Bn254FqP>(d, z, r, s, threads, proof_out, inf_out, phase_ms, h_out);
+  else if (d->curve == ZKP_BLS12_381) create_proof<Bls381FrP, Bls381FqP>(d, z, r, s, threads, proof_out, inf_out, phase_ms, h_out);
   else return -1;
   return 0;
 }

@@ -152,8 +152,9 @@ def witness_map(params, inst, z_mont: np.ndarray, threads: int = 1) -> np.ndarra
     return h
 
 
-def groth16_prove(params, inst, z_mont, r_mont, s_mont, threads: int = 1):
-    """-> (proof limbs, inf flags[3], phase_ms[8]) ; layout identical to zkp_groth16_prove."""
+def groth16_prove(params, inst, z_mont, r_mont, s_mont, threads: int = 1, want_h: bool = False):
+    """-> (proof limbs, inf flags[3], phase_ms[8]) ; layout identical to zkp_groth16_prove.  want_h: a fourth element, the quotient
+    h = witness_map(z) ((N, 4) Montgomery) the proof was made from (saves the separate oracle witness_map pass of the full-size tests)."""
     d, keep = _desc(params, inst)
     fq = params.curve.fq_limbs
     out = np.zeros(8 * fq, dtype=np.uint64)
@@ -161,6 +162,12 @@ def groth16_prove(params, inst, z_mont, r_mont, s_mont, threads: int = 1):
     ph = np.zeros(8, dtype=np.float64)
     z = np.ascontiguousarray(z_mont, dtype=np.uint64)
     r_mont, s_mont = np.ascontiguousarray(r_mont, dtype=np.uint64), np.ascontiguousarray(s_mont, dtype=np.uint64)
+    if want_h:
+        n = inst.num_constraints() + inst.num_inputs
+        h = np.zeros((1 << max(n - 1, 0).bit_length(), 4), dtype=np.uint64)
+        rc = load().oracle_groth16_prove_h(C.byref(d), _p(z), _p(r_mont), _p(s_mont), threads, _p(out), _p(inf), _p(ph), _p(h))
+        assert rc == 0
+        return out, inf, ph, h
     rc = load().oracle_groth16_prove(C.byref(d), _p(z), _p(r_mont), _p(s_mont), threads, _p(out), _p(inf), _p(ph))
     assert rc == 0
     return out, inf, ph

@@ -125,12 +125,14 @@ def test_config5_2p24_single_gpu_and_8way_sharded(ctx):
             from oracle import cpu_oracle
             thr = cpu_oracle.hardware_threads()
             h_dev = pk.witness_map(z)
-            # full-size pin at 2^24: h and the whole proof equal the C++ restatement of the reference (all host threads)
-            assert np.array_equal(h_dev, cpu_oracle.witness_map(params, inst, z, threads=thr))
-            assert not h_dev[-1].any()                          # deg h <= N - 2
             rm, sm = codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0]
             out1, inf1 = pk.prove_raw(zd, rm, sm, z_on_device=True)
-            o_out, o_inf, _ = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=thr)
+            # full-size pin at 2^24: h and the whole proof equal the C++ restatement of the reference (all host threads; ONE oracle
+            # pass returns the proof and the quotient it was made from)
+            o_out, o_inf, _, o_h = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=thr, want_h=True)
+            assert np.array_equal(h_dev, o_h)
+            del o_h
+            assert not h_dev[-1].any()                          # deg h <= N - 2
             assert np.array_equal(out1, o_out) and np.array_equal(inf1, o_inf)
             proof = pk.decode_proof(out1, inf1)
         finally:

@@ -189,13 +189,14 @@ def test_full_size_proof_trapdoor_and_pipeline(ctx, curve, k):
         h_dev = pk.witness_map(z)
         # FULL-SIZE pin of h: the device's witness map equals the C++ restatement of
         # R1CStoQAP::witness_map (r1cs_to_qap.rs:113-172) limb for limb, not just "h[-1] == 0"
-        assert np.array_equal(h_dev, cpu_oracle.witness_map(params, inst, z, threads=thr))
-        assert not h_dev[-1].any()                             # deg h <= N - 2
         r_, s_ = 0x1F2E3D4C5B6A7988, 0x8899AABBCCDDEEFF
         rm, sm = codec.fr_to_mont([r_], c)[0], codec.fr_to_mont([s_], c)[0]
         out, inf = pk.prove_raw(z, rm, sm)
         # ... and of the whole proof: device proof == the C++ restatement of create_proof (prover.rs:124-211) on all host threads
-        o_out, o_inf, _ = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=thr)
+        # (one oracle pass hands back the proof and the quotient h it was made from)
+        o_out, o_inf, _, o_h = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=thr, want_h=True)
+        assert np.array_equal(h_dev, o_h)
+        assert not h_dev[-1].any()                             # deg h <= N - 2
         assert np.array_equal(out, o_out) and np.array_equal(inf, o_inf)
         proof = pk.decode_proof(out, inf)
         # the key's exponents (computed with the library's Fr kernels at this size) re-derived for a sample with Python integers,
