@@ -634,6 +634,21 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   commit_early(ZA_);
   DVec z_b = masked(z_b_ev, fr_of(rnd->z_b));
   poly[ZB_] = z_b;
+  // Round 5: three of the five product-domain transforms of the SECOND round (z_a, z_b and z = w v_X + x over the 4|H| domain) do not
+  // depend on the verifier's first message, and the first round leaves the device under-used while its early commitment MSMs drain
+  // (kernel trace: accumulate 0.4-0.9 of the time, nothing else): they run here instead of alone after alpha is known (3.5 ms of
+  // transforms with no MSM to overlap).  MEASURED NEUTRAL (profiles/r05_marlin_ab.txt: rounds 1 + 2 incl.
+  // commits 16.1 ms without, 16.5 with: the first round's early MSMs simply take the vector ALUs the transforms left, the device is
+  // saturated either way), so it is OFF by default; ZKP_MARLIN_EARLY_FFT=1 enables it; same proof bytes.
+  static const bool early_fft = getenv("ZKP_MARLIN_EARLY_FFT") && atoi(getenv("ZKP_MARLIN_EARLY_FFT")) != 0;
+  DVec z_poly = be.axpy(be.sub(be.shift(w_poly, xs), w_poly), x_poly, F.one_());      // w * v_X + x  (prover.rs:277-281)
+  const size_t r2_size = next_pow2(std::max({mask.n, hs + (z_a.n + z_b.n - 1), hs + z_poly.n}));   // r_alpha and t have |H| coefficients
+  DVec ZA_early, ZB_early, ZZ_early;
+  if (early_fft) {
+    ZA_early = be.fft(z_a, r2_size);
+    ZB_early = be.fft(z_b, r2_size);
+    ZZ_early = be.fft(z_poly, r2_size);
+  }
   const size_t bound[NLAB] = {0, 0, 0, 0, 0, hs - 2, 0, ks - 2, 0};
   Commitment comm[NLAB];
 
@@ -746,14 +761,15 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   DVec t_poly = be.ifft(t_on_h, hs);
   poly[T_] = t_poly;
   commit_early(T_);                                                        // under the product FFTs below
-  DVec z_poly = be.axpy(be.sub(be.shift(w_poly, xs), w_poly), x_poly, one);          // w * v_X + x
   {
     // m(X) = eta_c z_a z_b + eta_a z_a + eta_b z_b (z_a.n + z_b.n - 1 coefficients) is formed pointwise over the product domain
     const size_t m_n = z_a.n + z_b.n - 1;
     const size_t size = next_pow2(std::max({mask.n, r_alpha.n + m_n, t_poly.n + z_poly.n}));
     DVec prod = be.alloc(size);
     {
-      DVec RA = be.fft(r_alpha, size), ZA = be.fft(z_a, size), ZB = be.fft(z_b, size), TT = be.fft(t_poly, size), ZZ = be.fft(z_poly, size);
+      const bool pre = early_fft && size == r2_size;
+      DVec RA = be.fft(r_alpha, size), TT = be.fft(t_poly, size);
+      DVec ZA = pre ? ZA_early : be.fft(z_a, size), ZB = pre ? ZB_early : be.fft(z_b, size), ZZ = pre ? ZZ_early : be.fft(z_poly, size);
       uint64_t kh[3 * 4];
       memcpy(kh, ea.data(), 32);
       memcpy(kh + 4, eb.data(), 32);
@@ -814,6 +830,23 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
     DVec h2 = be.fold(be.sub(a_poly.view(0, 3 * ks - 2), be.pmul(b_poly.view(0, 3 * ks - 2), t3)), ks).first;
     poly[H2_] = h2.view(0, 3 * ks - 3);
   }
+  // Round 5: h_2's commitment starts before the round's host synchronisation, and the seven evaluations at beta (first- and
+  // second-round polynomials: all known since the second round) run under its bucket sort instead of after gamma is known
+  // — MEASURED SLOWER (profiles/r05_marlin_ab.txt: evaluations 1.0 -> 0.8 ms, batch_open +0.7 ms): OFF by default, ZKP_MARLIN_EARLY_EVAL=1 enables
+  static const bool early_eval = getenv("ZKP_MARLIN_EARLY_EVAL") && atoi(getenv("ZKP_MARLIN_EARLY_EVAL")) != 0;
+  uint64_t beta_evals[4 * G2_];
+  if (early_eval) {
+    commit_early(H2_);
+    const uint64_t* qp[G2_];
+    size_t qn[G2_];
+    uint64_t qz[4 * G2_];
+    for (int l = 0; l < G2_; l++) {
+      qp[l] = poly[l].p;
+      qn[l] = poly[l].n;
+      memcpy(qz + 4 * l, beta.data(), 32);
+    }
+    poly_evaluate_batch(ctx, curve, G2_, qp, qn, qz, beta_evals);
+  }
   lap(&tm.ms_round[2]);
   commit_round({G2_, H2_});                                                // lib.rs:124-127
   lap(&tm.ms_commit[2]);
@@ -837,15 +870,23 @@ void marlin_prove(zkp_ctx* ctx, zkp_marlin_index* ix, uint64_t powers_g, uint64_
   std::vector<uint8_t> ev_bytes;
   {
     // all 21 Horner chains are enqueued, then ONE read-back (a host round trip per polynomial cost 2.5 ms of a proof)
-    std::vector<const uint64_t*> qp(query.size());
-    std::vector<size_t> qn(query.size());
-    std::vector<uint64_t> qz(4 * query.size());
+    std::vector<const uint64_t*> qp;
+    std::vector<size_t> qn, slot;
+    std::vector<uint64_t> qz;
     for (size_t i = 0; i < query.size(); i++) {
-      qp[i] = query[i].p.p;
-      qn[i] = query[i].p.n;
-      memcpy(qz.data() + 4 * i, (query[i].at_beta ? beta : gamma).data(), 32);
+      if (early_eval && query[i].at_beta && query[i].l >= 0) {            // evaluated under the h_2 commitment above
+        memcpy(out->evaluations + 4 * i, beta_evals + 4 * query[i].l, 32);
+        continue;
+      }
+      qp.push_back(query[i].p.p);
+      qn.push_back(query[i].p.n);
+      slot.push_back(i);
+      const FrE& pt = query[i].at_beta ? beta : gamma;
+      qz.insert(qz.end(), reinterpret_cast<const uint64_t*>(pt.data()), reinterpret_cast<const uint64_t*>(pt.data()) + 4);
     }
-    poly_evaluate_batch(ctx, curve, query.size(), qp.data(), qn.data(), qz.data(), out->evaluations);
+    std::vector<uint64_t> ev(4 * std::max<size_t>(qp.size(), 1));
+    poly_evaluate_batch(ctx, curve, qp.size(), qp.data(), qn.data(), qz.data(), ev.data());
+    for (size_t k = 0; k < slot.size(); k++) memcpy(out->evaluations + 4 * slot[k], ev.data() + 4 * k, 32);
   }
   for (size_t i = 0; i < query.size(); i++) {
     FrE e{};

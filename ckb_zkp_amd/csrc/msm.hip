@@ -841,7 +841,15 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
   // (per is rounded up to a multiple of 256, so the chunk count is recomputed from it: with a ZKP_MSM_CHUNK that is not a multiple
   //  of 256 the last of the original nch chunks could come out empty — ADVICE r4)
   const size_t nch0 = (n + chunk_pts - 1) / chunk_pts, per = ((n + nch0 - 1) / nch0 + 255) & ~(size_t)255;
-  const size_t nch = (n + per - 1) / per;
+  // Round 5: a SHORT first chunk.  Nothing overlaps the bucket sort of chunk 0 — a lone MSM (Marlin's h_2 commitment and the two
+  // opening witnesses) shows 1-2 ms of sort kernels with the vector ALUs idle before its first accumulate launch (kernel trace,
+  // profiles/r05_marlin_trace.txt) — so chunk 0 is per / ZKP_MSM_CHUNK_FIRST points (default 2: 57.7 -> 56.8 ms per Marlin proof, profiles/r05_marlin_ab.txt; 1 = equal chunks)
+  // and the rest is split evenly.
+  static const size_t first_div = [] { const char* e = getenv("ZKP_MSM_CHUNK_FIRST"); long v = e ? atol(e) : 2; return (size_t)(v < 1 ? 1 : v); }();
+  const size_t first = first_div > 1 ? std::max<size_t>(((per / first_div) + 255) & ~(size_t)255, 1024) : 0;
+  const size_t rest = first && first < n ? n - first : n;
+  const size_t nrest = (rest + per - 1) / per, per_rest = ((rest + nrest - 1) / nrest + 255) & ~(size_t)255;
+  const size_t nch = (first && first < n ? 1 : 0) + (rest + per_rest - 1) / per_rest;
   const int wa = ws_idx, wb = ws_idx ^ 2;                               // partner: 0 <-> 2, 1 <-> 3
   hipStream_t sa = wa == 0 ? ctx->cur->stream : ctx->cur->ws[wa].stream, sb = wb == 0 ? ctx->cur->stream : ctx->cur->ws[wb].stream;
   // the partner's stream joins behind everything this MSM's stream has seen (scalars complete, bucket array of `wa` free)
@@ -849,7 +857,7 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
   ZKP_HIP(hipStreamWaitEvent(sb, ctx->cur->ws[wa].l1_done, 0));
   size_t done = 0;
   for (size_t k = 0; k < nch; k++) {
-    const size_t len = std::min(per, n - done);
+    const size_t len = std::min((k == 0 && first && first < n) ? first : per_rest, n - done);
     const bool last = k + 1 == nch;
     const int w = ((nch - 1 - k) & 1) ? wb : wa;                        // the last chunk runs on `wa`: result, `done` event, read-back
     ctx->msm_defer_reduce = !last;
