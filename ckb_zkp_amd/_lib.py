@@ -137,6 +137,7 @@ SIGNATURES = {
     "zkp_fixed_base_mul_g1": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, vp, vp]),
     "zkp_fixed_base_mul_g2": (C.c_int32, [vp, C.c_int, vp, vp, C.c_size_t, vp, vp]),
     "zkp_groth16_pk_upload": (C.c_int32, [vp, C.POINTER(Groth16PkDesc), C.POINTER(vp)]),
+    "zkp_groth16_pk_upload_ex": (C.c_int32, [vp, C.POINTER(Groth16PkDesc), C.c_uint32, C.POINTER(vp)]),
     "zkp_groth16_pk_upload_shard": (C.c_int32, [vp, C.POINTER(Groth16PkDesc), C.c_int32, C.c_int32, C.POINTER(vp)]),
     "zkp_groth16_partials_bytes": (C.c_int32, [C.c_int, C.POINTER(C.c_size_t)]),
     "zkp_groth16_prove_partials_dev": (C.c_int32, [vp, vp, vp, vp, vp, vp]),

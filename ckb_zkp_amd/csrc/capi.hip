@@ -501,6 +501,10 @@ int32_t zkp_groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, zkp
   if (!desc || !out) return ZKP_ERR_BAD_ARG;
   return guarded(ctx, [&] { *out = groth16_pk_upload(ctx, desc); });
 }
+int32_t zkp_groth16_pk_upload_ex(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, uint32_t flags, zkp_groth16_pk** out) {
+  if (!desc || !out || (flags & ~(uint32_t)ZKP_PK_KEEP_FORM)) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] { *out = groth16_pk_upload(ctx, desc, 0, 0, (int)flags); });
+}
 int32_t zkp_groth16_pk_upload_shard(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, int32_t rank, int32_t world,
                                     zkp_groth16_pk** out) {
   if (!desc || !out || world < 1 || rank < 0 || rank >= world) return ZKP_ERR_BAD_ARG;

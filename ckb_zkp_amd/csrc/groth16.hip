@@ -432,7 +432,7 @@ static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz,
   }
 }
 
-zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, int rank, int world) {
+zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, int rank, int world, int flags) {
   ZKP_REQUIRE(d->curve == ZKP_BN254 || d->curve == ZKP_BLS12_381, ZKP_ERR_UNSUPPORTED_CURVE);
   ZKP_REQUIRE(d->num_inputs >= 1, ZKP_ERR_BAD_ARG);
   ZKP_REQUIRE(world >= 0 && (world == 0 ? rank == 0 : (rank >= 0 && rank < world)), ZKP_ERR_BAD_ARG);
@@ -482,7 +482,9 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
     int lgk = 0;
     {
       const int groups[5] = {1, 1, 2, 1, 1};
-      const size_t ns[5] = {pk->q_n[0], pk->q_n[1], pk->q_n[2], world > 0 ? pk->q_n[3] : (size_t)d->h_len, pk->q_n[4]};
+      // (the evaluation-form H query has N points, one more than the h_len = N - 1 the reference keeps: ADVICE r4)
+      const bool h_eval = !(flags & 1) && !(getenv("ZKP_H_LAGRANGE") && atoi(getenv("ZKP_H_LAGRANGE")) == 0) && d->h_query && h_used > 0;
+      const size_t ns[5] = {pk->q_n[0], pk->q_n[1], pk->q_n[2], world > 0 ? pk->q_n[3] : (h_eval ? pk->N : (size_t)d->h_len), pk->q_n[4]};
       lgk = bases_plan_lgk(ctx, d->curve, groups, ns, 5);
       if (lgk > 0 && getenv("ZKP_DEBUG_MSM")) fprintf(stderr, "[groth16] window tables do not fit: window groups of %d\n", 1 << lgk);
     }
@@ -523,7 +525,10 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
                             (d->b_g1_inf && d->b_g2_inf && memcmp(d->b_g1_inf, d->b_g2_inf, d->b_g1_len) == 0);
       pk->share_b_sort = on && same_inf && bases_same_shape(ctx, pk->hB1, pk->hB2);
     }
-    static const bool lagrange_on = !(getenv("ZKP_H_LAGRANGE") && atoi(getenv("ZKP_H_LAGRANGE")) == 0);
+    // flags bit 0 (zkp_groth16_pk_upload_ex, ZKP_PK_KEEP_FORM): keep the key as given — no group transforms at upload (one-shot and
+    // low-volume callers: the transforms cost ~0.65 s per 2^20 and pay back after ~2000 proofs), 7 transforms per proof
+    static const bool lagrange_env = !(getenv("ZKP_H_LAGRANGE") && atoi(getenv("ZKP_H_LAGRANGE")) == 0);
+    const bool lagrange_on = lagrange_env && !(flags & 1);
     if (lagrange_on && d->h_query && h_used > 0 && pk->log_n >= 1) {
       LagrangeCache& cache = lagrange_cache;
       if (!(lagrange_keep_cache && cache.q == d->h_query && cache.used == h_used && cache.log_n == pk->log_n && cache.curve == d->curve)) {

@@ -89,7 +89,7 @@ void fixed_base_mul(zkp_ctx* ctx, int curve, int group, const uint64_t* base_xy,
                     uint64_t* out_xy, uint8_t* out_inf);
 
 // groth16.hip
-zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, int rank = 0, int world = 0);
+zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, int rank = 0, int world = 0, int flags = 0);
 size_t groth16_partials_bytes(int curve);
 void groth16_prove_partials(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t* z_dev, const uint64_t* r, const uint64_t* s,
                             void* out_dev);

@@ -329,7 +329,8 @@ class ProvingKey:
     shard=(rank, world) keeps 1/world of every query resident (zkp_groth16_pk_upload_shard): such a key yields the
     partial sums of its slices (partials_dev) and refuses to prove on its own."""
 
-    def __init__(self, ctx: Context, params: Parameters, circuit, matrices_only: bool = False, shard=None):
+    def __init__(self, ctx: Context, params: Parameters, circuit, matrices_only: bool = False, shard=None, keep_form: bool = False):
+        """keep_form: zkp_groth16_pk_upload_ex(ZKP_PK_KEEP_FORM) — no evaluation-form transforms at upload (one-shot callers)"""
         self.ctx, self.params, self.curve = ctx, params, params.curve
         self.shard = shard
         inst = _as_instance(self.curve, circuit, assign=False)
@@ -358,7 +359,9 @@ class ProvingKey:
             setattr(d, f"{name}_inf", P(inf.astype(np.uint8)) if len(inf) else None)
             setattr(d, f"{name}_len", len(inf))
         h = C.c_void_p()
-        if shard is None:
+        if shard is None and keep_form:
+            _lib.check(ctx.lib.zkp_groth16_pk_upload_ex(ctx.h, C.byref(d), 1, C.byref(h)), "zkp_groth16_pk_upload_ex")
+        elif shard is None:
             _lib.check(ctx.lib.zkp_groth16_pk_upload(ctx.h, C.byref(d), C.byref(h)), "zkp_groth16_pk_upload")
         else:
             _lib.check(ctx.lib.zkp_groth16_pk_upload_shard(ctx.h, C.byref(d), shard[0], shard[1], C.byref(h)),

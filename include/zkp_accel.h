@@ -46,7 +46,7 @@ typedef enum { ZKP_NTT_FFT = 0, ZKP_NTT_IFFT = 1, ZKP_NTT_COSET_FFT = 2, ZKP_NTT
 typedef struct zkp_ctx zkp_ctx; /* opaque: device, stream, twiddle tables, scratch, resident bases */
 
 const char* zkp_status_string(int32_t status);
-/* "zkp_accel <major.minor> (gfx950)".  0.5 (round 5): per-context lock (see Conventions); ZKP_MULTI_EXCHANGE=rccl also takes the RCCL
+/* "zkp_accel <major.minor> (gfx950)".  0.5 (round 5): per-context lock (see Conventions); zkp_groth16_pk_upload_ex (ZKP_PK_KEEP_FORM); ZKP_MULTI_EXCHANGE=rccl also takes the RCCL
  * exchange with one rank; slots L / H of zkp_groth16_prove_partials_dev are only defined as a SUM for folded / evaluation-form /
  * bucket-chained keys (zkp_groth16_pk_info info[7] says which).  0.4 (round 4): ZKP_ERR_INVALID_POINT for malformed / out-of-subgroup points (0.2 used
  * ZKP_ERR_BAD_ARG), zkp_groth16_multi_info, zkp_bench_hbm_copy, zkp_groth16_points_into_affine; since 0.3 a bucket-chained key returns slot L of
@@ -252,6 +252,12 @@ typedef struct zkp_groth16_pk zkp_groth16_pk; /* opaque device-resident proving 
  * Proofs are the group elements of prover.rs:192-210 for every assignment, satisfying or not; zkp_groth16_witness_map still
  * returns h in coefficient form.  ZKP_H_LAGRANGE=0 / ZKP_C_FOLD=0 keep the key as given (21 instead of 12 transform passes). */
 int32_t zkp_groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, zkp_groth16_pk** out);
+/* The same with flags (ABI 0.5).  ZKP_PK_KEEP_FORM: skip the evaluation-form transforms above — the key stays as `Parameters<E>` holds it
+ * (upload ~0.65 s shorter per 2^20 constraints, a proof runs all 7 transforms of r1cs_to_qap.rs:144-169: 7.0 instead of 6.5 ms at 2^20).
+ * For callers that prove once or a few times per key, e.g. the reference CLI (cli/src/zkp_prove.rs loads a key, proves, exits): the
+ * transforms pay back after ~2000 proofs.  Same proof bytes either way.  Unknown flag bits -> ZKP_ERR_BAD_ARG. */
+#define ZKP_PK_KEEP_FORM 1u
+int32_t zkp_groth16_pk_upload_ex(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, uint32_t flags, zkp_groth16_pk** out);
 int32_t zkp_groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk);
 
 /* R1CStoQAP::witness_map (groth16/src/r1cs_to_qap.rs:113-172): z (num_inputs+num_aux Fr, Montgomery)

@@ -143,6 +143,18 @@ where
         Ok(DeviceProvingKey { ctx, pk, nz: num_inputs + num_aux, _p: std::marker::PhantomData })
     }
 
+    /// `zkp_groth16_pk_upload_ex(ZKP_PK_KEEP_FORM)`: the key stays as `Parameters` holds it — no evaluation-form transforms at upload
+    /// (~0.65 s less per 2^20 constraints), all seven transforms of `witness_map` per proof.  For callers that prove once or a few
+    /// times per key (the reference CLI, cli/src/zkp_prove.rs); the transforms of `upload` pay back after ~2000 proofs.
+    pub fn upload_as_given(ctx: &'c Ctx, key: &KeyRef<G1, G2>, at: &Csr, bt: &Csr, ct: &Csr, num_inputs: usize, num_aux: usize) -> Result<Self, Error> {
+        let mut pk: *mut ffi::zkp_groth16_pk = ptr::null_mut();
+        let st = with_desc(key, at, bt, ct, num_inputs, num_aux, |desc| unsafe {
+            ffi::zkp_groth16_pk_upload_ex(ctx.0, desc, ffi::ZKP_PK_KEEP_FORM, &mut pk)
+        });
+        check(st)?;
+        Ok(DeviceProvingKey { ctx, pk, nz: num_inputs + num_aux, _p: std::marker::PhantomData })
+    }
+
     /// `create_proof(params, circuit, r, s)` minus synthesis: `input_assignment` (with the leading one, prover.rs:143)
     /// and `aux_assignment` as `Fr` elements, r / s as `Fr`.  Returns (A, B, C) affine.
     pub fn prove<F: AbiField>(&self, input_assignment: &[F], aux_assignment: &[F], r: &F, s: &F)

@@ -137,6 +137,40 @@ def test_batch_prove_equals_sequential(ctx):
         pk.free()
 
 
+@pytest.mark.parametrize("curve,k", [("bn254", 11), ("bls12_381", 9)])
+def test_key_kept_as_given_proves_the_same(ctx, curve, k):
+    """zkp_groth16_pk_upload_ex(ZKP_PK_KEEP_FORM) (one-shot callers should not pay the evaluation-form transforms): the key
+    stays in the reference's form (pk_info: no evaluation-form H, no folded C), the proof bytes equal those of the transformed key and
+    oracle/cpu's; an unknown flag bit is refused."""
+    import ctypes as C
+    import numpy as np
+    from ckb_zkp_amd import _lib
+    from ckb_zkp_amd.circuits import samples_for_domain
+    from oracle import cpu_oracle
+    inst = mimc_chain_instance(curve, samples_for_domain(k))
+    params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    c = params.curve
+    z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+    rm, sm = codec.fr_to_mont([0xA5A5A5A5], c)[0], codec.fr_to_mont([0x5A5A5A5A5A], c)[0]
+    pk = groth16.ProvingKey(ctx, params, inst)
+    pk_raw = groth16.ProvingKey(ctx, params, inst, keep_form=True)
+    try:
+        assert pk.table_plan()["h_evaluation_form"] and pk.table_plan()["c_folded_into_l"]
+        assert not pk_raw.table_plan()["h_evaluation_form"] and not pk_raw.table_plan()["c_folded_into_l"]
+        o1, i1 = pk.prove_raw(z, rm, sm)
+        o2, i2 = pk_raw.prove_raw(z, rm, sm)
+        o3, i3, _ = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=4)
+        assert np.array_equal(o1, o2) and np.array_equal(i1, i2)
+        assert np.array_equal(o2, o3) and np.array_equal(i2, i3)
+        assert np.array_equal(pk_raw.witness_map(z), pk.witness_map(z))
+        d, keep = groth16._fill_desc(params, inst)
+        h = C.c_void_p()
+        assert ctx.lib.zkp_groth16_pk_upload_ex(ctx.h, C.byref(d), 6, C.byref(h)) == -1          # ZKP_ERR_BAD_ARG
+    finally:
+        pk.free()
+        pk_raw.free()
+
+
 @pytest.mark.parametrize("curve,k,skew", [("bn254", 12, False), ("bls12_381", 11, False), ("bn254", 13, True)])
 def test_device_keygen_equals_host_keygen(ctx, curve, k, skew):
     """generate_parameters(keygen="device") — the exponent vectors of large synthetic keys computed with the library's Fr vector

@@ -24,7 +24,7 @@ def strip_comments(t):
 
 
 H = strip_comments(HDR)
-DEFINES = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(ZKP_[A-Z0-9_]+)\s+(\d+)", H)}
+DEFINES = {m.group(1): (int(m.group(2)), "u32" if m.group(3) else "usize") for m in re.finditer(r"#define\s+(ZKP_[A-Z0-9_]+)\s+(\d+)(u?)\b", H)}
 
 
 def rust_type(ctype: str) -> str:
@@ -114,7 +114,7 @@ def enums():
 def eval_dim(expr: str) -> int:
     expr = expr.strip()
     for k, v in DEFINES.items():
-        expr = expr.replace(k, str(v))
+        expr = expr.replace(k, str(v[0]))
     assert re.fullmatch(r"[0-9*+ ()]+", expr), expr
     return int(eval(expr))
 
@@ -158,7 +158,7 @@ def main():
         rty = "c_int" if ty in ("zkp_curve_t",) else "i32"
         w(f"pub const {k}: {rty} = {v};\n")
     for k, v in DEFINES.items():
-        w(f"pub const {k}: usize = {v};\n")
+        w(f"pub const {k}: {v[1]} = {v[0]};\n")
     w("\n")
     for name, fields in structs():
         copy = "#[derive(Clone, Copy)]\n" if name in ("zkp_csr", "zkp_groth16_timing") else ""
