@@ -41,6 +41,73 @@ TOXIC = dict(alpha=0x1234567890ABCDEF1, beta=0xFEDCBA09876543211, gamma=0x111111
              delta=0x2222222222222222223, tau=0x3333333333333333335)
 
 
+DETAIL_PATH = os.path.join("gpurun_out", "bench_detail.json")
+LINE_CAP = 4096                      # the driver's parser lost the 21 KB line of round 5: the final stdout line stays under 4 KB
+
+
+def _short(v, n):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "~"
+
+
+def _pick(d, keys, strcap=160):
+    return {k: _short(d[k], strcap) for k in keys if isinstance(d, dict) and k in d} if isinstance(d, dict) else None
+
+
+def compact_line(out):
+    """The ONE stdout line of a bench run (<= LINE_CAP bytes): the contract keys, `roofline`, `cpu_baseline`, both halves of
+    BASELINE.json's metric (`value` and `msm_g1.mops`) and the `summary` digest.  Everything else (per-config blocks, phase
+    timings, notes) goes to DETAIL_PATH, named in `detail`."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline")}
+    line["dtype"] = out.get("dtype")
+    line["data"] = _short(out.get("data"), 60)
+    cfg = out.get("config") or {}
+    line["config"] = {"workload": _short(cfg.get("workload"), 200), **_pick(cfg, ("curve", "log_domain", "parallelism", "key_upload_s"), 90)}
+    if cfg.get("key_form"):
+        line["config"]["key_form"] = _short(cfg["key_form"], 150)
+    rf = out.get("roofline")
+    line["roofline"] = (dict(_pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_kind", "traffic_source",
+                                         "avg_launch_ms", "algorithmic_bytes_per_launch", "algorithmic_bytes", "ms",
+                                         "peak_measured", "frac_of_measured_peak", "from")),
+                             kernel=_short(rf.get("kernel"), 70)) if isinstance(rf, dict) else None)
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = (dict(_pick(cb, ("value", "unit", "cores", "kind", "cpu_model", "s_per_proof", "from")),
+                                 sample=_short(cb.get("sample"), 170)) if isinstance(cb, dict) else None)
+    if isinstance(out.get("msm_g1"), dict):
+        line["msm_g1"] = _pick(out["msm_g1"], ("n", "ms", "mops", "batched_ms", "batched_mops", "window_bits"))
+    if isinstance(out.get("parity_check"), dict):
+        line["parity_check"] = _pick(out["parity_check"], ("device_eq_cpu_port", "witness_map_eq_cpu_port", "instance"), 60)
+    if out.get("scale_parity") is not None:
+        line["scale_parity"] = _pick(out["scale_parity"], ("all_ranks_eq_rank0", "sharded_eq_single_gpu", "all_devices_eq_device0", "ranks"))
+    if isinstance(out.get("exchange"), dict):
+        line["exchange"] = _pick(out["exchange"], ("kind", "ranks", "devices", "bytes_per_rank"), 80)
+    if out.get("summary") is not None:
+        line["summary"] = out["summary"]
+    line["detail"] = out.get("detail")
+    txt = json.dumps(line)
+    if len(txt) >= LINE_CAP:                                # never lose the line: drop the digest before the contract keys
+        for k in ("summary", "exchange", "parity_check"):
+            line.pop(k, None)
+            txt = json.dumps(line)
+            if len(txt) < LINE_CAP:
+                break
+    assert len(txt) < LINE_CAP, len(txt)
+    return txt
+
+
+def emit(out):
+    """full record -> gpurun_out/bench_detail.json (merged back by gpurun; copied into profiles/ per round), compact line -> stdout"""
+    try:
+        os.makedirs(os.path.dirname(DETAIL_PATH), exist_ok=True)
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(out, f)
+        out["detail"] = DETAIL_PATH
+    except OSError as e:
+        out["detail"] = f"not written ({e.__class__.__name__})"
+    log(f"full record ({len(json.dumps(out))} bytes): {out['detail']}")
+    print(compact_line(out), flush=True)
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -67,11 +134,18 @@ def bench_sharded(args, ctx, c, inst, params, z, rank, world, local):
     z_dev = ctx.to_device(z)                                    # witness resident in HBM before the timed region
     # scale_parity, checked BEFORE timing: the sharded proof of a fixed (r, s) == the proof rank 0 computes alone with the whole key
     sharded = prover.prove(z_dev, r_, s_)                       # collective: every rank takes part
-    scale_parity = None
+    scale_parity = roofline = None
     if rank == 0:
         from ckb_zkp_amd import groth16
         pk0 = groth16.ProvingKey(ctx, params, inst)
         single = pk0.prove_raw(z_dev, codec_mont(c, r_), codec_mont(c, s_), z_on_device=True)
+        # per-device roofline of the dominant kernel, measured on rank 0 with the whole key before it is freed (accumulate is
+        # per-point work: a shard runs the same kernel over 1/world of the points)
+        try:
+            roofline, _ = accumulate_roofline(ctx, pk0, c, inst, lambda: pk0.prove_raw(z_dev, codec_mont(c, r_), codec_mont(c, s_), z_on_device=True), None)
+            roofline["from"] = "rank 0, whole key on one device (same kernel a shard runs over 1/world of the points)"
+        except Exception as e:
+            log("roofline on rank 0 failed:", repr(e))
         pk0.free()
         scale_parity = {"sharded_eq_single_gpu": bool(np.array_equal(sharded[0], single[0]) and list(sharded[1]) == list(single[1])),
                         "ranks": world, "note": "one proof with a fixed (r, s): all ranks sharded vs rank 0 alone with the full key"}
@@ -96,7 +170,7 @@ def bench_sharded(args, ctx, c, inst, params, z, rank, world, local):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": f"Groth16 proofs/sec (2^{args.log_n} domain, {c.name}), ONE proof base-sharded over the GPUs",
             "value": round(args.steps / dt, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -111,7 +185,7 @@ def bench_sharded(args, ctx, c, inst, params, z, rank, world, local):
             "exchange": {"kind": "gloo (host-staged, TEST ONLY)" if args.single_device_test else "rccl" if world > 1 else "none",
                          "ranks": world, "call": "torch.distributed.all_gather_into_tensor on device buffers" if world > 1 else None,
                          "bytes_per_rank": prover.pb},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "roofline": roofline, "cpu_baseline": recorded_cpu_baseline(c.name, args.log_n)})
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -188,7 +262,16 @@ def bench_single_process_multi(args):
     sync_all()
     dt = time.perf_counter() - t0
     proofs = args.steps if shard else args.steps * n
-    print(json.dumps({
+    # per-device roofline of the dominant kernel: device 0 alone with its own copy of the whole key (outside the timed region)
+    roofline = None
+    try:
+        pk0 = groth16.ProvingKey(m.member(0), params, inst)
+        roofline, _ = accumulate_roofline(m.member(0), pk0, c, inst, lambda: pk0.prove_raw(zds[0], r_fix, s_fix, z_on_device=True), None)
+        roofline["from"] = "device 0 alone, whole key (per-device figure; the same kernel runs on every device)"
+        pk0.free()
+    except Exception as e:
+        log("per-device roofline failed:", repr(e))
+    emit({
         "metric": "Groth16 proofs/sec (2^20 constraints, BN256)" if (args.log_n == 20 and c.name == "bn254" and not shard)
         else f"Groth16 proofs/sec (2^{args.log_n} domain, {c.name})" + (", ONE proof base-sharded over the GPUs" if shard else ""),
         "value": round(proofs / dt, 4), "unit": "proofs/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -204,7 +287,7 @@ def bench_single_process_multi(args):
         "exchange": (dict(mpk.info(), call="inside zkp_groth16_prove_multi: ncclAllGather when the devices are distinct, else "
                                             "hipMemcpyPeerAsync (said on stderr); witness-map variant measured on proofs 3-4 of the key")
                      if shard else {"kind": "none (independent proofs, replicated key)", "devices": n}),
-        "roofline": None, "cpu_baseline": None}), flush=True)
+        "roofline": roofline, "cpu_baseline": recorded_cpu_baseline(c.name, args.log_n)})
     for k, d in enumerate(zds):
         m.member(k).dev_free(d)
     mpk.free()
@@ -401,14 +484,30 @@ def hbm_peak_block(ctx):
                     "this process; every roofline block quotes its fraction of BOTH peaks"}
 
 
-def recorded(name):
+def recorded(name, quiet=False):
     """a value recorded under profiles/ by a separate rocprofv3 --pmc pass (PMC counters cannot be read from inside the process)"""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     try:
         return json.load(open(path)), "profiles/" + name
     except (OSError, ValueError) as e:
-        log(f"recorded PMC source profiles/{name} unavailable ({e.__class__.__name__}): the fields that quote it stay null")
+        if not quiet:
+            log(f"recorded PMC source profiles/{name} unavailable ({e.__class__.__name__}): the fields that quote it stay null")
         return None, None
+
+
+def recorded_cpu_baseline(curve, log_n):
+    """N > 1 lines: the CPU port is timed on rank 0 at N = 1 only (contract); the multi-GPU lines quote that run's block"""
+    for rnd in ("r06", "r05", "r04"):
+        d, src = recorded(f"{rnd}_bench_bn254_2p20.json", quiet=True)
+        if not d:
+            continue
+        blk = (d.get("cpu_baseline") if (curve, log_n) == ("bn254", 20) else
+               (d.get("bn254_2p24_single_gpu") or {}).get("cpu_baseline") if (curve, log_n) == ("bn254", 24) else
+               (d.get("bls12_381_2p22") or {}).get("cpu_baseline") if (curve, log_n) == ("bls12_381", 22) else None)
+        if isinstance(blk, dict):
+            return dict({k: blk[k] for k in ("value", "unit", "cores", "kind", "cpu_model", "s_per_proof", "sample") if k in blk},
+                        **{"from": f"{src} (the N=1 run of this config on the same box type: the CPU port does not depend on the GPU count)"})
+    return None
 
 
 def with_measured(block, hbm_meas):
@@ -677,12 +776,12 @@ def main():
     if args.workload == "marlin":
         m = bench_marlin(ctx, args.curve, reps=max(args.steps if args.steps != 64 else 3, 1), cpu=not args.no_cpu_baseline)
         if rank == 0:
-            print(json.dumps({"metric": "Marlin proofs/sec (2^20 constraints, BN256)", "value": m["value"], "unit": "proofs/s",
+            emit({"metric": "Marlin proofs/sec (2^20 constraints, BN256)", "value": m["value"], "unit": "proofs/s",
                               "n_gpus": 1, "steps": m["runs"], "warmup": 1, "ms_per_step": round(m["s_per_proof"] * 1e3, 2),
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": "u32 limbs (256-bit Montgomery integers)", "data": "synthetic (MiMC-chain R1CS, trapdoor SRS)",
                               "config": {"workload": m["workload"]}, "roofline": m.pop("roofline"), "cpu_baseline": m.pop("cpu_baseline"),
-                              "marlin": m}), flush=True)
+                              "marlin": m})
         return
     t0 = time.time()
     S = samples_for_domain(args.log_n)
@@ -919,7 +1018,8 @@ def main():
                                    "query once at upload (outside the timed region, like the window tables); 4 instead of 7 transforms per "
                                    "proof, same proof bytes for every assignment (DESIGN.md section 5)",
                        "pipelining": "none" if args.no_pipeline else f"{os.environ.get('ZKP_LANES', '8 (4 above 2^22)')} proofs in flight per GPU (zkp_groth16_prove_batch_dev), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "hbm_peak_measured": hbm_meas,
+            "roofline": roofline, "cpu_baseline": cpu_baseline if world == 1 else recorded_cpu_baseline(c.name, args.log_n),
+            "hbm_peak_measured": hbm_meas,
             "roofline_ntt": roofline_ntt, "roofline_scan": roofline_scan, "valu_roof": valu_roof,
             "with_h2d": with_h2d, "latency": latency, "parity_check": parity_check, "scale_parity": scale_parity,
             "exchange": None if world == 1 else {"kind": "none on the data path (independent proofs per rank, replicated key)",
@@ -930,7 +1030,7 @@ def main():
             "phases_ms": phases, "bench_wall_s": round(time.time() - t_start, 1),
         }
         out["summary"] = summary_block(out, marlin, extra)     # LAST key: the driver keeps the tail of the line
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
