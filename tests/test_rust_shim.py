@@ -146,3 +146,21 @@ def test_every_zkp_accel_path_in_the_patches_resolves_to_a_crate_item():
     # the seam's call shape: the closure handed to get_or_upload builds the key with DeviceProvingKey::upload(accel_cache::ctx(), ..)
     g = (ROOT / "rust" / "patches" / "groth16-accel.diff").read_text()
     assert "use zkp_accel::accel_cache;" in g and "accel_cache::get_or_upload(params" in g and "DeviceProvingKey::upload(accel_cache::ctx()" in g
+
+
+def test_accel_cache_identifies_keys_by_content_not_only_by_address():
+    """a `Parameters` reloaded at the same address must not hit the old device key.  Static shape of the fix:
+    `get_or_upload` takes a `Fingerprint` (buffer spans, circuit shape, content digest), compares it on a hit, uploads under the
+    entry's own lock with the table unlocked, recovers poisoned locks, and leaves the process environment alone."""
+    src = (ROOT / "rust" / "zkp-accel" / "src" / "accel_cache.rs").read_text()
+    code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("//"))
+    assert "pub struct Fingerprint" in code and "pub fn of<" in code
+    for field in ("a_query", "h_query", "l_query", "num_inputs", "num_aux", "nnz", "digest"):
+        assert re.search(rf"pub {field}:", code), field
+    assert re.search(r"pub fn get_or_upload<[^>]*>\(params: &P, print: Fingerprint, upload: F\)", code)
+    assert "s.print == print" in code                        # the hit test
+    assert "set_var" not in code and "into_inner" in code
+    # the table guard is dropped (end of the block that produced `slot`) before upload() runs
+    assert code.index("let slot = {") < code.index("};") < code.index("upload()?")
+    g = (ROOT / "rust" / "patches" / "groth16-accel.diff").read_text()
+    assert "accel_cache::Fingerprint::of(&key" in g and "accel_cache::get_or_upload(params, print," in g
