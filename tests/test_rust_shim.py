@@ -161,6 +161,7 @@ def test_accel_cache_identifies_keys_by_content_not_only_by_address():
     assert "s.print == print" in code                        # the hit test
     assert "set_var" not in code and "into_inner" in code
     # the table guard is dropped (end of the block that produced `slot`) before upload() runs
-    assert code.index("let slot = {") < code.index("};") < code.index("upload()?")
+    a = code.index("let slot = {")
+    assert a < code.index("\n    };", a) < code.index("upload()?")
     g = (ROOT / "rust" / "patches" / "groth16-accel.diff").read_text()
     assert "accel_cache::Fingerprint::of(&key" in g and "accel_cache::get_or_upload(params, print," in g
