@@ -55,6 +55,40 @@ const char* zkp_version(void);
 
 /* ---- context & device memory ------------------------------------------------------------------ */
 int32_t zkp_ctx_create(zkp_ctx** out, int device_id);
+/* Per-context configuration (since 0.6; SURVEY §5 "Config / flags": struct, with the environment as the default).  A field left
+ * at 0 means "default": the environment variable named beside it when the process has it set, else the built-in choice — so
+ * zkp_ctx_create(out, dev) == zkp_ctx_create_ex(out, dev, NULL) and the A/B variables keep working.  A field that is set wins
+ * over the environment and belongs to THIS context only: two contexts of one process may differ (the library keeps no other
+ * prover state outside zkp_ctx).  Switches are tri-state: 0 default, ZKP_ON, ZKP_OFF. */
+enum { ZKP_DEFAULT = 0, ZKP_ON = 1, ZKP_OFF = 2 };
+enum { ZKP_EXCHANGE_AUTO = 0, ZKP_EXCHANGE_RCCL = 1, ZKP_EXCHANGE_PEER = 2 };
+typedef struct zkp_ctx_config {
+  uint32_t struct_size;        /* sizeof(zkp_ctx_config) as the caller compiled it (fields beyond it are defaults); 0 is rejected */
+  int32_t lanes;               /* proofs in flight inside zkp_groth16_prove_batch*: 1..8            [ZKP_LANES; 8, 4 above 2^22] */
+  int32_t msm_batch_lanes;     /* lanes zkp_msm_g1_mont_batch_dev / Marlin's commitments rotate over [ZKP_BATCH_LANES; 1] */
+  int32_t msm_window_bits;     /* bucket-index bits c of resident-table MSMs, 2..22                 [ZKP_MSM_C; round(log2 n) <= 20] */
+  int32_t msm_window_bits_g2;  /* the same for G2 bases                                             [ZKP_MSM_C_G2; as G1] */
+  int64_t msm_chunk_points;    /* lone G1 MSMs of >= 2x this many points run in chunks that share one bucket array; -1 = never
+                                  chunk                                                             [ZKP_MSM_CHUNK; 3 * 2^19] */
+  double table_budget_gb;      /* budget for resident window tables of this context, GiB            [ZKP_TABLE_BUDGET_GB; free
+                                  device memory minus a quarter of the device] */
+  int32_t h_evaluation_form;   /* tri-state: H query transformed to evaluation form at key upload   [ZKP_H_LAGRANGE; on] */
+  int32_t c_fold;              /* tri-state: C matrix folded into the L query at key upload         [ZKP_C_FOLD; on] */
+  int32_t host_affine;         /* tri-state: into_affine of the three proof points on the host      [ZKP_HOST_AFFINE; on] */
+  int64_t c_fold_heavy_cost;   /* a C column above this cost (1 per +-1 coefficient, 380 per general one) leaves the fold kernel
+                                  for one MSM of its own                                            [ZKP_LFOLD_HEAVY_COST; 2000000] */
+  int32_t multi_exchange;      /* ZKP_EXCHANGE_*: partial sums of zkp_groth16_prove_multi           [ZKP_MULTI_EXCHANGE; auto =
+                                  RCCL all-gather when the devices are distinct and librccl loads, else peer copies] */
+  int32_t multi_exchange_timeout_ms; /* watchdog of the RCCL setup and of the first all-gather: when it expires the key falls
+                                  back to peer copies (said on stderr and in zkp_groth16_multi_info)  [ZKP_MULTI_EXCHANGE_TIMEOUT_MS; 30000] */
+  int32_t multi_witness_split; /* tri-state: a / b / c chains of the witness map on devices 0 / 1 / 2 [ZKP_MULTI_WM_SPLIT;
+                                  measured per key on proofs 3-4] */
+} zkp_ctx_config;
+/* cfg == NULL: all defaults.  ZKP_ERR_BAD_ARG for struct_size == 0 or a field out of range. */
+int32_t zkp_ctx_create_ex(zkp_ctx** out, int device_id, const zkp_ctx_config* cfg);
+/* the RESOLVED configuration of a context (defaults replaced by what the context actually uses; 0 where the choice depends on the
+ * job, e.g. lanes / msm_window_bits) */
+int32_t zkp_ctx_get_config(zkp_ctx* ctx, zkp_ctx_config* out);
 int32_t zkp_ctx_destroy(zkp_ctx* ctx);
 /* run on an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 int32_t zkp_ctx_set_stream(zkp_ctx* ctx, void* hip_stream);
