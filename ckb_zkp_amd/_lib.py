@@ -61,6 +61,40 @@ class MarlinRand(C.Structure):
                 ("blind_w", vp), ("blind_z_a", vp), ("blind_z_b", vp), ("blind_g_1", vp), ("blind_shifted_g_1", vp)]
 
 
+class CtxConfig(C.Structure):
+    """zkp_ctx_config (include/zkp_accel.h): 0 = default (environment variable, else built-in); tri-states 1 on / 2 off"""
+    _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_int32), ("msm_batch_lanes", C.c_int32),
+                ("msm_window_bits", C.c_int32), ("msm_window_bits_g2", C.c_int32), ("msm_chunk_points", C.c_int64),
+                ("table_budget_gb", C.c_double), ("h_evaluation_form", C.c_int32), ("c_fold", C.c_int32),
+                ("host_affine", C.c_int32), ("c_fold_heavy_cost", C.c_int64), ("multi_exchange", C.c_int32),
+                ("multi_exchange_timeout_ms", C.c_int32), ("multi_witness_split", C.c_int32)]
+
+
+ZKP_ON, ZKP_OFF = 1, 2
+ZKP_EXCHANGE_AUTO, ZKP_EXCHANGE_RCCL, ZKP_EXCHANGE_PEER = 0, 1, 2
+
+
+def make_config(config) -> "CtxConfig | None":
+    """dict / CtxConfig / None -> CtxConfig with struct_size set.  Booleans map to the tri-state (True = on, False = off)."""
+    if config is None:
+        return None
+    if isinstance(config, CtxConfig):
+        cfg = config
+    else:
+        cfg = CtxConfig()
+        names = {f[0] for f in CtxConfig._fields_} - {"struct_size"}
+        for k, v in dict(config).items():
+            if k not in names:
+                raise KeyError(f"zkp_ctx_config has no field {k!r} (fields: {sorted(names)})")
+            if isinstance(v, bool):
+                v = ZKP_ON if v else ZKP_OFF
+            if k == "multi_exchange" and isinstance(v, str):
+                v = {"auto": ZKP_EXCHANGE_AUTO, "rccl": ZKP_EXCHANGE_RCCL, "peer": ZKP_EXCHANGE_PEER}[v]
+            setattr(cfg, k, v)
+    cfg.struct_size = C.sizeof(CtxConfig)
+    return cfg
+
+
 MARLIN_NUM_EVALS = 21
 
 
@@ -78,8 +112,11 @@ SIGNATURES = {
     "zkp_status_string": (C.c_char_p, [C.c_int32]),
     "zkp_version": (C.c_char_p, []),
     "zkp_ctx_create": (C.c_int32, [C.POINTER(vp), C.c_int]),
+    "zkp_ctx_create_ex": (C.c_int32, [C.POINTER(vp), C.c_int, C.POINTER(CtxConfig)]),
+    "zkp_ctx_get_config": (C.c_int32, [vp, C.POINTER(CtxConfig)]),
     "zkp_ctx_destroy": (C.c_int32, [vp]),
     "zkp_ctx_create_multi": (C.c_int32, [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]),
+    "zkp_ctx_create_multi_ex": (C.c_int32, [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.POINTER(CtxConfig)]),
     "zkp_ctx_num_devices": (C.c_int32, [vp, C.POINTER(C.c_int32)]),
     "zkp_ctx_device": (C.c_int32, [vp, C.c_int32, C.POINTER(vp)]),
     "zkp_groth16_pk_upload_multi": (C.c_int32, [vp, C.POINTER(Groth16PkDesc), C.c_int32, C.POINTER(vp)]),

@@ -26,12 +26,24 @@ def _c64(a) -> np.ndarray:
 class Context:
     """zkp_ctx: device, stream, twiddle tables, scratch, resident bases."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, config=None):
+        """config: None (defaults = environment) or a dict / _lib.CtxConfig of zkp_ctx_config fields for THIS context
+        (zkp_ctx_create_ex), e.g. Context(0, dict(lanes=2, h_evaluation_form=False))."""
         self.lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(self.lib.zkp_ctx_create(C.byref(h), device), "zkp_ctx_create")
+        cfg = _lib.make_config(config)
+        if cfg is None:
+            _lib.check(self.lib.zkp_ctx_create(C.byref(h), device), "zkp_ctx_create")
+        else:
+            _lib.check(self.lib.zkp_ctx_create_ex(C.byref(h), device, C.byref(cfg)), "zkp_ctx_create_ex")
         self.h = h
         self.device = device
+
+    def config(self) -> dict:
+        """the resolved zkp_ctx_config of this context (zkp_ctx_get_config)"""
+        cfg = _lib.CtxConfig()
+        _lib.check(self.lib.zkp_ctx_get_config(self.h, C.byref(cfg)), "zkp_ctx_get_config")
+        return {f[0]: getattr(cfg, f[0]) for f in _lib.CtxConfig._fields_}
 
     def close(self):
         if getattr(self, "h", None):
@@ -390,11 +402,13 @@ class MultiContext(Context):
     step of the base-sharded prover owned by the library.  The object itself is rank 0's context (usable like any
     Context); member(k) borrows rank k's."""
 
-    def __init__(self, device_ids):
+    def __init__(self, device_ids, config=None):
         self.lib = _lib.load()
         ids = (C.c_int * len(device_ids))(*device_ids)
         h = C.c_void_p()
-        _lib.check(self.lib.zkp_ctx_create_multi(C.byref(h), ids, len(device_ids)), "zkp_ctx_create_multi")
+        cfg = _lib.make_config(config)
+        _lib.check(self.lib.zkp_ctx_create_multi_ex(C.byref(h), ids, len(device_ids), C.byref(cfg) if cfg is not None else None),
+                   "zkp_ctx_create_multi_ex")
         self.h = h
         self.device = device_ids[0]
         self.device_ids = list(device_ids)

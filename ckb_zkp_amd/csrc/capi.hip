@@ -33,6 +33,68 @@ int32_t guarded(zkp_ctx* ctx, Fn&& fn) {
   }
 }
 
+// The multi-GPU entry points drive every member context from worker threads through internal functions: they hold the lock of the
+// root AND of every member (rank order: no two callers can take them in opposite orders) for the whole call, so a second thread that
+// enters a member obtained from zkp_ctx_device waits instead of interleaving with a running multi-prove.
+template <class Fn>
+int32_t guarded_multi(zkp_ctx* root, Fn&& fn) {
+  if (!root) return ZKP_ERR_BAD_ARG;
+  std::vector<std::unique_lock<std::recursive_mutex>> member_locks;
+  std::unique_lock<std::recursive_mutex> root_lock(root->mu);
+  for (size_t k = 1; k < root->devs.size(); k++) member_locks.emplace_back(root->devs[k]->mu);
+  return guarded(root, fn);
+}
+
+zkp_cfg cfg_from_env() {
+  zkp_cfg c;
+  auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
+  auto off = [](const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; };
+  c.lanes = (int)num("ZKP_LANES", 0);
+  c.msm_batch_lanes = (int)std::max<long long>(1, std::min<long long>(num("ZKP_BATCH_LANES", 1), zkp_ctx::N_LANES));
+  c.msm_c = (int)num("ZKP_MSM_C", 0);
+  c.msm_c_g2 = (int)num("ZKP_MSM_C_G2", 0);
+  if (const char* e = getenv("ZKP_MSM_CHUNK")) c.msm_chunk = (long long)strtoull(e, nullptr, 0);
+  if (const char* e = getenv("ZKP_TABLE_BUDGET_GB")) c.table_budget_gb = atof(e);
+  c.h_lagrange = !off("ZKP_H_LAGRANGE");
+  c.c_fold = !off("ZKP_C_FOLD");
+  c.host_affine = !off("ZKP_HOST_AFFINE");
+  c.lfold_heavy_cost = num("ZKP_LFOLD_HEAVY_COST", c.lfold_heavy_cost);
+  if (const char* e = getenv("ZKP_MULTI_EXCHANGE")) c.multi_exchange = !strcmp(e, "rccl") ? ZKP_EXCHANGE_RCCL : !strcmp(e, "peer") ? ZKP_EXCHANGE_PEER : ZKP_EXCHANGE_AUTO;
+  c.multi_exchange_timeout_ms = (int)num("ZKP_MULTI_EXCHANGE_TIMEOUT_MS", c.multi_exchange_timeout_ms);
+  c.multi_wm_split = (int)num("ZKP_MULTI_WM_SPLIT", -1);
+  return c;
+}
+
+// zkp_ctx_config (caller's view: 0 = default) -> zkp_cfg (resolved), on top of the environment defaults
+int32_t apply_config(zkp_cfg* c, const zkp_ctx_config* u) {
+  if (!u) return ZKP_OK;
+  if (u->struct_size < sizeof(uint32_t) * 2) return ZKP_ERR_BAD_ARG;
+  zkp_ctx_config f{};                                            // fields beyond the caller's struct_size stay 0 = default
+  memcpy(&f, u, std::min<size_t>(u->struct_size, sizeof f));
+  auto tri_ok = [](int32_t v) { return v == ZKP_DEFAULT || v == ZKP_ON || v == ZKP_OFF; };
+  if (f.lanes < 0 || f.lanes > zkp_ctx::N_LANES || f.msm_batch_lanes < 0 || f.msm_batch_lanes > zkp_ctx::N_LANES) return ZKP_ERR_BAD_ARG;
+  for (int32_t b : {f.msm_window_bits, f.msm_window_bits_g2})
+    if (b != 0 && (b < 2 || b > 22)) return ZKP_ERR_BAD_ARG;
+  if (f.msm_chunk_points < -1 || (f.msm_chunk_points > 0 && f.msm_chunk_points < 1024)) return ZKP_ERR_BAD_ARG;
+  if (!(f.table_budget_gb >= 0.0) || f.c_fold_heavy_cost < 0 || f.multi_exchange_timeout_ms < 0) return ZKP_ERR_BAD_ARG;
+  if (!tri_ok(f.h_evaluation_form) || !tri_ok(f.c_fold) || !tri_ok(f.host_affine) || !tri_ok(f.multi_witness_split)) return ZKP_ERR_BAD_ARG;
+  if (f.multi_exchange < ZKP_EXCHANGE_AUTO || f.multi_exchange > ZKP_EXCHANGE_PEER) return ZKP_ERR_BAD_ARG;
+  if (f.lanes) c->lanes = f.lanes;
+  if (f.msm_batch_lanes) c->msm_batch_lanes = f.msm_batch_lanes;
+  if (f.msm_window_bits) c->msm_c = f.msm_window_bits;
+  if (f.msm_window_bits_g2) c->msm_c_g2 = f.msm_window_bits_g2;
+  if (f.msm_chunk_points) c->msm_chunk = f.msm_chunk_points < 0 ? 0 : f.msm_chunk_points;
+  if (f.table_budget_gb > 0.0) c->table_budget_gb = f.table_budget_gb;
+  if (f.h_evaluation_form) c->h_lagrange = f.h_evaluation_form == ZKP_ON;
+  if (f.c_fold) c->c_fold = f.c_fold == ZKP_ON;
+  if (f.host_affine) c->host_affine = f.host_affine == ZKP_ON;
+  if (f.c_fold_heavy_cost) c->lfold_heavy_cost = f.c_fold_heavy_cost;
+  if (f.multi_exchange) c->multi_exchange = f.multi_exchange;
+  if (f.multi_exchange_timeout_ms) c->multi_exchange_timeout_ms = f.multi_exchange_timeout_ms;
+  if (f.multi_witness_split) c->multi_wm_split = f.multi_witness_split == ZKP_ON ? 1 : 0;
+  return ZKP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -52,11 +114,38 @@ const char* zkp_status_string(int32_t s) {
 }
 
 // 0.2: ZKP_ERR_INVALID_POINT; partials slot 4 (L) = identity, slot 3 (H) = h + l (bucket chaining)
-const char* zkp_version(void) { return "zkp_accel 0.5 (gfx950)"; }
+const char* zkp_version(void) { return "zkp_accel 0.6 (gfx950)"; }
 
-int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
+int32_t zkp_ctx_get_config(zkp_ctx* ctx, zkp_ctx_config* out) {
+  if (!ctx || !out) return ZKP_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    const zkp_cfg& c = ctx->cfg;
+    zkp_ctx_config f{};
+    f.struct_size = sizeof f;
+    f.lanes = c.lanes;
+    f.msm_batch_lanes = c.msm_batch_lanes;
+    f.msm_window_bits = c.msm_c;
+    f.msm_window_bits_g2 = c.msm_c_g2;
+    f.msm_chunk_points = c.msm_chunk > 0 ? c.msm_chunk : -1;
+    f.table_budget_gb = c.table_budget_gb;
+    f.h_evaluation_form = c.h_lagrange ? ZKP_ON : ZKP_OFF;
+    f.c_fold = c.c_fold ? ZKP_ON : ZKP_OFF;
+    f.host_affine = c.host_affine ? ZKP_ON : ZKP_OFF;
+    f.c_fold_heavy_cost = c.lfold_heavy_cost;
+    f.multi_exchange = c.multi_exchange;
+    f.multi_exchange_timeout_ms = c.multi_exchange_timeout_ms;
+    f.multi_witness_split = c.multi_wm_split < 0 ? ZKP_DEFAULT : c.multi_wm_split ? ZKP_ON : ZKP_OFF;
+    *out = f;
+  });
+}
+
+int32_t zkp_ctx_create(zkp_ctx** out, int device_id) { return zkp_ctx_create_ex(out, device_id, nullptr); }
+
+int32_t zkp_ctx_create_ex(zkp_ctx** out, int device_id, const zkp_ctx_config* user_cfg) {
   if (!out) return ZKP_ERR_BAD_ARG;
   *out = nullptr;
+  zkp_cfg cfg = cfg_from_env();
+  if (int32_t st = apply_config(&cfg, user_cfg); st != ZKP_OK) return st;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) {
     fprintf(stderr, "[zkp_accel] no usable HIP device (count=%d, requested %d); there is no CPU fallback\n", count,
@@ -80,6 +169,7 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
   zkp_ctx* ctx = new (std::nothrow) zkp_ctx();
   if (!ctx) return ZKP_ERR_OOM;
   ctx->device = device_id;
+  ctx->cfg = cfg;
   int32_t st = guarded(ctx, [&] {
     ZKP_HIP(hipEventCreate(&ctx->ev0));
     ZKP_HIP(hipEventCreate(&ctx->ev1));
@@ -115,15 +205,19 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id) {
 }
 
 int32_t zkp_ctx_create_multi(zkp_ctx** out, const int* device_ids, int n_devices) {
+  return zkp_ctx_create_multi_ex(out, device_ids, n_devices, nullptr);
+}
+
+int32_t zkp_ctx_create_multi_ex(zkp_ctx** out, const int* device_ids, int n_devices, const zkp_ctx_config* cfg) {
   if (!out || !device_ids || n_devices < 1 || n_devices > 64) return ZKP_ERR_BAD_ARG;
   *out = nullptr;
   zkp_ctx* root = nullptr;
-  int32_t st = zkp_ctx_create(&root, device_ids[0]);
+  int32_t st = zkp_ctx_create_ex(&root, device_ids[0], cfg);
   if (st != ZKP_OK) return st;
   root->devs.push_back(root);
   for (int k = 1; k < n_devices; k++) {
     zkp_ctx* m = nullptr;
-    st = zkp_ctx_create(&m, device_ids[k]);
+    st = zkp_ctx_create_ex(&m, device_ids[k], cfg);
     if (st != ZKP_OK) {
       (void)zkp_ctx_destroy(root);
       return st;
@@ -164,6 +258,7 @@ int32_t zkp_ctx_device(zkp_ctx* ctx, int32_t rank, zkp_ctx** member) {
 
 int32_t zkp_ctx_destroy(zkp_ctx* ctx) {
   if (!ctx) return ZKP_ERR_BAD_ARG;
+  { std::lock_guard<std::recursive_mutex> wait_for_calls_in_flight(ctx->mu); }     // (destroying a context another thread still uses stays the caller's bug)
   for (size_t k = 1; k < ctx->devs.size(); k++) (void)zkp_ctx_destroy(ctx->devs[k]);      // members of a multi-device root
   ctx->devs.clear();
   (void)hipSetDevice(ctx->device);
@@ -249,9 +344,7 @@ int32_t zkp_timer_stop_ms(zkp_ctx* ctx, float* ms) {
   });
 }
 int32_t zkp_set_profiling(zkp_ctx* ctx, int32_t enable) {
-  if (!ctx) return ZKP_ERR_BAD_ARG;
-  ctx->profiling = enable != 0;
-  return ZKP_OK;
+  return guarded(ctx, [&] { ctx->profiling = enable != 0; });
 }
 
 // ------------------------------------------------------------------------------------------- NTT
@@ -527,16 +620,15 @@ int32_t zkp_groth16_fold_assemble_dev(zkp_ctx* ctx, zkp_curve_t curve, const voi
 }
 int32_t zkp_groth16_pk_upload_multi(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, int32_t mode, zkp_groth16_pk_multi** out) {
   if (!ctx || !desc || !out || ctx->devs.empty() || (mode != ZKP_MULTI_SHARD && mode != ZKP_MULTI_REPLICATE)) return ZKP_ERR_BAD_ARG;
-  return guarded(ctx, [&] { *out = groth16_pk_upload_multi(ctx, desc, mode); });
+  return guarded_multi(ctx, [&] { *out = groth16_pk_upload_multi(ctx, desc, mode); });
 }
 int32_t zkp_groth16_pk_multi_free(zkp_ctx* ctx, zkp_groth16_pk_multi* pk) {
   if (!ctx || !pk || ctx->devs.empty()) return ZKP_ERR_BAD_ARG;
-  return guarded(ctx, [&] { groth16_pk_multi_free(ctx, pk); });
+  return guarded_multi(ctx, [&] { groth16_pk_multi_free(ctx, pk); });
 }
 int32_t zkp_groth16_multi_info(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, uint64_t info[6]) {
   if (!ctx || !pk || !info || ctx->devs.empty()) return ZKP_ERR_BAD_ARG;
-  groth16_multi_info(ctx, pk, info);
-  return ZKP_OK;
+  return guarded(ctx, [&] { groth16_multi_info(ctx, pk, info); });
 }
 int32_t zkp_groth16_prove_multi(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, const uint64_t* const* z, int32_t z_on_device,
                                 const uint64_t* r, const uint64_t* s, uint64_t* proof, uint8_t* inf) {
@@ -544,13 +636,13 @@ int32_t zkp_groth16_prove_multi(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, const ui
   if (z_on_device)
     for (size_t k = 0; k < ctx->devs.size(); k++)
       if (!z[k]) return ZKP_ERR_BAD_ARG;
-  return guarded(ctx, [&] { groth16_prove_multi(ctx, pk, z, z_on_device != 0, r, s, proof, inf); });
+  return guarded_multi(ctx, [&] { groth16_prove_multi(ctx, pk, z, z_on_device != 0, r, s, proof, inf); });
 }
 int32_t zkp_groth16_prove_batch_multi(zkp_ctx* ctx, zkp_groth16_pk_multi* pk, size_t count, const uint64_t* const* z,
                                       int32_t z_on_device, const uint64_t* r, const uint64_t* s, uint64_t* proofs,
                                       uint8_t* inf) {
   if (!ctx || !pk || ctx->devs.empty() || (count && (!z || !r || !s || !proofs || !inf))) return ZKP_ERR_BAD_ARG;
-  return guarded(ctx, [&] { groth16_prove_batch_multi(ctx, pk, count, z, z_on_device != 0, r, s, proofs, inf); });
+  return guarded_multi(ctx, [&] { groth16_prove_batch_multi(ctx, pk, count, z, z_on_device != 0, r, s, proofs, inf); });
 }
 int32_t zkp_groth16_pk_free(zkp_ctx* ctx, zkp_groth16_pk* pk) {
   if (!pk) return ZKP_ERR_BAD_ARG;
@@ -637,13 +729,11 @@ int32_t zkp_bench_hbm_copy(zkp_ctx* ctx, size_t bytes, double* out) {
 }
 int32_t zkp_marlin_last_timing(zkp_ctx* ctx, zkp_marlin_timing* out) {
   if (!ctx || !out) return ZKP_ERR_BAD_ARG;
-  *out = ctx->last_marlin_timing;
-  return ZKP_OK;
+  return guarded(ctx, [&] { *out = ctx->last_marlin_timing; });
 }
 int32_t zkp_groth16_last_timing(zkp_ctx* ctx, zkp_groth16_timing* out) {
   if (!ctx || !out) return ZKP_ERR_BAD_ARG;
-  *out = ctx->last_timing;
-  return ZKP_OK;
+  return guarded(ctx, [&] { *out = ctx->last_timing; });
 }
 
 }  // extern "C"

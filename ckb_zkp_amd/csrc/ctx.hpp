@@ -125,8 +125,25 @@ struct zkp_lane {
   bool busy = false;
 };
 
+// Resolved per-context configuration (include/zkp_accel.h zkp_ctx_config): filled from the environment when the context is created
+// (the A/B variables stay the defaults), then overridden field by field by zkp_ctx_create_ex.  Read through ctx->cfg everywhere:
+// no prover switch is process-global.
+struct zkp_cfg {
+  int lanes = 0;                      // 0: 8, 4 above 2^22 (groth16.hip prove_batch)
+  int msm_batch_lanes = 1;
+  int msm_c = 0, msm_c_g2 = 0;        // 0: round(log2 n) <= 20 (msm.hip pick_window_bits)
+  long long msm_chunk = (long long)3 << 19;   // 0: never chunk
+  double table_budget_gb = 0;         // 0: free device memory minus a quarter of the device
+  bool h_lagrange = true, c_fold = true, host_affine = true;
+  long long lfold_heavy_cost = 0;     // 0: chosen per key (groth16.hip fold_c_into_l)
+  int multi_exchange = 0;             // ZKP_EXCHANGE_*
+  int multi_exchange_timeout_ms = 30000;
+  int multi_wm_split = -1;            // -1: measured per key; 0 / 1 forced
+};
+
 struct zkp_ctx {
   int device = 0;
+  zkp_cfg cfg;
   // Every C-ABI entry point that takes this context holds this lock for the whole call (capi.hip guarded()): two host threads entering
   // ONE context are serialised instead of interleaving its lanes / scratch (since ABI 0.5; the documented contract stays "one ctx per
   // prover thread" — that is what runs concurrently).  Recursive: internal helpers may re-enter through a public entry point.

@@ -324,7 +324,12 @@ static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz,
   // double-and-add per general coefficient.  A dense column (the constant-one variable of packing / x * x_inv = 1 constraints, any
   // variable with 1e5+ entries of C) would be a single-lane chain of 1e6-1e8 point operations.  Columns above a cost threshold leave
   // the kernel's CSC and take ONE variable-base MSM each (msm_var_run over the gathered G rows), subtracted on the host below.
-  const size_t heavy_cost = getenv("ZKP_LFOLD_HEAVY_COST") ? (size_t)atoll(getenv("ZKP_LFOLD_HEAVY_COST")) : 50000;
+  // Threshold: a heavy column pays a host gather, an H2D copy and one msm_var_run with a stream sync (~2 ms, about
+  // 4000 lane-serial point operations' worth), one after the other, while the kernel's lanes run side by side and finish with
+  // the LONGEST remaining column.  So the cut is chosen per key: with the column costs sorted descending, k heavy columns cost
+  // about cost[k] + 4000 k — the k that minimises it, never cutting below 50000 (a chain the kernel walks in well under 0.1 s).
+  // A circuit with thousands of medium-dense columns keeps them in the kernel instead of running thousands of serial MSMs.
+  // cfg.lfold_heavy_cost > 0 (zkp_ctx_config.c_fold_heavy_cost / ZKP_LFOLD_HEAVY_COST) fixes the threshold instead.
   HostField::E one = F.one_(), minus_one = F.neg(one);
   std::vector<uint8_t> heavy(nz, 0);
   std::vector<uint32_t> heavy_cols;
@@ -335,14 +340,30 @@ static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz,
       memcpy(c.data(), d->ct.coeff + e * 4, 32);
       cost[d->ct.col[e]] += (c == one || c == minus_one) ? 1 : 380;       // 255 doublings + ~125 additions
     }
+    uint64_t heavy_cost = ctx->cfg.lfold_heavy_cost > 0 ? (uint64_t)ctx->cfg.lfold_heavy_cost : 0;
+    if (!heavy_cost) {
+      const uint64_t floor_cost = 50000, per_msm = 4000;
+      std::vector<uint64_t> big;
+      for (uint64_t c : cost)
+        if (c > floor_cost) big.push_back(c);
+      std::sort(big.begin(), big.end(), std::greater<uint64_t>());
+      heavy_cost = floor_cost;                                   // k = all of `big` heavy
+      uint64_t best = floor_cost + per_msm * big.size();
+      for (size_t k = 0; k < big.size(); k++)                    // k heavy columns, the kernel's longest chain is big[k]
+        if (big[k] + per_msm * k < best) {
+          best = big[k] + per_msm * k;
+          heavy_cost = big[k];
+        }
+    }
     for (size_t m = 0; m < nz; m++)
       if (cost[m] > heavy_cost) {
         heavy[m] = 1;
         heavy_cols.push_back((uint32_t)m);
       }
   }
-  struct HeavyCol { std::vector<uint64_t> xy, sc; std::vector<uint8_t> inf; };
-  std::vector<HeavyCol> hv(heavy_cols.size());
+  // (row, entry) lists of the heavy columns: 8 bytes per entry; the points and coefficients of ONE column at a time are gathered
+  // right before its MSM below (gathering every heavy column up front held 100 bytes per entry on the host)
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> hv(heavy_cols.size());
   if (!heavy_cols.empty()) {
     std::vector<uint32_t> slot(nz, 0);
     for (size_t i = 0; i < heavy_cols.size(); i++) slot[heavy_cols[i]] = (uint32_t)i;
@@ -350,10 +371,7 @@ static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz,
       for (uint32_t e = d->ct.row_ptr[k]; e < d->ct.row_ptr[k + 1]; e++) {
         const uint32_t m = d->ct.col[e];
         if (!heavy[m]) continue;
-        HeavyCol& H = hv[slot[m]];
-        H.xy.insert(H.xy.end(), g_xy.begin() + (size_t)k * 2 * fq, g_xy.begin() + (size_t)(k + 1) * 2 * fq);
-        H.inf.push_back(g_inf[k]);
-        H.sc.insert(H.sc.end(), d->ct.coeff + (size_t)e * 4, d->ct.coeff + (size_t)e * 4 + 4);
+        hv[slot[m]].emplace_back(k, e);
         col_ptr[m + 1]--;                                        // (counts, before the prefix sum below)
       }
   }
@@ -406,9 +424,22 @@ static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz,
     const size_t fw = 2 * fq;                                  // u64 words of an affine point
     std::vector<HostJac> res(heavy_cols.size());
     std::vector<uint64_t> xyz(3 * fq);
+    std::vector<uint64_t> cxy, csc;
+    std::vector<uint8_t> cinf;
     for (size_t i = 0; i < heavy_cols.size(); i++) {
       const uint32_t m = heavy_cols[i];
-      msm_var_run(ctx, d->curve, 1, hv[i].xy.data(), hv[i].inf.data(), hv[i].sc.data(), hv[i].inf.size(), /*montgomery=*/true, xyz.data());
+      const size_t cn = hv[i].size();
+      cxy.resize(cn * fw);
+      csc.resize(cn * 4);
+      cinf.resize(cn);
+      for (size_t j = 0; j < cn; j++) {
+        const uint32_t k = hv[i][j].first, e = hv[i][j].second;
+        memcpy(&cxy[j * fw], &g_xy[(size_t)k * fw], 8 * fw);
+        cinf[j] = g_inf[k];
+        memcpy(&csc[j * 4], d->ct.coeff + (size_t)e * 4, 32);
+      }
+      std::vector<std::pair<uint32_t, uint32_t>>().swap(hv[i]);
+      msm_var_run(ctx, d->curve, 1, cxy.data(), cinf.data(), csc.data(), cn, /*montgomery=*/true, xyz.data());
       HostJac D = host_jac_load(Q, xyz.data());
       D.y = Q.neg(D.y);
       HostJac Lm{};
@@ -479,12 +510,19 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
     pk->q_n[4] = pk->q_n[0];
     // Window-group size for the WHOLE key (msm.hip BasesEntry::lgk): the five queries are sized together so that they keep one
     // window configuration (sort sharing) and their tables fit ZKP_TABLE_BUDGET_GB / the free device memory.
+    // ONE predicate for "the H query goes to evaluation form" (the planning block and the upload below used to evaluate two
+    // different ones): flags bit 0 (zkp_groth16_pk_upload_ex, ZKP_PK_KEEP_FORM) keeps the key as given — no group transforms at upload
+    // (one-shot and low-volume callers: the transforms cost ~0.65 s per 2^20 and pay back after ~2000 proofs), 7 transforms per proof;
+    // zkp_ctx_config.h_evaluation_form / ZKP_H_LAGRANGE switches it per context.
+    const bool lagrange_on = ctx->cfg.h_lagrange && !(flags & 1) && d->h_query && h_used > 0 && pk->log_n >= 1;
     int lgk = 0;
     {
       const int groups[5] = {1, 1, 2, 1, 1};
-      // (the evaluation-form H query has N points, one more than the h_len = N - 1 the reference keeps: ADVICE r4)
-      const bool h_eval = !(flags & 1) && !(getenv("ZKP_H_LAGRANGE") && atoi(getenv("ZKP_H_LAGRANGE")) == 0) && d->h_query && h_used > 0;
-      const size_t ns[5] = {pk->q_n[0], pk->q_n[1], pk->q_n[2], world > 0 ? pk->q_n[3] : (h_eval ? pk->N : (size_t)d->h_len), pk->q_n[4]};
+      // (the evaluation-form H query has N points, one more than the h_len = N - 1 the reference keeps: ADVICE r4; a sharded key
+      //  re-shards it over N, so its slice is planned from N as well)
+      size_t hq_lo = 0, hq_n = pk->q_n[3];
+      if (lagrange_on) shard_bounds(pk->N, rank, world, &hq_lo, &hq_n);
+      const size_t ns[5] = {pk->q_n[0], pk->q_n[1], pk->q_n[2], lagrange_on ? hq_n : (world > 0 ? pk->q_n[3] : (size_t)d->h_len), pk->q_n[4]};
       lgk = bases_plan_lgk(ctx, d->curve, groups, ns, 5);
       if (lgk > 0 && getenv("ZKP_DEBUG_MSM")) fprintf(stderr, "[groth16] window tables do not fit: window groups of %d\n", 1 << lgk);
     }
@@ -507,7 +545,7 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
       int lg2 = 0;
       while (((size_t)2 << lg2) <= std::max<size_t>(live, 1)) lg2++;
       if (lg2 < 62 && (double)live >= 1.41421356 * (double)((size_t)1 << lg2)) lg2++;
-      if (on && world == 0 && live >= ((size_t)1 << 14) && !getenv("ZKP_MSM_C") && !getenv("ZKP_MSM_C_G2")) {
+      if (on && world == 0 && live >= ((size_t)1 << 14) && !ctx->cfg.msm_c && !ctx->cfg.msm_c_g2) {
         cB = std::max(12, std::min(20, lg2 - 2));
         if (const char* e = getenv("ZKP_B_WINDOW_BITS")) cB = atoi(e);
         capB = 32;
@@ -525,11 +563,7 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
                             (d->b_g1_inf && d->b_g2_inf && memcmp(d->b_g1_inf, d->b_g2_inf, d->b_g1_len) == 0);
       pk->share_b_sort = on && same_inf && bases_same_shape(ctx, pk->hB1, pk->hB2);
     }
-    // flags bit 0 (zkp_groth16_pk_upload_ex, ZKP_PK_KEEP_FORM): keep the key as given — no group transforms at upload (one-shot and
-    // low-volume callers: the transforms cost ~0.65 s per 2^20 and pay back after ~2000 proofs), 7 transforms per proof
-    static const bool lagrange_env = !(getenv("ZKP_H_LAGRANGE") && atoi(getenv("ZKP_H_LAGRANGE")) == 0);
-    const bool lagrange_on = lagrange_env && !(flags & 1);
-    if (lagrange_on && d->h_query && h_used > 0 && pk->log_n >= 1) {
+    if (lagrange_on) {
       LagrangeCache& cache = lagrange_cache;
       if (!(lagrange_keep_cache && cache.q == d->h_query && cache.used == h_used && cache.log_n == pk->log_n && cache.curve == d->curve)) {
         lagrange_h(ctx, d->curve, d->h_query, d->h_inf, h_used, pk->log_n, &cache.xy, &cache.inf);
@@ -546,8 +580,7 @@ zkp_groth16_pk* groth16_pk_upload(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, in
     } else
     pk->hH = bases_upload(ctx, d->curve, 1, d->h_query ? d->h_query + pk->q_lo[3] * 2 * fq : nullptr,
                           d->h_inf ? d->h_inf + pk->q_lo[3] : nullptr, world > 0 ? pk->q_n[3] : (size_t)d->h_len, 0, 0, lgk);
-    static const bool cfold_on = !(getenv("ZKP_C_FOLD") && atoi(getenv("ZKP_C_FOLD")) == 0);
-    if (pk->h_lagrange && cfold_on && d->l_query) {
+    if (pk->h_lagrange && ctx->cfg.c_fold && d->l_query) {                // zkp_ctx_config.c_fold / ZKP_C_FOLD
       std::vector<uint64_t> lxy;
       std::vector<uint8_t> linf;
       LagrangeCache& gc = lagrange_cache_g;
@@ -751,9 +784,8 @@ static void prove_enqueue_part(zkp_ctx* ctx, zkp_groth16_pk* pk, const uint64_t*
   zkp_groth16_pk::PerLane& PL = pk->lane[ctx->cur_idx];
   hipStream_t st = ctx->cur->stream;
   const bool prof = ctx->profiling;
-  // ZKP_HOST_AFFINE=0: into_affine of the proof points on the device (rounds 1-3) instead of the host
-  static const bool host_tail_on = !(getenv("ZKP_HOST_AFFINE") && atoi(getenv("ZKP_HOST_AFFINE")) == 0);
-  const bool host_tail = host_tail_on && !partial_out;
+  // zkp_ctx_config.host_affine = ZKP_OFF / ZKP_HOST_AFFINE=0: into_affine of the proof points on the device (rounds 1-3) instead of the host
+  const bool host_tail = ctx->cfg.host_affine && !partial_out;
   zkp_groth16_timing tm{};
   struct ProfEvents {                                   // destroyed on every exit path (msm_run may throw)
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1156,9 +1188,8 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
   size_t pending[zkp_ctx::N_LANES] = {};
   // proofs in flight: 8 lanes x 4 streams = 2 streams per hardware queue (measured optimum at 2^20: 4 lanes 102, 6 lanes 103,
   // 8 lanes 108-110, 12 lanes 104 proofs/s); 4 above 2^22 where a lane's scratch is tens of GB.  ZKP_LANES overrides.
-  static const int lanes_env = [] { const char* e = getenv("ZKP_LANES"); return e ? atoi(e) : 0; }();
-  const int lanes_default = pk->log_n <= 22 ? 8 : 4;
-  const int nl = std::max(1, std::min(lanes_env > 0 ? lanes_env : lanes_default, (int)zkp_ctx::N_LANES));
+  const int lanes_default = pk->log_n <= 22 ? 8 : 4;          // zkp_ctx_config.lanes / ZKP_LANES override it per context
+  const int nl = std::max(1, std::min(ctx->cfg.lanes > 0 ? ctx->cfg.lanes : lanes_default, (int)zkp_ctx::N_LANES));
   auto select = [&](int l) {
     ctx->cur = &ctx->lanes[l];
     ctx->cur_idx = l;
@@ -1229,6 +1260,8 @@ void groth16_prove_batch(zkp_ctx* ctx, zkp_groth16_pk* pk, size_t n, const uint6
 #include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 
 #include <thread>
@@ -1242,7 +1275,8 @@ struct zkp_groth16_pk_multi {
   std::vector<void*> partial;               // per device: 5 XYZZ slots
   // run-time choices of the sharded prover (zkp_groth16_multi_info): which exchange carried the last proof, and whether the
   // three chains of the witness map are split over devices 0..2 — measured on this key's own first proofs, not assumed
-  int exchange = 0;                         // 0 = peer copies, 1 = RCCL all-gather
+  int exchange = 0;                         // 0 = peer copies, 1 = RCCL all-gather, 2 = peer copies after the RCCL watchdog gave up
+  bool exchange_fallback = false;
   int rccl_ranks = 0;
   int split_choice = -1;                    // -1 undecided, 0 replicated witness map, 1 three-way split
   int calls = 0;
@@ -1252,40 +1286,155 @@ namespace zkp {
 
 namespace {
 // RCCL all-gather of the partial sums, resolved at run time (no link-time dependency: the host may already have loaded its
-// own librccl).  Opt-in: ZKP_MULTI_EXCHANGE=rccl; needs distinct devices.  Falls back to peer copies when unavailable.
+// own librccl).  Needs distinct devices.  Falls back to peer copies when unavailable.
+//
+// Watchdog (round 6).  The first multi-rank ncclCommInitAll and the first collective are the two places where a mis-configured
+// node HANGS instead of failing (no IPC handles, a dead link, a peer that never joins), and a hung create_proof is worse than a
+// slow one.  So the whole bring-up — dlopen, ncclCommInitAll, and a PROBE all-gather of 64 bytes per rank on throw-away streams
+// and buffers — runs on a helper thread; the calling thread waits for it with a deadline (zkp_ctx_config.multi_exchange_timeout_ms
+// / ZKP_MULTI_EXCHANGE_TIMEOUT_MS, default 30 s per stage).  The helper polls the probe's streams itself and, when they do not
+// drain in time, aborts the communicators (ncclCommAbort makes RCCL's kernels exit).  Either way — probe failed, or the helper
+// never came back — RCCL is marked unusable for the life of the process, the reason is printed once on stderr, the key's
+// zkp_groth16_multi_info says 2 ("peer copies after the RCCL watchdog"), and the partial sums travel by hipMemcpyPeerAsync.
+// The proof's streams only ever see an all-gather on communicators whose probe completed.
+// ZKP_DEBUG_RCCL_HANG=init | probe simulates the two hangs on any box (tests/test_gpu_multi.py).
 struct RcclApi {
-  void* lib = nullptr;
-  int (*CommInitAll)(void**, int, const int*) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  struct Fns {
+    void* lib = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  };
+  // what the helper thread and the caller share; the caller may walk away from it (shared_ptr keeps it alive for a helper
+  // that returns late)
+  struct Attempt {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, ok = false, abandoned = false;
+    Fns f;
+    std::vector<void*> comms;
+    std::string why;
+  };
+  Fns f;
   std::vector<void*> comms;
   std::vector<int> devices;
-  bool ready(const std::vector<zkp_ctx*>& devs) {
+  bool unusable = false, watchdog_fired = false;
+  std::string why;
+
+  static void bring_up(std::shared_ptr<Attempt> at, std::vector<int> ids, int timeout_ms) {
+    const char* hang = getenv("ZKP_DEBUG_RCCL_HANG");
+    Fns f;
+    std::vector<void*> comms(ids.size(), nullptr);
+    std::string why;
+    bool ok = false;
+    do {
+      for (const char* name : {"librccl.so", "librccl.so.1"})
+        if ((f.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+      if (!f.lib) { why = "librccl.so not loadable"; break; }
+      f.CommInitAll = reinterpret_cast<decltype(f.CommInitAll)>(dlsym(f.lib, "ncclCommInitAll"));
+      f.CommDestroy = reinterpret_cast<decltype(f.CommDestroy)>(dlsym(f.lib, "ncclCommDestroy"));
+      f.CommAbort = reinterpret_cast<decltype(f.CommAbort)>(dlsym(f.lib, "ncclCommAbort"));
+      f.GroupStart = reinterpret_cast<decltype(f.GroupStart)>(dlsym(f.lib, "ncclGroupStart"));
+      f.GroupEnd = reinterpret_cast<decltype(f.GroupEnd)>(dlsym(f.lib, "ncclGroupEnd"));
+      f.AllGather = reinterpret_cast<decltype(f.AllGather)>(dlsym(f.lib, "ncclAllGather"));
+      if (!f.CommInitAll || !f.CommDestroy || !f.GroupStart || !f.GroupEnd || !f.AllGather) { why = "librccl.so lacks a symbol"; break; }
+      if (hang && !strcmp(hang, "init")) std::this_thread::sleep_for(std::chrono::hours(24));      // simulated: ncclCommInitAll never returns
+      if (f.CommInitAll(comms.data(), (int)ids.size(), ids.data()) != 0) { why = "ncclCommInitAll failed"; comms.clear(); break; }
+      // probe: one all-gather of 64 bytes per rank on streams and buffers nothing else uses
+      const int n = (int)ids.size();
+      std::vector<hipStream_t> st(n, nullptr);
+      std::vector<void*> snd(n, nullptr), rcv(n, nullptr);
+      bool issued = true;
+      for (int k = 0; k < n && issued; k++)
+        issued = hipSetDevice(ids[k]) == hipSuccess && hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) == hipSuccess &&
+                 hipMalloc(&snd[k], 64) == hipSuccess && hipMalloc(&rcv[k], 64 * (size_t)n) == hipSuccess &&
+                 hipMemsetAsync(snd[k], k + 1, 64, st[k]) == hipSuccess;
+      if (issued) {
+        issued = f.GroupStart() == 0;
+        for (int k = 0; k < n && issued; k++)
+          issued = hipSetDevice(ids[k]) == hipSuccess && f.AllGather(snd[k], rcv[k], 64, /*ncclUint8*/ 1, comms[k], st[k]) == 0;
+        issued = f.GroupEnd() == 0 && issued;
+      }
+      bool drained = false, right = true;
+      if (issued) {
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+        while (!drained && std::chrono::steady_clock::now() < deadline) {
+          drained = !(hang && !strcmp(hang, "probe"));                                     // simulated: the collective never completes
+          for (int k = 0; k < n && drained; k++) drained = hipStreamQuery(st[k]) == hipSuccess;
+          if (!drained) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        if (drained) {                                                                   // every rank holds byte k + 1 in slot k
+          std::vector<uint8_t> got(64 * (size_t)n);
+          for (int k = 0; k < n && right; k++) {
+            right = hipSetDevice(ids[k]) == hipSuccess && hipMemcpy(got.data(), rcv[k], got.size(), hipMemcpyDeviceToHost) == hipSuccess;
+            for (int j = 0; j < n && right; j++) right = got[64 * (size_t)j] == (uint8_t)(j + 1) && got[64 * (size_t)j + 63] == (uint8_t)(j + 1);
+          }
+        }
+      }
+      if (!issued || !drained || !right) {
+        why = !issued ? "the probe all-gather could not be enqueued" : !drained ? "the probe all-gather did not complete within " + std::to_string(timeout_ms) + " ms"
+                      : "the probe all-gather returned wrong bytes";
+        for (void* c : comms)
+          if (c) (void)(f.CommAbort ? f.CommAbort(c) : f.CommDestroy(c));
+        comms.clear();
+        if (!drained) break;                                                             // streams may still be wedged: leak the probe's resources
+      }
+      for (int k = 0; k < n; k++) {
+        (void)hipSetDevice(ids[k]);
+        if (st[k]) (void)hipStreamDestroy(st[k]);
+        if (snd[k]) (void)hipFree(snd[k]);
+        if (rcv[k]) (void)hipFree(rcv[k]);
+      }
+      ok = issued && drained && right;
+    } while (false);
+    std::lock_guard<std::mutex> lk(at->m);
+    if (at->abandoned) {                                  // the caller gave up on this attempt: nobody will use these communicators
+      for (void* c : comms)
+        if (c && f.CommAbort) (void)f.CommAbort(c);
+      return;
+    }
+    at->f = f;
+    at->comms = ok ? comms : std::vector<void*>();
+    at->ok = ok;
+    at->why = why;
+    at->done = true;
+    at->cv.notify_all();
+  }
+
+  bool ready(const std::vector<zkp_ctx*>& devs, int timeout_ms) {
+    if (unusable) return false;
     std::vector<int> ids;
     for (zkp_ctx* d : devs) ids.push_back(d->device);
     if (!comms.empty() && ids == devices) return true;
     for (size_t i = 0; i < ids.size(); i++)
       for (size_t j = i + 1; j < ids.size(); j++)
-        if (ids[i] == ids[j]) return false;                         // RCCL refuses duplicate devices
-    if (!lib) {
-      for (const char* name : {"librccl.so", "librccl.so.1"})
-        if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
-      if (!lib) return false;
-      CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
-      CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
-      GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
-      GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
-      AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
-    }
-    if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !AllGather) return false;
-    for (void* c : comms) (void)CommDestroy(c);
-    comms.assign(ids.size(), nullptr);
-    if (CommInitAll(comms.data(), (int)ids.size(), ids.data()) != 0) {
-      comms.clear();
+        if (ids[i] == ids[j]) { why = "duplicate device ids"; return false; }             // RCCL refuses duplicate devices (not sticky)
+    for (void* c : comms) (void)f.CommDestroy(c);                                          // another device set: new communicators
+    comms.clear();
+    timeout_ms = std::max(1, timeout_ms);
+    auto at = std::make_shared<Attempt>();
+    std::thread(bring_up, at, ids, timeout_ms).detach();
+    std::unique_lock<std::mutex> lk(at->m);
+    // two stages on the helper (communicator setup, probe), one deadline each, and a margin for the teardown
+    const bool back = at->cv.wait_for(lk, std::chrono::milliseconds(2 * (long long)timeout_ms + 2000), [&] { return at->done; });
+    if (!back) {
+      at->abandoned = true;
+      unusable = watchdog_fired = true;
+      why = "RCCL bring-up (ncclCommInitAll + probe all-gather) did not return within " + std::to_string(2 * (long long)timeout_ms + 2000) + " ms";
       return false;
     }
+    f = at->f;
+    if (!at->ok) {
+      why = at->why;
+      // a missing library is an ordinary "unavailable"; a failed init or probe is what the watchdog exists for
+      unusable = true;
+      watchdog_fired = f.lib != nullptr && at->why != "librccl.so lacks a symbol";
+      return false;
+    }
+    comms = at->comms;
     devices = ids;
     return true;
   }
@@ -1351,7 +1500,7 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
   // and on the domain, so the key MEASURES it: proofs 1-2 warm both variants up, proofs 3-4 time them (wall clock of the whole
   // call, same witness), from proof 5 on the faster one runs.  The proof bytes do not depend on the choice.
   // ZKP_MULTI_WM_SPLIT=0 / 1 forces a variant.
-  static const int split_env = getenv("ZKP_MULTI_WM_SPLIT") ? atoi(getenv("ZKP_MULTI_WM_SPLIT")) : -1;
+  const int split_env = root->cfg.multi_wm_split;               // zkp_ctx_config.multi_witness_split / ZKP_MULTI_WM_SPLIT
   bool split = false;
   const int call = M->calls++;
   if (n >= 3) {
@@ -1366,18 +1515,21 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
   // otherwise, said once on stderr.  ZKP_MULTI_EXCHANGE=peer / rccl forces one.
   // ZKP_MULTI_EXCHANGE=rccl also takes the RCCL branch with ONE rank (a one-rank ncclCommInitAll + ncclAllGather is legal): the
   // hand-declared prototypes below get executed on a one-GPU box (tests/test_gpu_multi.py) before any 8-GPU node sees them.
-  const std::string want = getenv("ZKP_MULTI_EXCHANGE") ? getenv("ZKP_MULTI_EXCHANGE") : "auto";    // read per call
+  const int want = root->cfg.multi_exchange;                     // zkp_ctx_config.multi_exchange / ZKP_MULTI_EXCHANGE, per context
   bool use_rccl = false;
-  if ((n > 1 && want != "peer") || (n == 1 && want == "rccl")) {
-    use_rccl = rccl().ready(root->devs);
+  if ((n > 1 && want != ZKP_EXCHANGE_PEER) || (n == 1 && want == ZKP_EXCHANGE_RCCL)) {
+    static std::mutex rccl_mu;                                   // the communicators are process-wide: one bring-up at a time
+    std::lock_guard<std::mutex> lk(rccl_mu);
+    use_rccl = rccl().ready(root->devs, root->cfg.multi_exchange_timeout_ms);
     static bool told = false;
     if (!use_rccl && !told) {
       told = true;
-      fprintf(stderr, "[zkp_accel] sharded prover: RCCL all-gather unavailable (%s) — the partial sums travel by peer copies\n",
-              rccl().lib ? "duplicate device ids or ncclCommInitAll failed" : "librccl.so not loadable");
+      fprintf(stderr, "[zkp_accel] sharded prover: RCCL all-gather unavailable (%s)%s — the partial sums travel by peer copies\n",
+              rccl().why.c_str(), rccl().watchdog_fired ? " [watchdog: RCCL stays off for this process]" : "");
     }
+    if (!use_rccl && rccl().watchdog_fired) M->exchange_fallback = true;
   }
-  M->exchange = use_rccl ? 1 : 0;
+  M->exchange = use_rccl ? 1 : (M->exchange_fallback ? 2 : 0);
   M->rccl_ranks = use_rccl ? n : 0;
   std::vector<uint32_t*> S(n), h(n, nullptr);
   std::vector<char*> res(n);
@@ -1466,13 +1618,13 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
   const void* gathered = M->gathered;
   if (use_rccl) {
     RcclApi& R = rccl();
-    ZKP_REQUIRE(R.GroupStart() == 0, ZKP_ERR_DEVICE);
+    ZKP_REQUIRE(R.f.GroupStart() == 0, ZKP_ERR_DEVICE);
     for (int k = 0; k < n; k++) {
       ZKP_HIP(hipSetDevice(root->devs[k]->device));
-      ZKP_REQUIRE(R.AllGather(M->partial[k], M->gathered_all[k], pb, /*ncclUint8*/ 1, R.comms[k], root->devs[k]->cur->stream) == 0,
+      ZKP_REQUIRE(R.f.AllGather(M->partial[k], M->gathered_all[k], pb, /*ncclUint8*/ 1, R.comms[k], root->devs[k]->cur->stream) == 0,
                   ZKP_ERR_DEVICE);
     }
-    ZKP_REQUIRE(R.GroupEnd() == 0, ZKP_ERR_DEVICE);
+    ZKP_REQUIRE(R.f.GroupEnd() == 0, ZKP_ERR_DEVICE);
     gathered = M->gathered_all[0];
     ZKP_HIP(hipSetDevice(c0->device));
   } else {

@@ -41,7 +41,7 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy_hos
                       int c_hint = 0, int cap_hint = 0, int lgk_hint = -1);
 // bytes of the resident window tables of n points at group size 2^lgk, and the smallest lgk whose tables (sum over `count`
 // queries) fit the budget
-size_t bases_table_bytes(int curve, int group, size_t n, int lgk);
+size_t bases_table_bytes(zkp_ctx* ctx, int curve, int group, size_t n, int lgk);
 int bases_plan_lgk(zkp_ctx* ctx, int curve, const int* groups, const size_t* ns, int count);
 void bases_free(zkp_ctx* ctx, uint64_t handle);
 uint64_t bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t handle);

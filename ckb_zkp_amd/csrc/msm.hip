@@ -94,17 +94,9 @@ struct BasesEntry {
   }
 };
 
-static int pick_window_bits(size_t n, int group) {
-  if (group == 2) {
-    if (const char* e = getenv("ZKP_MSM_C_G2")) {
-      int c = atoi(e);
-      if (c >= 2 && c <= 22) return c;
-    }
-  }
-  if (const char* e = getenv("ZKP_MSM_C")) {
-    int c = atoi(e);
-    if (c >= 2 && c <= 22) return c;
-  }
+static int pick_window_bits(const zkp_cfg& cfg, size_t n, int group) {
+  if (group == 2 && cfg.msm_c_g2 >= 2 && cfg.msm_c_g2 <= 22) return cfg.msm_c_g2;       // zkp_ctx_config.msm_window_bits_g2 / ZKP_MSM_C_G2
+  if (cfg.msm_c >= 2 && cfg.msm_c <= 22) return cfg.msm_c;                                // zkp_ctx_config.msm_window_bits / ZKP_MSM_C
   int lg = 0;
   while (((size_t)2 << lg) <= n) lg++;          // floor(log2 n)
   if (lg < 63 && (double)n >= 1.41421356 * (double)((size_t)1 << lg)) lg++;   // round(log2 n): 2^20 - 1 -> 20
@@ -115,9 +107,9 @@ static int pick_window_bits(size_t n, int group) {
 struct WindowPlan {
   int c, W, wide, lgk, J;
 };
-static WindowPlan window_plan(int scalar_bits, size_t n, int group, int c_hint, int lgk) {
+static WindowPlan window_plan(const zkp_cfg& cfg, int scalar_bits, size_t n, int group, int c_hint, int lgk) {
   static const bool balanced = !(getenv("ZKP_MSM_BALANCED") && atoi(getenv("ZKP_MSM_BALANCED")) == 0);
-  const int T = scalar_bits + 1, c0 = c_hint >= 2 && c_hint <= 22 ? c_hint : pick_window_bits(n, group);
+  const int T = scalar_bits + 1, c0 = c_hint >= 2 && c_hint <= 22 ? c_hint : pick_window_bits(cfg, n, group);
   WindowPlan p{};
   if (lgk <= 0) {
     // Balanced windows: T = scalar_bits + 1 (one spare bit absorbs the last signed-digit carry) is spread over W = ceil(T / c)
@@ -144,9 +136,9 @@ static WindowPlan window_plan(int scalar_bits, size_t n, int group, int c_hint, 
   p.J = (p.W + (1 << p.lgk) - 1) >> p.lgk;
   return p;
 }
-size_t bases_table_bytes(int curve, int group, size_t n, int lgk) {
+size_t bases_table_bytes(zkp_ctx* ctx, int curve, int group, size_t n, int lgk) {
   const MsmVtbl* vt = msm_vtbl(curve, group);
-  return std::max<size_t>(1, n) * (size_t)window_plan(vt->scalar_bits, n, group, 0, lgk).J * vt->aff_bytes;
+  return std::max<size_t>(1, n) * (size_t)window_plan(ctx->cfg, vt->scalar_bits, n, group, 0, lgk).J * vt->aff_bytes;
 }
 // Budget for resident window tables: ZKP_TABLE_BUDGET_GB (whole context) if set, else the free device memory minus a quarter of
 // the device for MSM / NTT scratch; what the context already holds is subtracted.
@@ -154,8 +146,8 @@ static double table_budget_left(zkp_ctx* ctx) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 1e30;
   double left = (double)free_b - 0.25 * (double)total_b;
-  if (const char* e = getenv("ZKP_TABLE_BUDGET_GB")) {
-    const double b = atof(e) * 1073741824.0 - (double)ctx->table_bytes;
+  if (ctx->cfg.table_budget_gb > 0.0) {                          // zkp_ctx_config.table_budget_gb / ZKP_TABLE_BUDGET_GB
+    const double b = ctx->cfg.table_budget_gb * 1073741824.0 - (double)ctx->table_bytes;
     left = std::min(left + 0.25 * (double)total_b - 1073741824.0, b);     // an explicit budget only keeps 1 GiB back
   }
   return left;
@@ -169,7 +161,7 @@ int bases_plan_lgk(zkp_ctx* ctx, int curve, const int* groups, const size_t* ns,
   const double left = table_budget_left(ctx);
   for (int lgk = 0; lgk <= 6; lgk++) {
     double need = 0;
-    for (int q = 0; q < count; q++) need += (double)bases_table_bytes(curve, groups[q], ns[q], lgk);
+    for (int q = 0; q < count; q++) need += (double)bases_table_bytes(ctx, curve, groups[q], ns[q], lgk);
     if (need <= left) return lgk;
   }
   return 6;                                                      // one copy per query: let the allocation decide
@@ -188,7 +180,7 @@ uint64_t bases_upload(zkp_ctx* ctx, int curve, int group, const uint64_t* xy, co
   // reduction tail of (c k - 1) doublings.
   int lgk = lgk_hint;
   if (lgk < 0) lgk = c_hint > 0 ? 0 : bases_plan_lgk(ctx, curve, &group, &n, 1);
-  const WindowPlan wp = window_plan(e->vt->scalar_bits, n, group, c_hint, lgk);
+  const WindowPlan wp = window_plan(ctx->cfg, e->vt->scalar_bits, n, group, c_hint, lgk);
   e->c = wp.c;
   e->W = wp.W;
   e->wide = wp.wide;
@@ -828,8 +820,7 @@ void msm_run(zkp_ctx* ctx, uint64_t handle, size_t offset, const uint64_t* scala
   // scratch), so that the sort of chunk k + 1 runs under the accumulation of chunk k.  The result is the same group element.
   // ZKP_MSM_CHUNK=<points per chunk> (0 = off); not for MSMs that share a sort, belong to a sort group, are profiled, or are
   // part of a caller's own bucket chain.
-  const char* ce = getenv("ZKP_MSM_CHUNK");
-  const size_t chunk_pts = ce ? (size_t)strtoull(ce, nullptr, 0) : ((size_t)3 << 19);
+  const size_t chunk_pts = (size_t)std::max<long long>(0, ctx->cfg.msm_chunk);        // zkp_ctx_config.msm_chunk_points / ZKP_MSM_CHUNK
   const bool chunkable = chunk_pts >= 1024 && n >= 2 * chunk_pts && be->group == 1 && !be->var && sort_src < 0 && l1_src < 0 &&
                          !be->group_flags && !ctx->profiling && !ms_accumulate && !ms_scan && !n_entries &&
                          !ctx->msm_defer_reduce && ctx->msm_acc_into < 0 && ctx->msm_bucket_ws < 0 && !ctx->batch_mode;
@@ -1225,7 +1216,7 @@ void msm_run_multi(zkp_ctx* ctx, size_t count, const uint64_t* handles, const si
     ctx->pinned_cap = count * jw * 4 + 4096;
   }
   constexpr int NW = zkp_lane::N_WS_MSM;                          // MSM workspaces (stream + scratch) per lane
-  static const int NL = [] { const char* e = getenv("ZKP_BATCH_LANES"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > zkp_ctx::N_LANES ? zkp_ctx::N_LANES : v); }();
+  const int NL = std::max(1, std::min(ctx->cfg.msm_batch_lanes, (int)zkp_ctx::N_LANES));      // zkp_ctx_config.msm_batch_lanes / ZKP_BATCH_LANES
   // job k runs on lane (k / NW) % NL, workspace k % NW: up to NL * NW MSMs in flight, one hardware queue each
   auto stream_of = [&](int li, int w) { return w == 0 ? ctx->lanes[li].stream : ctx->lanes[li].ws[w].stream; };
   struct Restore {                                               // msm_run may throw: always hand the context back on lane L

@@ -333,6 +333,11 @@ class ProvingKey:
         """keep_form: zkp_groth16_pk_upload_ex(ZKP_PK_KEEP_FORM) — no evaluation-form transforms at upload (one-shot callers)"""
         self.ctx, self.params, self.curve = ctx, params, params.curve
         self.shard = shard
+        if shard is not None and keep_form:
+            # zkp_groth16_pk_upload_shard has no flags argument: a sharded key always takes the context's key form
+            # (zkp_ctx_config.h_evaluation_form / c_fold select it per context).  Silently ignoring the request was ADVICE r5.
+            raise ValueError("keep_form applies to unsharded keys (zkp_groth16_pk_upload_ex); for a sharded key create the "
+                             "context with dict(h_evaluation_form=False, c_fold=False)")
         inst = _as_instance(self.curve, circuit, assign=False)
         assert (inst.num_inputs, inst.num_aux, inst.num_constraints()) == \
             (params.num_inputs, params.num_aux, params.num_constraints)
@@ -513,7 +518,7 @@ class MultiProvingKey:
         """zkp_groth16_multi_info: what the last sharded proof did (exchange, witness-map variant and its measured times)"""
         v = (C.c_uint64 * 6)()
         _lib.check(self.ctx.lib.zkp_groth16_multi_info(self.ctx.h, self.h, v), "zkp_groth16_multi_info")
-        return {"exchange": "rccl" if v[0] else "peer", "rccl_ranks": int(v[1]),
+        return {"exchange": ("peer", "rccl", "peer (rccl watchdog gave up)")[min(int(v[0]), 2)], "rccl_ranks": int(v[1]),
                 "witness_map": ("replicated", "split over devices 0..2", "measuring")[int(v[2])],
                 "ms_replicated": v[3] / 1e3, "ms_split": v[4] / 1e3, "devices": int(v[5])}
 

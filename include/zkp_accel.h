@@ -15,7 +15,9 @@
  *     host variants copy in/out and synchronise;
  *   - one in-flight call per ctx; create one ctx per prover thread / per GPU (one process per GPU): contexts on one device run
  *     concurrently from different host threads (the reference may prove from several rayon threads).  Since 0.5 every entry point
- *     holds a per-context lock for the whole call, so two threads entering the SAME ctx are serialised, never interleaved.
+ *     that takes a ctx holds its lock for the whole call, so two threads entering the SAME ctx are serialised, never interleaved
+ *     (0.6: zkp_set_profiling / zkp_*_last_timing too; the zkp_*_multi entry points hold the root's and every member's lock;
+ *     zkp_ctx_destroy waits for a call in flight — destroying a context another thread still uses stays the caller's bug).
  */
 #ifndef ZKP_ACCEL_H
 #define ZKP_ACCEL_H
@@ -46,7 +48,9 @@ typedef enum { ZKP_NTT_FFT = 0, ZKP_NTT_IFFT = 1, ZKP_NTT_COSET_FFT = 2, ZKP_NTT
 typedef struct zkp_ctx zkp_ctx; /* opaque: device, stream, twiddle tables, scratch, resident bases */
 
 const char* zkp_status_string(int32_t status);
-/* "zkp_accel <major.minor> (gfx950)".  0.5 (round 5): per-context lock (see Conventions); zkp_groth16_pk_upload_ex (ZKP_PK_KEEP_FORM); ZKP_MULTI_EXCHANGE=rccl also takes the RCCL
+/* "zkp_accel <major.minor> (gfx950)".  0.6 (round 6): zkp_ctx_config / zkp_ctx_create_ex / zkp_ctx_create_multi_ex / zkp_ctx_get_config (the
+ * prover switches are per context; the environment only supplies defaults, read when the context is created); RCCL bring-up behind a
+ * watchdog (zkp_groth16_multi_info info[0] == 2); the multi-GPU entry points lock every member context.  0.5 (round 5): per-context lock (see Conventions); zkp_groth16_pk_upload_ex (ZKP_PK_KEEP_FORM); ZKP_MULTI_EXCHANGE=rccl also takes the RCCL
  * exchange with one rank; slots L / H of zkp_groth16_prove_partials_dev are only defined as a SUM for folded / evaluation-form /
  * bucket-chained keys (zkp_groth16_pk_info info[7] says which).  0.4 (round 4): ZKP_ERR_INVALID_POINT for malformed / out-of-subgroup points (0.2 used
  * ZKP_ERR_BAD_ARG), zkp_groth16_multi_info, zkp_bench_hbm_copy, zkp_groth16_points_into_affine; since 0.3 a bucket-chained key returns slot L of
@@ -60,9 +64,9 @@ int32_t zkp_ctx_create(zkp_ctx** out, int device_id);
  * zkp_ctx_create(out, dev) == zkp_ctx_create_ex(out, dev, NULL) and the A/B variables keep working.  A field that is set wins
  * over the environment and belongs to THIS context only: two contexts of one process may differ (the library keeps no other
  * prover state outside zkp_ctx).  Switches are tri-state: 0 default, ZKP_ON, ZKP_OFF. */
-enum { ZKP_DEFAULT = 0, ZKP_ON = 1, ZKP_OFF = 2 };
-enum { ZKP_EXCHANGE_AUTO = 0, ZKP_EXCHANGE_RCCL = 1, ZKP_EXCHANGE_PEER = 2 };
-typedef struct zkp_ctx_config {
+typedef enum { ZKP_DEFAULT = 0, ZKP_ON = 1, ZKP_OFF = 2 } zkp_tristate;
+typedef enum { ZKP_EXCHANGE_AUTO = 0, ZKP_EXCHANGE_RCCL = 1, ZKP_EXCHANGE_PEER = 2 } zkp_exchange;
+typedef struct {
   uint32_t struct_size;        /* sizeof(zkp_ctx_config) as the caller compiled it (fields beyond it are defaults); 0 is rejected */
   int32_t lanes;               /* proofs in flight inside zkp_groth16_prove_batch*: 1..8            [ZKP_LANES; 8, 4 above 2^22] */
   int32_t msm_batch_lanes;     /* lanes zkp_msm_g1_mont_batch_dev / Marlin's commitments rotate over [ZKP_BATCH_LANES; 1] */
@@ -76,7 +80,8 @@ typedef struct zkp_ctx_config {
   int32_t c_fold;              /* tri-state: C matrix folded into the L query at key upload         [ZKP_C_FOLD; on] */
   int32_t host_affine;         /* tri-state: into_affine of the three proof points on the host      [ZKP_HOST_AFFINE; on] */
   int64_t c_fold_heavy_cost;   /* a C column above this cost (1 per +-1 coefficient, 380 per general one) leaves the fold kernel
-                                  for one MSM of its own                                            [ZKP_LFOLD_HEAVY_COST; 2000000] */
+                                  for one MSM of its own                                            [ZKP_LFOLD_HEAVY_COST; chosen per
+                                  key: the cut that minimises longest kernel chain + 4000 per heavy column, never below 50000] */
   int32_t multi_exchange;      /* ZKP_EXCHANGE_*: partial sums of zkp_groth16_prove_multi           [ZKP_MULTI_EXCHANGE; auto =
                                   RCCL all-gather when the devices are distinct and librccl loads, else peer copies] */
   int32_t multi_exchange_timeout_ms; /* watchdog of the RCCL setup and of the first all-gather: when it expires the key falls
@@ -379,7 +384,9 @@ int32_t zkp_groth16_fold_assemble_dev(zkp_ctx* ctx, zkp_curve_t curve, const voi
  *                          the faster from proof 5 on; the proof bytes do not depend on it (ZKP_MULTI_WM_SPLIT=0 / 1
  *                          forces).  z_on_device == 0: z[0] is the host assignment; != 0: z[k] is a device pointer on rank
  *                          k's device, k < n.
- *   zkp_groth16_multi_info  what the last zkp_groth16_prove_multi did: info[0] = exchange (0 peer copies, 1 RCCL all-gather),
+ *   zkp_groth16_multi_info  what the last zkp_groth16_prove_multi did: info[0] = exchange (0 peer copies, 1 RCCL all-gather, 2 peer copies because
+ *                          the RCCL watchdog gave up: ncclCommInitAll or the probe all-gather failed or did not return within
+ *                          zkp_ctx_config.multi_exchange_timeout_ms — RCCL then stays off for the process),
  *                          info[1] = RCCL ranks, info[2] = witness map (0 replicated, 1 split, 2 still measuring), info[3] /
  *                          info[4] = microseconds of the timed proof with the replicated / split map (0 = not measured),
  *                          info[5] = devices.
@@ -389,6 +396,8 @@ int32_t zkp_groth16_fold_assemble_dev(zkp_ctx* ctx, zkp_curve_t curve, const voi
 typedef struct zkp_groth16_pk_multi zkp_groth16_pk_multi;
 typedef enum { ZKP_MULTI_SHARD = 0, ZKP_MULTI_REPLICATE = 1 } zkp_multi_mode;
 int32_t zkp_ctx_create_multi(zkp_ctx** out, const int* device_ids, int n_devices);
+/* the same with a configuration applied to the root and every member (cfg == NULL: defaults) */
+int32_t zkp_ctx_create_multi_ex(zkp_ctx** out, const int* device_ids, int n_devices, const zkp_ctx_config* cfg);
 int32_t zkp_ctx_num_devices(zkp_ctx* ctx, int32_t* n);
 int32_t zkp_ctx_device(zkp_ctx* ctx, int32_t rank, zkp_ctx** member);
 int32_t zkp_groth16_pk_upload_multi(zkp_ctx* ctx, const zkp_groth16_pk_desc* desc, int32_t mode,

@@ -95,6 +95,61 @@ impl Ctx {
         check(unsafe { ffi::zkp_ctx_create(&mut p, device_id as c_int) })?;
         Ok(Ctx(p))
     }
+
+    /// `zkp_ctx_create_ex`: a context with its own configuration (ABI 0.6).  Fields left at 0 are defaults (the environment
+    /// variable named in the header when set, else the built-in choice); two contexts of one process may differ:
+    /// `Ctx::with_config(0, &CtxConfig { lanes: 2, h_evaluation_form: ffi::ZKP_OFF, ..CtxConfig::default() })`.
+    pub fn with_config(device_id: i32, cfg: &CtxConfig) -> Result<Self, Error> {
+        let mut p: *mut ffi::zkp_ctx = ptr::null_mut();
+        let raw = cfg.to_ffi();
+        check(unsafe { ffi::zkp_ctx_create_ex(&mut p, device_id as c_int, &raw) })?;
+        Ok(Ctx(p))
+    }
+
+    /// The resolved configuration of this context (`zkp_ctx_get_config`).
+    pub fn config(&self) -> Result<ffi::zkp_ctx_config, Error> {
+        let mut raw: ffi::zkp_ctx_config = unsafe { std::mem::zeroed() };
+        check(unsafe { ffi::zkp_ctx_get_config(self.0, &mut raw) })?;
+        Ok(raw)
+    }
+}
+
+/// `zkp_ctx_config` without the `struct_size` bookkeeping (`to_ffi` fills it in).  `Default` = every field default.
+#[derive(Clone, Copy, Debug, Default, PartialEq)]
+pub struct CtxConfig {
+    pub lanes: i32,
+    pub msm_batch_lanes: i32,
+    pub msm_window_bits: i32,
+    pub msm_window_bits_g2: i32,
+    pub msm_chunk_points: i64,
+    pub table_budget_gb: f64,
+    pub h_evaluation_form: i32,
+    pub c_fold: i32,
+    pub host_affine: i32,
+    pub c_fold_heavy_cost: i64,
+    pub multi_exchange: i32,
+    pub multi_exchange_timeout_ms: i32,
+    pub multi_witness_split: i32,
+}
+impl CtxConfig {
+    pub fn to_ffi(&self) -> ffi::zkp_ctx_config {
+        ffi::zkp_ctx_config {
+            struct_size: std::mem::size_of::<ffi::zkp_ctx_config>() as u32,
+            lanes: self.lanes,
+            msm_batch_lanes: self.msm_batch_lanes,
+            msm_window_bits: self.msm_window_bits,
+            msm_window_bits_g2: self.msm_window_bits_g2,
+            msm_chunk_points: self.msm_chunk_points,
+            table_budget_gb: self.table_budget_gb,
+            h_evaluation_form: self.h_evaluation_form,
+            c_fold: self.c_fold,
+            host_affine: self.host_affine,
+            c_fold_heavy_cost: self.c_fold_heavy_cost,
+            multi_exchange: self.multi_exchange,
+            multi_exchange_timeout_ms: self.multi_exchange_timeout_ms,
+            multi_witness_split: self.multi_witness_split,
+        }
+    }
 }
 impl Drop for Ctx {
     fn drop(&mut self) {
@@ -114,6 +169,16 @@ impl MultiCtx {
         let ids: Vec<c_int> = device_ids.iter().map(|&d| d as c_int).collect();
         let mut p: *mut ffi::zkp_ctx = ptr::null_mut();
         check(unsafe { ffi::zkp_ctx_create_multi(&mut p, ids.as_ptr(), ids.len() as c_int) })?;
+        Ok(MultiCtx { root: Ctx(p), num_devices: ids.len() })
+    }
+
+    /// `zkp_ctx_create_multi_ex`: the configuration applies to the root and to every member (e.g. `multi_exchange`,
+    /// `multi_exchange_timeout_ms` for the RCCL bring-up watchdog).
+    pub fn with_config(device_ids: &[i32], cfg: &CtxConfig) -> Result<Self, Error> {
+        let ids: Vec<c_int> = device_ids.iter().map(|&d| d as c_int).collect();
+        let mut p: *mut ffi::zkp_ctx = ptr::null_mut();
+        let raw = cfg.to_ffi();
+        check(unsafe { ffi::zkp_ctx_create_multi_ex(&mut p, ids.as_ptr(), ids.len() as c_int, &raw) })?;
         Ok(MultiCtx { root: Ctx(p), num_devices: ids.len() })
     }
 }

@@ -217,21 +217,25 @@ class _DenseColumnCircuit:
                        lambda lc, k1=k1, k2=k2: (lc + (k1, cs.one()) + (k2, hub)) if k2 else (lc + (k1, cs.one())))
 
 
-@pytest.mark.parametrize("curve,rows,cost", [("bn254", 300, "3"), ("bls12_381", 90, "3"), ("bn254", 700, "50000")])
-def test_groth16_dense_c_column_takes_the_heavy_fold_path(ctx, curve, rows, cost, monkeypatch):
-    """fold_c_into_l (csrc/groth16.hip): columns of C above ZKP_LFOLD_HEAVY_COST leave the one-lane-per-variable kernel and take one
-    variable-base MSM each; the proof and witness map still equal oracle/cpu's.  cost = 3 forces nearly every column through the MSM
-    path; the default 50000 with 700 rows sends exactly the two dense columns (constant one + hub) there."""
+@pytest.mark.parametrize("curve,rows,cost", [("bn254", 300, 3), ("bls12_381", 90, 3), ("bn254", 700, 50000), ("bn254", 700, 0)])
+def test_groth16_dense_c_column_takes_the_heavy_fold_path(ctx, curve, rows, cost):
+    """fold_c_into_l (csrc/groth16.hip): columns of C above zkp_ctx_config.c_fold_heavy_cost leave the one-lane-per-variable kernel and
+    take one variable-base MSM each (gathered one column at a time); the proof and witness map still equal oracle/cpu's.  cost = 3
+    forces nearly every column through the MSM path; 50000 with 700 rows sends exactly the two dense columns (constant one + hub)
+    there; 0 = the default, a cut chosen per key (longest kernel chain + 4000 per heavy column minimised: the same two columns here).
+    The key is uploaded through a context of its own with that configuration; the session context generates the parameters."""
     from ckb_zkp_amd import groth16
+    from ckb_zkp_amd.api import Context
     from ckb_zkp_amd.r1cs import ConstraintSystem, R1csInstance
-    monkeypatch.setenv("ZKP_LFOLD_HEAVY_COST", cost)
+    own = Context(ctx.device, dict(c_fold_heavy_cost=cost) if cost else None)
+    assert own.config()["c_fold_heavy_cost"] == cost
     c = get_curve(curve)
     toxic = dict(alpha=0x7654321, beta=0x1ABCDE, gamma=0xF0145, delta=0x67ABC, tau=0xDEF01236789)
     cs = ConstraintSystem(c, True)
     _DenseColumnCircuit(curve, 4242 + rows, rows).generate_constraints(cs)
     inst = R1csInstance.from_cs(cs)
     params = groth16.generate_parameters(ctx, c, inst, **toxic)
-    pk = groth16.ProvingKey(ctx, params, inst)
+    pk = groth16.ProvingKey(own, params, inst)
     try:
         assert pk.table_plan()["c_folded_into_l"]
         z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
@@ -244,6 +248,7 @@ def test_groth16_dense_c_column_takes_the_heavy_fold_path(ctx, curve, rows, cost
             assert np.array_equal(out, o_out) and np.array_equal(inf, o_inf)
     finally:
         pk.free()
+        own.close()
 
 
 @pytest.mark.parametrize("curve,seed,ni,nc", [("bn254", 1, 1, 5), ("bn254", 2, 0, 9), ("bls12_381", 3, 1, 6), ("bn254", 4, 3, 14), ("bls12_381", 5, 0, 3), ("bn254", 6, 1, 30), ("bls12_381", 7, 3, 21)])

@@ -375,9 +375,10 @@ def test_msm_many_long_buckets(ctx, curve, group, log_n, distinct):
 
 
 @pytest.mark.parametrize("chunk,n", [(40000, (1 << 18) - 3), (1 << 16, (1 << 18) + 777), (100000, 300001)])
-def test_chunked_msm_equals_unchunked_and_known_dlog(ctx, monkeypatch, chunk, n):
+def test_chunked_msm_equals_unchunked_and_known_dlog(ctx, chunk, n):
     """Round 4: a large stand-alone G1 MSM is split by index into chunks that share one bucket array (bucket chaining) on two
-    workspaces, so that the sort of chunk k + 1 runs under the accumulation of chunk k (msm.hip msm_run, ZKP_MSM_CHUNK).  Odd and even
+    workspaces, so that the sort of chunk k + 1 runs under the accumulation of chunk k (msm.hip msm_run; zkp_ctx_config.msm_chunk_points:
+    the chunked and the never-chunking context below share ONE resident table, zkp_bases_share).  Odd and even
     chunk counts, a ragged last chunk, zero / one / r - 1 scalars and identity bases: the result equals the unchunked MSM and the
     known-discrete-log expectation, call after call (the workspaces are reused)."""
     curve = "bn254"
@@ -390,7 +391,12 @@ def test_chunked_msm_equals_unchunked_and_known_dlog(ctx, monkeypatch, chunk, n)
     g_xy, _ = to_abi_points(curve, 1, [G.gen])
     xy, inf = ctx.fixed_base_mul(c, 1, g_xy, d)
     assert inf[5] == 1
-    bases = ctx.upload_bases(c, 1, xy, inf)
+    from ckb_zkp_amd.api import Context
+    plain_ctx = Context(ctx.device, dict(msm_chunk_points=-1))    # never chunks
+    chunk_ctx = Context(ctx.device, dict(msm_chunk_points=chunk)) # chunks MSMs of >= 2 * chunk points
+    assert plain_ctx.config()["msm_chunk_points"] == -1 and chunk_ctx.config()["msm_chunk_points"] == chunk
+    bases0 = ctx.upload_bases(c, 1, xy, inf)
+    plain_b, bases = bases0.share_with(plain_ctx), bases0.share_with(chunk_ctx)
     k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     k[:, 3] >>= np.uint64(4)
     k[7] = 0
@@ -401,10 +407,8 @@ def test_chunked_msm_equals_unchunked_and_known_dlog(ctx, monkeypatch, chunk, n)
     try:
         e = sum(a * b for a, b in zip(codec.limbs_to_ints(d), codec.limbs_to_ints(k))) % c.r
         want = G.mul(G.gen, e)
-        monkeypatch.setenv("ZKP_MSM_CHUNK", "0")
-        plain = jac_limbs_to_affine_oracle(curve, 1, bases.msm(k))
+        plain = jac_limbs_to_affine_oracle(curve, 1, plain_b.msm(k))
         assert plain == want
-        monkeypatch.setenv("ZKP_MSM_CHUNK", str(chunk))
         for _ in range(3):
             assert jac_limbs_to_affine_oracle(curve, 1, bases.msm(k)) == want
         # Montgomery-scalar batch entry point (PC::commit): two chunked MSMs in flight on partner workspaces + two plain ones
@@ -412,10 +416,13 @@ def test_chunked_msm_equals_unchunked_and_known_dlog(ctx, monkeypatch, chunk, n)
         kd = ctx.to_device(km)
         outs = bases.msm_mont_batch_dev([(kd, n, 0), (kd, n, 0), (kd, 1000, 0), (kd + 32 * 10, n - 10, 10)])
         assert jac_limbs_to_affine_oracle(curve, 1, outs[0]) == want and jac_limbs_to_affine_oracle(curve, 1, outs[1]) == want
-        monkeypatch.setenv("ZKP_MSM_CHUNK", "0")
-        ref = bases.msm_mont_batch_dev([(kd, 1000, 0), (kd + 32 * 10, n - 10, 10)])
+        ref = plain_b.msm_mont_batch_dev([(kd, 1000, 0), (kd + 32 * 10, n - 10, 10)])
         assert np.array_equal(jac_limbs_to_affine_oracle(curve, 1, outs[2]), jac_limbs_to_affine_oracle(curve, 1, ref[0]))
         assert jac_limbs_to_affine_oracle(curve, 1, outs[3]) == jac_limbs_to_affine_oracle(curve, 1, ref[1])
         ctx.dev_free(kd)
     finally:
+        plain_b.free()
         bases.free()
+        bases0.free()
+        plain_ctx.close()
+        chunk_ctx.close()

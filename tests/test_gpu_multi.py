@@ -122,6 +122,50 @@ m.close()
     assert "INFO rccl 1 1" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
+@pytest.mark.parametrize("hang", ["init", "probe"])
+def test_rccl_watchdog_falls_back_to_peer_copies(ctx, hang):
+    """VERDICT r5 task 6a: the first multi-rank ncclCommInitAll / collective is where a mis-configured node hangs instead of failing.
+    The RCCL bring-up (dlopen + ncclCommInitAll + a probe all-gather on throw-away streams) runs on a helper thread under a deadline
+    (zkp_ctx_config.multi_exchange_timeout_ms); ZKP_DEBUG_RCCL_HANG simulates a ncclCommInitAll that never returns ("init") and a
+    collective that never completes ("probe").  Either way the call must come back: the proof equals the single-GPU proof, the
+    partial sums travelled by peer copies, zkp_groth16_multi_info says so (exchange 2) and stderr names the watchdog.  The
+    configuration goes through zkp_ctx_create_multi_ex, not the environment."""
+    code = r'''
+import time
+import numpy as np
+from ckb_zkp_amd import codec, groth16
+from ckb_zkp_amd.api import MultiContext
+from ckb_zkp_amd.circuits import mimc_chain_instance, samples_for_domain
+TOXIC = dict(alpha=11, beta=13, gamma=17, delta=19, tau=23)
+m = MultiContext([0], dict(multi_exchange="rccl", multi_exchange_timeout_ms=400))
+assert m.config()["multi_exchange"] == 1 and m.config()["multi_exchange_timeout_ms"] == 400
+inst = mimc_chain_instance("bn254", samples_for_domain(10))
+params = groth16.generate_parameters(m, "bn254", inst, **TOXIC)
+c = params.curve
+z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+rm, sm = codec.fr_to_mont([0x1234567], c)[0], codec.fr_to_mont([0x7654321], c)[0]
+pk = groth16.ProvingKey(m, params, inst)
+want = pk.prove_raw(z, rm, sm)
+pk.free()
+mpk = groth16.MultiProvingKey(m, params, inst, groth16.MULTI_SHARD)
+t = time.time()
+for rep in range(3):
+    got = mpk.prove_raw(z, rm, sm)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), rep
+print("INFO", mpk.info()["exchange"], "|", round(time.time() - t, 1))
+mpk.free()
+m.close()
+'''
+    env = dict(os.environ, ZKP_DEBUG_RCCL_HANG=hang, PYTHONPATH=ROOT)
+    env.pop("ZKP_MULTI_EXCHANGE", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("INFO")][0]
+    assert "peer (rccl watchdog gave up)" in line, (line, out.stderr[-1500:])
+    assert float(line.split("|")[1]) < 30.0                      # deadline 0.4 s per stage: the three proofs return in seconds
+    assert "watchdog" in out.stderr and "peer copies" in out.stderr
+
+
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_prove_batch_multi_replicated_equals_sequential(ctx, world):
     """Throughput mode through the C boundary: n independent proofs dealt round-robin over `world` ranks (one host thread

@@ -179,3 +179,27 @@ def test_host_into_affine_of_the_proof_points_matches_the_oracle(curve):
         if b is None:
             assert not out[2 * f:6 * f].any()
     assert lib.zkp_groth16_points_into_affine(c.cid, None, None, None, None, None) != 0
+
+
+def test_keep_form_with_a_sharded_key_is_refused_not_ignored():
+    """zkp_groth16_pk_upload_shard has no flags argument; ProvingKey(shard=..., keep_form=True) used to drop the request
+    silently.  It raises before anything touches a device."""
+    from types import SimpleNamespace
+    with pytest.raises(ValueError, match="keep_form"):
+        groth16.ProvingKey(None, SimpleNamespace(curve=get_curve("bn254")), None, shard=(0, 2), keep_form=True)
+
+
+def test_ctx_config_struct_matches_the_header_field_for_field():
+    """_lib.CtxConfig mirrors `zkp_ctx_config` (include/zkp_accel.h): same field names, order and C types."""
+    import re
+    from pathlib import Path
+    from ckb_zkp_amd import _lib
+    import ctypes as C
+    hdr = (Path(__file__).resolve().parent.parent / "include" / "zkp_accel.h").read_text()
+    body = re.search(r"typedef struct \{(.*?)\} zkp_ctx_config;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(uint32_t|int32_t|int64_t|double)\s+([a-z_0-9]+)\s*;", body)
+    ctype = {"uint32_t": C.c_uint32, "int32_t": C.c_int32, "int64_t": C.c_int64, "double": C.c_double}
+    assert [(n, ctype[t]) for t, n in fields] == list(_lib.CtxConfig._fields_)
+    cfg = _lib.make_config(dict(lanes=3, h_evaluation_form=False, c_fold=True, multi_exchange="peer"))
+    assert (cfg.struct_size, cfg.lanes, cfg.h_evaluation_form, cfg.c_fold, cfg.multi_exchange) == (C.sizeof(_lib.CtxConfig), 3, 2, 1, 2)

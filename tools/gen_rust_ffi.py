@@ -12,10 +12,10 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 HDR = (ROOT / "include" / "zkp_accel.h").read_text()
 
-SCALAR = {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "int": "c_int", "float": "f32",
+SCALAR = {"int32_t": "i32", "int64_t": "i64", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "int": "c_int", "float": "f32",
           "double": "f64", "uint8_t": "u8", "void": "c_void", "char": "c_char", "zkp_curve_t": "c_int"}
 OPAQUE = ["zkp_ctx", "zkp_groth16_pk", "zkp_groth16_pk_multi", "zkp_fs_rng", "zkp_marlin_index"]
-STRUCTS = ["zkp_csr", "zkp_groth16_pk_desc", "zkp_marlin_index_desc", "zkp_marlin_rand", "zkp_marlin_proof",
+STRUCTS = ["zkp_ctx_config", "zkp_csr", "zkp_groth16_pk_desc", "zkp_marlin_index_desc", "zkp_marlin_rand", "zkp_marlin_proof",
            "zkp_groth16_timing", "zkp_marlin_timing"]
 
 
@@ -161,7 +161,7 @@ def main():
         w(f"pub const {k}: {v[1]} = {v[0]};\n")
     w("\n")
     for name, fields in structs():
-        copy = "#[derive(Clone, Copy)]\n" if name in ("zkp_csr", "zkp_groth16_timing") else ""
+        copy = "#[derive(Clone, Copy)]\n" if name in ("zkp_csr", "zkp_groth16_timing", "zkp_ctx_config") else ""
         w(f"#[repr(C)]\n{copy}pub struct {name} {{\n")
         for fn_, rt in fields:
             w(f"    pub {fn_}: {rt},\n")
