@@ -80,7 +80,8 @@ def compact_line(out):
     if out.get("scale_parity") is not None:
         line["scale_parity"] = _pick(out["scale_parity"], ("all_ranks_eq_rank0", "sharded_eq_single_gpu", "all_devices_eq_device0", "ranks"))
     if isinstance(out.get("exchange"), dict):
-        line["exchange"] = _pick(out["exchange"], ("kind", "ranks", "devices", "bytes_per_rank"), 80)
+        line["exchange"] = _pick(out["exchange"], ("kind", "ranks", "devices", "bytes_per_rank", "exchange", "rccl_ranks", "witness_map",
+                                                   "ms_replicated", "ms_split"), 80)
     if out.get("summary") is not None:
         line["summary"] = out["summary"]
     line["detail"] = out.get("detail")

@@ -17,6 +17,10 @@ CSRC = ROOT / "csrc"
 # the untagged build.
 TAG = os.environ.get("ZKP_BUILD_TAG", "")
 EXTRA_DEFS = os.environ.get("ZKP_BUILD_DEFS", "").split()
+# Sanitizer build of the HOST code (tools/asan_run.sh): ZKP_BUILD_TAG=asan
+#   ZKP_BUILD_DEFS="-fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -g"  ZKP_BUILD_LDFLAGS="-fsanitize=address,undefined -shared-libasan"
+# (-fno-gpu-sanitize: device code is compiled as always; the runtime is LD_PRELOADed into the Python process that loads the library)
+EXTRA_LDFLAGS = os.environ.get("ZKP_BUILD_LDFLAGS", "").split()
 LIBDIR = (ROOT.parent / "variants" / TAG) if TAG else ROOT / "lib"
 OBJDIR = LIBDIR / "obj"
 LIB = LIBDIR / "libzkp_accel.so"
@@ -94,7 +98,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         for (o, dt), u in zip(results, UNITS):
             print(f"[build] {u[1]}: {'cached' if dt == 0 else '%.1fs' % dt}", file=sys.stderr)
     if force or not _newer(LIB, objs):
-        r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", str(LIB), *map(str, objs)],
+        r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *EXTRA_LDFLAGS, "-o", str(LIB), *map(str, objs)],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

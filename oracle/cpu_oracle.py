@@ -12,14 +12,36 @@ HERE = Path(__file__).resolve().parent
 SRC = HERE / "cpu" / "zkp_oracle.cpp"
 LIB = HERE / "build" / "libzkp_oracle.so"
 _lib = None
+CLANGXX = "/opt/rocm/lib/llvm/bin/clang++"
 
 
-def build(force: bool = False) -> Path:
+def asan_runtime() -> str:
+    """the shared AddressSanitizer runtime of the ROCm clang (to LD_PRELOAD into a Python process that loads a sanitized .so)"""
+    r = subprocess.run([CLANGXX, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    p = r.stdout.strip()
+    if r.returncode != 0 or not Path(p).exists():
+        import glob
+        hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+        if not hits:
+            raise RuntimeError("libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm")
+        p = hits[-1]
+    return p
+
+
+def build(force: bool = False, sanitize: bool = False) -> Path:
+    """sanitize=True: an ASan + UBSan build (oracle/build/libzkp_oracle_asan.so, clang++ of the ROCm toolchain with its shared
+    runtime, -O1) for tests/test_sanitizers.py — the process that loads it LD_PRELOADs the runtime (asan_runtime())."""
+    global LIB
+    if sanitize:
+        LIB = HERE / "build" / "libzkp_oracle_asan.so"
     LIB.parent.mkdir(exist_ok=True)
     deps = [SRC, HERE / "cpu" / "field_constants64.inc", HERE / "cpu" / "marlin_oracle.inc", HERE.parent / "include" / "zkp_accel.h"]
     if not force and LIB.exists() and all(d.stat().st_mtime <= LIB.stat().st_mtime for d in deps):
         return LIB
     cmd = ["g++", "-O3", "-march=native", "-std=c++17", "-shared", "-fPIC", "-pthread", str(SRC), "-o", str(LIB)]
+    if sanitize:
+        cmd = [CLANGXX, "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-pthread", "-fsanitize=address,undefined", "-shared-libasan",
+               "-fno-omit-frame-pointer", str(SRC), "-o", str(LIB)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         # -march=native objects do not travel between hosts with different ISAs: fall back to a portable build

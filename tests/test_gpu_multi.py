@@ -276,6 +276,8 @@ def test_bench_torchrun_two_ranks_reports_scale_parity_and_exchange():
                           torchrun_world=2)
     assert line["scaling"] == "strong" and line["scale_parity"]["sharded_eq_single_gpu"] is True
     assert line["exchange"]["ranks"] == 2 and line["exchange"]["bytes_per_rank"] > 0
+    # the N > 1 lines carry a per-device roofline (a `None` there would leave the first SCALE run "unmeasured")
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["bound"] == "hbm" and "from" in line["roofline"]
 
 
 def test_bench_single_process_three_ranks_measures_the_witness_split():
@@ -291,3 +293,4 @@ def test_bench_single_process_three_ranks_measures_the_witness_split():
     assert (ex["witness_map"] == "replicated") == (ex["ms_replicated"] <= ex["ms_split"])
     line, _ = _bench_line(["--devices", "0,0", "--steps", "4", "--warmup", "2", "--log-n", "12"])
     assert line["n_gpus"] == 2 and line["scale_parity"]["all_devices_eq_device0"] is True
+    assert line["roofline"]["frac"] > 0 and line["detail"].endswith("bench_detail.json")
