@@ -199,7 +199,8 @@ def test_device_keygen_equals_host_keygen(ctx, curve, k, skew):
 
 
 # configs[4]'s instance (2^24, BN254) is covered — single GPU and 8-way sharded — by tests/test_gpu_dist.py
-_FULL = [("bn254", 20), ("bls12_381", 20), ("bls12_381", 22)]
+from tests.util import TEST_FULL
+_FULL = [("bn254", 20), ("bls12_381", 20), ("bls12_381", 22)] if TEST_FULL else [("bn254", 20)]
 
 
 @pytest.mark.parametrize("curve,k", _FULL)

@@ -21,7 +21,7 @@ from oracle.pyref.curves import Group
 from tests.util import OC, jac_limbs_to_affine_oracle, to_abi_points
 
 pytestmark = pytest.mark.gpu
-FULL = os.environ.get("ZKP_TEST_FULL", "1") != "0"
+from tests.util import TEST_FULL as FULL
 OPS = (api.NTT_FFT, api.NTT_IFFT, api.NTT_COSET_FFT, api.NTT_COSET_IFFT)
 
 

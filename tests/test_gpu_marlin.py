@@ -229,9 +229,11 @@ def test_marlin_config4_full_size_verifies(ctx):
     from oracle.pyref.ntt import Domain
     curve = "bn254"
     c = get_curve(curve)
-    inst = mimc_chain_instance(curve, 87381, seed=0x4D41)
+    from tests.util import TEST_FULL
+    lh = 20 if TEST_FULL else 18                                  # ZKP_TEST_FULL=0: |H| = 2^18, same steps
+    inst = mimc_chain_instance(curve, 87381 if TEST_FULL else 21845, seed=0x4D41)
     didx = marlin_dev.DeviceIndex.from_instance(ctx, inst)
-    assert (didx.hs, didx.ks, didx.bs) == (1 << 20, 1 << 21, 1 << 23)
+    assert (didx.hs, didx.ks, didx.bs) == (1 << lh, 2 << lh, 8 << lh)
     beta_srs = 0x0F1E2D3C4B5A69788796A5B4C3D2E1F0
     ck = kzg10.setup(ctx, curve, didx.max_degree, beta_srs)
     try:

@@ -9,6 +9,10 @@ from oracle.pyref import fields as ofields
 from oracle.pyref.curves import Group
 
 OC = {"bn254": ofields.BN254, "bls12_381": ofields.BLS12_381}
+# ZKP_TEST_FULL=0: the full-size tests (2^24 Groth16, |H| = 2^20 Marlin, BLS12-381 2^22, the 2^24 kernel-level cases) shrink to one
+# smaller representative each — same code paths, a quarter of the points — for a suite that has to fit a time limit.  Default: full.
+import os
+TEST_FULL = os.environ.get("ZKP_TEST_FULL", "1") != "0"
 
 
 def jac_to_affine(ctx, curve, group, xyz):
