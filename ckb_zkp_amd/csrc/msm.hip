@@ -514,7 +514,10 @@ __device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* cnt, uint32_t idx, bo
 // write consecutive entries of one (bin, tile) run.  The one-entry-per-lane version above turns every 8-byte store into a
 // 32-byte fabric write (PMC: 9.0 M 32-byte + 2.3 M 64-byte write requests = 434 MB for 125 MB of entries); here a run of k
 // entries costs ceil(8k / 32) + 1 requests at most.  The bin id rides in bits 45..57 of the staged word (level 2 ignores them).
-constexpr uint32_t SORT_STAGE_BYTES = 56 * 1024;
+#ifndef ZKP_SORT_STAGE_BYTES              // A/B builds (ZKP_BUILD_DEFS_msm): 28 KiB = five workgroups per CU instead of two
+#define ZKP_SORT_STAGE_BYTES (56 * 1024)
+#endif
+constexpr uint32_t SORT_STAGE_BYTES = ZKP_SORT_STAGE_BYTES;
 template <class FrP>
 __global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t* __restrict__ scalars, size_t n,
                                                                   size_t offset, const uint8_t* __restrict__ inf,
