@@ -4,8 +4,8 @@
     python tools/msm_window_sweep.py [curve] [log_n ...]        -> one table per size: c, windows, ms per MSM, Mop/s, phase times
 
 c = 20 was chosen for the pipelined Groth16 prover (reduction tails overlap other MSMs' accumulates).  A lone MSM pays its
-bucket sort and its reduction tail serially, and both grow with the bucket count: ZKP_MSM_C is read at upload time
-(msm.hip pick_window_bits), so every row uploads its own window tables.  Scalars uniform, resident in HBM; the time is the host
+bucket sort and its reduction tail serially, and both grow with the bucket count: the window size is a per-context
+setting (zkp_ctx_config.msm_window_bits, msm.hip pick_window_bits), so every row creates a context and uploads its own window tables.  Scalars uniform, resident in HBM; the time is the host
 wall of zkp_msm_g1_dev (result read back each call), best and median of `runs`."""
 import os
 import statistics
@@ -39,13 +39,12 @@ for log_n in sizes:
     print(f"# {curve} G1, n = 2^{log_n} - 1, {runs} runs per row, uniform scalars resident in HBM")
     print(f"{'ZKP_MSM_C':>10} {'best ms':>9} {'median ms':>10} {'Mop/s(best)':>12} {'Mop/s(med)':>11}  same result")
     ref = None
-    for cw in ["default"] + [str(x) for x in range(max(12, log_n - 6), min(22, log_n + 1) + 1)]:
-        if cw == "default":
-            os.environ.pop("ZKP_MSM_C", None)
-        else:
-            os.environ["ZKP_MSM_C"] = cw
+    rows = ["default"] + [str(x) for x in range(max(12, log_n - 6), min(22, log_n + int(os.environ.get("SWEEP_ABOVE", "1"))) + 1)]
+    for cw in rows[:1] if os.environ.get("SWEEP_ONLY_DEFAULT") else rows:
+        # the window size is a per-context setting since ABI 0.6 (zkp_ctx_config.msm_window_bits): one context per row
+        row_ctx = ctx if cw == "default" else Context(0, dict(msm_window_bits=int(cw)))
         try:
-            bases = ctx.upload_bases(c, 1, xy, inf)
+            bases = row_ctx.upload_bases(c, 1, xy, inf)
         except Exception as e:                      # a plan the library refuses (n * W too large, ...)
             print(f"{cw:>10}  upload failed: {e!r}")
             continue
@@ -62,6 +61,7 @@ for log_n in sizes:
         b, m = min(ts), statistics.median(ts)
         print(f"{cw:>10} {b:9.3f} {m:10.3f} {n / b / 1e3:12.1f} {n / m / 1e3:11.1f}  {key == ref}")
         bases.free()
-    os.environ.pop("ZKP_MSM_C", None)
+        if row_ctx is not ctx:
+            row_ctx.close()
     ctx.dev_free(k_dev)
     print()

@@ -11,7 +11,7 @@ for pass in 1 2; do
     if [ $v = default ]; then unset ZKP_ACCEL_LIB; else export ZKP_ACCEL_LIB=$PWD/variants/$v/libzkp_accel.so; fi
     m=$(python bench.py --workload marlin --no-cpu-baseline --steps 8 2>/dev/null | val)
     g=$(python bench.py --no-cpu-baseline --no-marlin --no-extra-configs --steps 64 --warmup 10 2>/dev/null | val)
-    s=$(python tools/msm_window_sweep.py bn254 20 2>/dev/null | awk '$1=="default"{print $3, $5}')
+    s=$(SWEEP_ONLY_DEFAULT=1 python tools/msm_window_sweep.py bn254 20 2>/dev/null | awk '$1=="default"{print $3, $5}')
     echo "pass $pass $v  marlin(proofs/s ms): $m   groth16 2^20 (proofs/s ms): $g   lone MSM 2^20 (median ms, Mop/s): $s"
   done
 done
