@@ -100,6 +100,13 @@ static int pick_window_bits(const zkp_cfg& cfg, size_t n, int group) {
   int lg = 0;
   while (((size_t)2 << lg) <= n) lg++;          // floor(log2 n)
   if (lg < 63 && (double)n >= 1.41421356 * (double)((size_t)1 << lg)) lg++;   // round(log2 n): 2^20 - 1 -> 20
+  // Round 6 (profiles/r06_msm_window_sweep.txt): below 2^20 points an MSM is latency-bound — ~20 dependent launches, 0.55-0.9 ms
+  // whatever n is — and every window fewer is one table gather and one bucket addition per point less, while the bucket reduction
+  // of 2^(c-1) buckets hides in the same launches.  Measured optimum, lone G1 MSM on resident tables: c = lg + 3 up to 2^14
+  // (0.885 -> 0.577 ms at 2^12, 0.952 -> 0.607 at 2^14), lg + 2 up to 2^17 (0.812 -> 0.72 at 2^16), lg + 1 at 2^18 / 2^19
+  // (1.042 -> 0.959 at 2^18), lg from 2^20 on (c = 20 stays the optimum there and above: 19 and 21 both lose).
+  static const bool widen = !(getenv("ZKP_MSM_WIDEN") && atoi(getenv("ZKP_MSM_WIDEN")) == 0);      // A/B: 0 = the round(log2 n) rule of rounds 1-5
+  if (widen && lg >= 10) lg += lg <= 14 ? 3 : lg <= 17 ? 2 : lg <= 19 ? 1 : 0;
   return std::min(20, std::max(4, lg));
 }
 
