@@ -41,7 +41,7 @@ TOXIC = dict(alpha=0x1234567890ABCDEF1, beta=0xFEDCBA09876543211, gamma=0x111111
              delta=0x2222222222222222223, tau=0x3333333333333333335)
 
 
-DETAIL_PATH = os.path.join("gpurun_out", "bench_detail.json")
+DETAIL_PATH = os.environ.get("ZKP_BENCH_DETAIL") or os.path.join("gpurun_out", "bench_detail.json")
 LINE_CAP = 4096                      # the driver's parser lost the 21 KB line of round 5: the final stdout line stays under 4 KB
 
 
@@ -342,7 +342,7 @@ def bench_marlin(ctx, curve="bn254", samples=87381, reps=3, verify=True, cpu=Fal
     # Since round 3 the commitments of the mask polynomial and t(X) start DURING their rounds (marlin.hip, early commitments), so
     # the commit phases alone no longer hold all the MSM time: the clock is rounds + commits (conservative: it also holds the NTTs).
     commit_s = (sum(tm["ms_commit"]) + sum(tm["ms_round"])) * 1e-3
-    mpmc, msrc = recorded("r05_pmc_marlin_accumulate.json")
+    mpmc, msrc = recorded_latest("pmc_marlin_accumulate.json")
     roofline = {"bound": "hbm", "kernel": "accumulate_kernel inside the commitment MSMs (PC::commit of the three AHP rounds)",
                 "achieved": round(commit_bytes / commit_s / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(commit_bytes / commit_s / 1e9 / 8000.0, 5),
@@ -485,6 +485,16 @@ def hbm_peak_block(ctx):
                     "this process; every roofline block quotes its fraction of BOTH peaks"}
 
 
+def recorded_latest(suffix):
+    """the newest profiles/rNN_<suffix> a round has recorded"""
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
+        d, src = recorded(f"{rnd}_{suffix}", quiet=True)
+        if d:
+            return d, src
+    log(f"no recorded profiles/rNN_{suffix}: the fields that quote it stay null")
+    return None, None
+
+
 def recorded(name, quiet=False):
     """a value recorded under profiles/ by a separate rocprofv3 --pmc pass (PMC counters cannot be read from inside the process)"""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
@@ -605,7 +615,7 @@ def ntt_roofline(ctx, c, log_n, hbm_meas):
                         "frac_of_measured_peak": round(ach * passes / hbm_meas["value"], 4) if hbm_meas else None,
                         "note": "one pass reads and writes the vector once (64*N bytes)"},
            "valu": {"mulmods_per_element": round(mm, 2), "gmulmod_per_s": round(mm * N / (t_ntt * 1e-3) / 1e9, 1)}}
-    pmc, src = recorded("r05_pmc_ntt.json")
+    pmc, src = recorded_latest("pmc_ntt.json")
     if pmc:
         out["valu_busy_recorded"] = dict(pmc, source=src, kind="recorded",
                                          note="SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES per SIMD of ntt_pass2_kernel (tools/pmc_ntt.sh): the share "
@@ -876,12 +886,9 @@ def main():
         # HBM bytes per launch: PMC counters cannot be read from inside the process; they come from the separate
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command recorded under profiles/
         traffic, traffic_src = None, None
-        here = os.path.dirname(os.path.abspath(__file__))
-        for name in ("r05_pmc_accumulate.json", "r04_pmc_accumulate.json", "r03_pmc_accumulate.json", "r02_pmc_accumulate.json", "r01_pmc_accumulate.json"):
-            pmc = os.path.join(here, "profiles", name)
-            if primary and os.path.exists(pmc):
-                traffic, traffic_src = json.load(open(pmc))["traffic_bytes_per_launch"], "profiles/" + name
-                break
+        if primary:
+            pmc, traffic_src = recorded_latest("pmc_accumulate.json")
+            traffic = pmc["traffic_bytes_per_launch"] if pmc else None
         roofline, phases = accumulate_roofline(ctx, pk, c, inst, step, hbm_meas, traffic, traffic_src)
         roofline_ntt = ntt_roofline(ctx, c, args.log_n, hbm_meas)
         roofline_scan = scan_roofline(phases, hbm_meas)

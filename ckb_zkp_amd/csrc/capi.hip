@@ -374,12 +374,12 @@ int32_t zkp_ntt(zkp_ctx* ctx, zkp_curve_t curve, uint64_t* data, uint32_t log_n,
 int32_t zkp_bases_upload_g1(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n,
                             uint64_t* handle) {
   if (!handle || (n && !xy)) return ZKP_ERR_BAD_ARG;
-  return guarded(ctx, [&] { *handle = bases_upload(ctx, curve, 1, xy, inf, n); });
+  return guarded(ctx, [&] { *handle = bases_upload(ctx, curve, 1, xy, inf, n, /*c_hint=*/-1); });
 }
 int32_t zkp_bases_upload_g2(zkp_ctx* ctx, zkp_curve_t curve, const uint64_t* xy, const uint8_t* inf, size_t n,
                             uint64_t* handle) {
   if (!handle || (n && !xy)) return ZKP_ERR_BAD_ARG;
-  return guarded(ctx, [&] { *handle = bases_upload(ctx, curve, 2, xy, inf, n); });
+  return guarded(ctx, [&] { *handle = bases_upload(ctx, curve, 2, xy, inf, n, /*c_hint=*/-1); });
 }
 int32_t zkp_bases_share(zkp_ctx* dst, zkp_ctx* src, uint64_t src_handle, uint64_t* dst_handle) {
   if (!src || !dst_handle) return ZKP_ERR_BAD_ARG;

@@ -33,6 +33,7 @@ void poly_evaluate_batch(zkp_ctx* ctx, int curve, size_t count, const uint64_t* 
                          uint64_t* out_host);
 
 // msm.hip
+// c_hint == -1: a stand-alone base vector (zkp_bases_upload_*): the lone-MSM window rule (msm.hip pick_window_bits);
 // c_hint > 0: window bits chosen by the caller (Groth16: the B queries are sized by their NON-identity bases); cap_hint > 0:
 // entries per accumulate task
 // lgk_hint >= 0: window-group size 2^lgk chosen by the caller (a Groth16 key sizes all five queries together); -1: chosen here

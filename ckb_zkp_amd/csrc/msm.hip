@@ -94,19 +94,21 @@ struct BasesEntry {
   }
 };
 
-static int pick_window_bits(const zkp_cfg& cfg, size_t n, int group) {
+static int pick_window_bits(const zkp_cfg& cfg, size_t n, int group, bool lone) {
   if (group == 2 && cfg.msm_c_g2 >= 2 && cfg.msm_c_g2 <= 22) return cfg.msm_c_g2;       // zkp_ctx_config.msm_window_bits_g2 / ZKP_MSM_C_G2
   if (cfg.msm_c >= 2 && cfg.msm_c <= 22) return cfg.msm_c;                                // zkp_ctx_config.msm_window_bits / ZKP_MSM_C
   int lg = 0;
   while (((size_t)2 << lg) <= n) lg++;          // floor(log2 n)
   if (lg < 63 && (double)n >= 1.41421356 * (double)((size_t)1 << lg)) lg++;   // round(log2 n): 2^20 - 1 -> 20
-  // Round 6 (profiles/r06_msm_window_sweep.txt): below 2^20 points an MSM is latency-bound — ~20 dependent launches, 0.55-0.9 ms
-  // whatever n is — and every window fewer is one table gather and one bucket addition per point less, while the bucket reduction
-  // of 2^(c-1) buckets hides in the same launches.  Measured optimum, lone G1 MSM on resident tables: c = lg + 3 up to 2^14
-  // (0.885 -> 0.577 ms at 2^12, 0.952 -> 0.607 at 2^14), lg + 2 up to 2^17 (0.812 -> 0.72 at 2^16), lg + 1 at 2^18 / 2^19
-  // (1.042 -> 0.959 at 2^18), lg from 2^20 on (c = 20 stays the optimum there and above: 19 and 21 both lose).
-  static const bool widen = !(getenv("ZKP_MSM_WIDEN") && atoi(getenv("ZKP_MSM_WIDEN")) == 0);      // A/B: 0 = the round(log2 n) rule of rounds 1-5
-  if (widen && lg >= 10) lg += lg <= 14 ? 3 : lg <= 17 ? 2 : lg <= 19 ? 1 : 0;
+  // Round 6 (profiles/r06_msm_window_sweep.txt, r06_widen_ab.txt): chosen per call site.  A LONE MSM below 2^20 points (a base vector
+  // uploaded through zkp_bases_upload_*: KZG10 powers, VariableBaseMSM callers) is latency-bound — ~20 dependent launches, 0.55-0.9 ms
+  // whatever n is — and every window fewer is one table gather and one bucket addition per point less, while the reduction of 2^(c-1)
+  // buckets hides in the same launches.  Measured optimum on resident tables: c = lg + 3 up to 2^14 (0.886 -> 0.573 ms at 2^12,
+  // 0.951 -> 0.609 at 2^14), lg + 2 up to 2^17 (0.82 -> 0.705 at 2^16), lg + 1 at 2^18 / 2^19 (1.038 -> 0.957 at 2^18), lg from 2^20
+  // on (c = 20 stays the optimum there and above: 19 and 21 both lose).  The queries of a Groth16 key keep round(log2 n): the
+  // pipelined prover is VALU-bound, where twice the buckets is twice the reduction work (2^18 circuit: 495 -> 433 proofs/s widened).
+  static const bool widen = !(getenv("ZKP_MSM_WIDEN") && atoi(getenv("ZKP_MSM_WIDEN")) == 0);      // A/B: 0 = round(log2 n) everywhere
+  if (lone && widen && lg >= 10) lg += lg <= 14 ? 3 : lg <= 17 ? 2 : lg <= 19 ? 1 : 0;
   return std::min(20, std::max(4, lg));
 }
 
@@ -116,7 +118,7 @@ struct WindowPlan {
 };
 static WindowPlan window_plan(const zkp_cfg& cfg, int scalar_bits, size_t n, int group, int c_hint, int lgk) {
   static const bool balanced = !(getenv("ZKP_MSM_BALANCED") && atoi(getenv("ZKP_MSM_BALANCED")) == 0);
-  const int T = scalar_bits + 1, c0 = c_hint >= 2 && c_hint <= 22 ? c_hint : pick_window_bits(cfg, n, group);
+  const int T = scalar_bits + 1, c0 = c_hint >= 2 && c_hint <= 22 ? c_hint : pick_window_bits(cfg, n, group, /*lone=*/c_hint == -1);
   WindowPlan p{};
   if (lgk <= 0) {
     // Balanced windows: T = scalar_bits + 1 (one spare bit absorbs the last signed-digit carry) is spread over W = ceil(T / c)

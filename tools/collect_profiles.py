@@ -13,6 +13,13 @@ def last(path):
     return open(path).read().strip().split("\n")[-1]
 
 
+def full_record(path):
+    """since round 6 a bench run prints a compact line and writes the full record next to it (ZKP_BENCH_DETAIL=<path minus .json>.detail.json,
+    tools/profile_r6.sh): the full record when it exists, else the line"""
+    d = path[:-5] + ".detail.json"
+    return open(d).read().strip() if os.path.exists(d) else last(path)
+
+
 def row(path, kern):
     for l in open(path):
         if l.startswith(kern):
@@ -65,6 +72,6 @@ with open(P + rnd + "_kernel_stats_rocprofv3.txt", "w") as o:
 for a, b in (("bench_full.json", "_bench_bn254_2p20.json"), ("bls22.json", "_bench_bls12_381_2p22.json"),
              ("bn24.json", "_bench_bn254_2p24_single_gpu.json"), ("marlin.json", "_marlin_native_config4.json")):
     if os.path.exists(out + a):
-        open(P + rnd + b, "w").write(last(out + a) + "\n")
-open(P + rnd + "_bench_under_kernel_trace.json", "w").write(last(src + "stats_bench.json") + "\n")
+        open(P + rnd + b, "w").write(full_record(out + a) + "\n")
+open(P + rnd + "_bench_under_kernel_trace.json", "w").write(full_record(src + "stats_bench.json") + "\n")
 print("traffic_bytes_per_launch", traffic, "traced", traced, "untraced", full)
