@@ -217,6 +217,64 @@ class _DenseColumnCircuit:
                        lambda lc, k1=k1, k2=k2: (lc + (k1, cs.one()) + (k2, hub)) if k2 else (lc + (k1, cs.one())))
 
 
+class _ManyHubsCircuit:
+    """`hubs` witness variables, each on the C side of `per_hub` rows with a general coefficient (cost 380 each: a medium-dense
+    column just above the 50000 floor), next to the constant-one column that every row touches: the shape ADVICE r5 flagged — with a
+    fixed threshold every hub became a serial MSM of its own at key upload; the per-key cut keeps them in the fold kernel."""
+
+    def __init__(self, curve, seed, hubs, per_hub):
+        self.c, self.seed, self.hubs, self.per_hub = get_curve(curve), seed, hubs, per_hub
+
+    def generate_constraints(self, cs):
+        import random
+        rnd = random.Random(self.seed)
+        r = self.c.r
+        for _ in range(self.hubs):
+            hv = rnd.randrange(1, r)
+            hub = cs.alloc(lambda v=hv: v)
+            for _ in range(self.per_hub):
+                a, k1, k2 = rnd.randrange(1, r), rnd.randrange(1, r), rnd.randrange(2, r - 1)
+                bval = (k1 + k2 * hv) * pow(a, -1, r) % r
+                xa = cs.alloc(lambda v=a: v)
+                xb = cs.alloc(lambda v=bval: v)
+                cs.enforce(lambda lc, xa=xa: lc + (1, xa), lambda lc, xb=xb: lc + (1, xb),
+                           lambda lc, k1=k1, k2=k2, hub=hub: lc + (k1, cs.one()) + (k2, hub))
+
+
+def test_groth16_many_medium_dense_c_columns_stay_in_the_fold_kernel(ctx):
+    """40 columns of cost 57 000 (150 general coefficients each) + the constant-one column (2.3 M): the per-key cut sends ONE column
+    through an MSM (longest kernel chain 57 000 + 4 000 for the MSM beats 41 MSMs at 214 000), a fixed 50 000 sends 41; same key either
+    way — both proofs equal oracle/cpu's — and the upload with the default must not be slower than with the fixed threshold."""
+    import time
+    from ckb_zkp_amd import groth16
+    from ckb_zkp_amd.api import Context
+    from ckb_zkp_amd.r1cs import ConstraintSystem, R1csInstance
+    c = get_curve("bn254")
+    cs = ConstraintSystem(c, True)
+    _ManyHubsCircuit("bn254", 77, 40, 150).generate_constraints(cs)
+    inst = R1csInstance.from_cs(cs)
+    params = groth16.generate_parameters(ctx, c, inst, alpha=0x7654321, beta=0x1ABCDE, gamma=0xF0145, delta=0x67ABC, tau=0xDEF01236789)
+    z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
+    rm, sm = codec.fr_to_mont([0x1234567], c)[0], codec.fr_to_mont([0x89ABCDE], c)[0]
+    o_out, o_inf, _ = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=8)
+    secs = {}
+    for cost in (0, 50000):
+        own = Context(ctx.device, dict(c_fold_heavy_cost=cost) if cost else None)
+        try:
+            groth16.ProvingKey(own, params, inst).free()           # first upload of a context allocates its scratch
+            t = time.perf_counter()
+            pk = groth16.ProvingKey(own, params, inst)
+            secs[cost] = time.perf_counter() - t
+            assert pk.table_plan()["c_folded_into_l"]
+            out, inf = pk.prove_raw(z, rm, sm)
+            assert np.array_equal(out, o_out) and np.array_equal(inf, o_inf), cost
+            pk.free()
+        finally:
+            own.close()
+    print(f"key upload: per-key cut {secs[0]:.3f} s, fixed 50000 {secs[50000]:.3f} s")
+    assert secs[0] <= secs[50000] * 1.25 + 0.05
+
+
 @pytest.mark.parametrize("curve,rows,cost", [("bn254", 300, 3), ("bls12_381", 90, 3), ("bn254", 700, 50000), ("bn254", 700, 0)])
 def test_groth16_dense_c_column_takes_the_heavy_fold_path(ctx, curve, rows, cost):
     """fold_c_into_l (csrc/groth16.hip): columns of C above zkp_ctx_config.c_fold_heavy_cost leave the one-lane-per-variable kernel and
