@@ -324,11 +324,14 @@ static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz,
   // double-and-add per general coefficient.  A dense column (the constant-one variable of packing / x * x_inv = 1 constraints, any
   // variable with 1e5+ entries of C) would be a single-lane chain of 1e6-1e8 point operations.  Columns above a cost threshold leave
   // the kernel's CSC and take ONE variable-base MSM each (msm_var_run over the gathered G rows), subtracted on the host below.
-  // Threshold: a heavy column pays a host gather, an H2D copy and one msm_var_run with a stream sync (~2 ms, about
-  // 4000 lane-serial point operations' worth), one after the other, while the kernel's lanes run side by side and finish with
-  // the LONGEST remaining column.  So the cut is chosen per key: with the column costs sorted descending, k heavy columns cost
-  // about cost[k] + 4000 k — the k that minimises it, never cutting below 50000 (a chain the kernel walks in well under 0.1 s).
-  // A circuit with thousands of medium-dense columns keeps them in the kernel instead of running thousands of serial MSMs.
+  // Threshold, MEASURED in round 6 (tests/test_gpu_fuzz.py::test_groth16_key_fold_cut_is_chosen_per_key): one cost unit = one
+  // point operation of a single lane ≈ 8 µs alone and ≈ 16 µs when the lanes of a wave diverge over different coefficients (40 columns
+  // x 57 000 units: 0.45 s; 300 x 53 200: 0.85 s), while a heavy column = host gather + H2D + msm_var_run + sync ≈ 1.7-3 ms ≈ 150 units,
+  // one after the other.  The fixed 50 000 of round 5 was therefore far too HIGH for the common case (a handful of dense columns: each
+  // up to 0.8 s of kernel chain instead of a 2 ms MSM) and only right when there are hundreds of them.  So the cut is chosen per key:
+  // with the column costs sorted descending, k heavy columns cost about cost[k] + 150 k — the k that minimises it, never cutting below
+  // 1000 (≈ 10 ms of chain).  12 columns of 38 000: twelve MSMs (≈ 30 ms) instead of a 0.3-0.6 s chain; 3000 columns of 50 000 stay in
+  // the kernel (≈ 0.8 s, side by side) instead of 5 s of serial MSMs.
   // cfg.lfold_heavy_cost > 0 (zkp_ctx_config.c_fold_heavy_cost / ZKP_LFOLD_HEAVY_COST) fixes the threshold instead.
   HostField::E one = F.one_(), minus_one = F.neg(one);
   std::vector<uint8_t> heavy(nz, 0);
@@ -342,7 +345,7 @@ static void fold_c_into_l(zkp_ctx* ctx, const zkp_groth16_pk_desc* d, size_t nz,
     }
     uint64_t heavy_cost = ctx->cfg.lfold_heavy_cost > 0 ? (uint64_t)ctx->cfg.lfold_heavy_cost : 0;
     if (!heavy_cost) {
-      const uint64_t floor_cost = 50000, per_msm = 4000;
+      const uint64_t floor_cost = 1000, per_msm = 150;
       std::vector<uint64_t> big;
       for (uint64_t c : cost)
         if (c > floor_cost) big.push_back(c);

@@ -81,7 +81,7 @@ typedef struct {
   int32_t host_affine;         /* tri-state: into_affine of the three proof points on the host      [ZKP_HOST_AFFINE; on] */
   int64_t c_fold_heavy_cost;   /* a C column above this cost (1 per +-1 coefficient, 380 per general one) leaves the fold kernel
                                   for one MSM of its own                                            [ZKP_LFOLD_HEAVY_COST; chosen per
-                                  key: the cut that minimises longest kernel chain + 4000 per heavy column, never below 50000] */
+                                  key: the cut that minimises longest kernel chain + 150 per heavy column, never below 1000] */
   int32_t multi_exchange;      /* ZKP_EXCHANGE_*: partial sums of zkp_groth16_prove_multi           [ZKP_MULTI_EXCHANGE; auto =
                                   RCCL all-gather when the devices are distinct and librccl loads, else peer copies] */
   int32_t multi_exchange_timeout_ms; /* watchdog of the RCCL setup and of the first all-gather: when it expires the key falls

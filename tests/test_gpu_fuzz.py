@@ -219,8 +219,8 @@ class _DenseColumnCircuit:
 
 class _ManyHubsCircuit:
     """`hubs` witness variables, each on the C side of `per_hub` rows with a general coefficient (cost 380 each: a medium-dense
-    column just above the 50000 floor), next to the constant-one column that every row touches: the shape ADVICE r5 flagged — with a
-    fixed threshold every hub became a serial MSM of its own at key upload; the per-key cut keeps them in the fold kernel."""
+    column), next to the constant-one column that every row touches: the shape ADVICE r5 flagged — with a fixed threshold every hub
+    above it becomes a serial MSM of its own at key upload."""
 
     def __init__(self, curve, seed, hubs, per_hub):
         self.c, self.seed, self.hubs, self.per_hub = get_curve(curve), seed, hubs, per_hub
@@ -241,17 +241,20 @@ class _ManyHubsCircuit:
                            lambda lc, k1=k1, k2=k2, hub=hub: lc + (k1, cs.one()) + (k2, hub))
 
 
-def test_groth16_many_medium_dense_c_columns_stay_in_the_fold_kernel(ctx):
-    """40 columns of cost 57 000 (150 general coefficients each) + the constant-one column (2.3 M): the per-key cut sends ONE column
-    through an MSM (longest kernel chain 57 000 + 4 000 for the MSM beats 41 MSMs at 214 000), a fixed 50 000 sends 41; same key either
-    way — both proofs equal oracle/cpu's — and the upload with the default must not be slower than with the fixed threshold."""
+@pytest.mark.parametrize("hubs,per_hub", [(40, 150), (12, 100)])
+def test_groth16_key_fold_cut_is_chosen_per_key(ctx, hubs, per_hub):
+    """The heavy-column cut of fold_c_into_l, calibrated by this test in round 6: a lone lane's point operation takes 8-16 µs,
+    a heavy column's MSM 1.7-3 ms ≈ 150 operations (first measurements: 40 x 57 000: kernel 0.54 s, 41 MSMs 0.13 s; 300 x 53 200: kernel
+    0.88 s, 301 MSMs 0.52 s).  40 columns of cost 57 000 + the constant-one column: the per-key cut and the fixed 50 000 of round 5 agree
+    (all MSMs).  12 columns of cost 38 000: the fixed threshold keeps them in the kernel (a 0.3-0.6 s chain), the per-key cut sends them
+    through twelve MSMs.  Same key either way — both proofs equal oracle/cpu's — and the default must not be the slower one."""
     import time
     from ckb_zkp_amd import groth16
     from ckb_zkp_amd.api import Context
     from ckb_zkp_amd.r1cs import ConstraintSystem, R1csInstance
     c = get_curve("bn254")
     cs = ConstraintSystem(c, True)
-    _ManyHubsCircuit("bn254", 77, 40, 150).generate_constraints(cs)
+    _ManyHubsCircuit("bn254", 77, hubs, per_hub).generate_constraints(cs)
     inst = R1csInstance.from_cs(cs)
     params = groth16.generate_parameters(ctx, c, inst, alpha=0x7654321, beta=0x1ABCDE, gamma=0xF0145, delta=0x67ABC, tau=0xDEF01236789)
     z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
@@ -271,7 +274,7 @@ def test_groth16_many_medium_dense_c_columns_stay_in_the_fold_kernel(ctx):
             pk.free()
         finally:
             own.close()
-    print(f"key upload: per-key cut {secs[0]:.3f} s, fixed 50000 {secs[50000]:.3f} s")
+    print(f"key upload ({hubs} x {per_hub}): per-key cut {secs[0]:.3f} s, fixed 50000 {secs[50000]:.3f} s")
     assert secs[0] <= secs[50000] * 1.25 + 0.05
 
 
@@ -280,7 +283,7 @@ def test_groth16_dense_c_column_takes_the_heavy_fold_path(ctx, curve, rows, cost
     """fold_c_into_l (csrc/groth16.hip): columns of C above zkp_ctx_config.c_fold_heavy_cost leave the one-lane-per-variable kernel and
     take one variable-base MSM each (gathered one column at a time); the proof and witness map still equal oracle/cpu's.  cost = 3
     forces nearly every column through the MSM path; 50000 with 700 rows sends exactly the two dense columns (constant one + hub)
-    there; 0 = the default, a cut chosen per key (longest kernel chain + 4000 per heavy column minimised: the same two columns here).
+    there; 0 = the default, a cut chosen per key (longest kernel chain + 150 per heavy column minimised: the same two columns here).
     The key is uploaded through a context of its own with that configuration; the session context generates the parameters."""
     from ckb_zkp_amd import groth16
     from ckb_zkp_amd.api import Context
