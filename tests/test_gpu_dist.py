@@ -2,6 +2,8 @@
 simulated in-process (no collective), so what is checked is the device side: sliced uploads, partial MSMs on
 Montgomery scalars (G1 and G2), zkp_g*_fold, zkp_groth16_assemble.  The collective itself is covered on CPU by
 tests/test_dist_gloo.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -108,19 +110,29 @@ def test_config5_2p24_single_gpu_and_8way_sharded(ctx):
     (1) the single-GPU proof equals the proof computed in the exponent from the toxic waste (size-independent check,
     SURVEY §8(c).3) and h has degree <= N-2; (2) the 8-way base-sharded device-resident step (every rank's slice of the
     20 132 656-point queries, partial sums all-gathered in HBM, folded and assembled on the device) returns the same
-    proof bit for bit.  ~100 GB of HBM, a few minutes."""
+    proof bit for bit (through the in-library multi-GPU path by default, ZKP_TEST_2P24_SHARD=step for the per-process step:
+    tests at <= 2^12 above cover that one on every run).  ~100 GB of HBM, a few minutes."""
     from oracle.pyref.curves import Group
     from tests.util import OC
     from tests.util import TEST_FULL
     curve, k, world = "bn254", 24 if TEST_FULL else 22, 8       # ZKP_TEST_FULL=0: the same steps at 2^22
+    import time
+    tt = [time.time()]
+
+    def lap(what):                                              # (pytest -s: where the minutes of this test go)
+        tt.append(time.time())
+        print(f"[2^{k}] {what}: {tt[-1] - tt[-2]:.1f} s")
     c = get_curve(curve)
     inst = mimc_chain_instance(curve, samples_for_domain(k))
+    lap("instance")
     params = groth16.generate_parameters(ctx, curve, inst, **TOXIC)
+    lap("synthetic key")
     z = codec.fr_to_mont(inst.z, c).reshape(-1, 4)
     zd = ctx.to_device(z)
     r_, s_ = 0x1F2E3D4C5B6A7988, 0x8899AABBCCDDEEFF
     try:
         pk = groth16.ProvingKey(ctx, params, inst)
+        lap("key upload")
         try:
             assert pk.domain_size == 1 << k
             from oracle import cpu_oracle
@@ -130,7 +142,9 @@ def test_config5_2p24_single_gpu_and_8way_sharded(ctx):
             out1, inf1 = pk.prove_raw(zd, rm, sm, z_on_device=True)
             # full-size pin at 2^24: h and the whole proof equal the C++ restatement of the reference (all host threads; ONE oracle
             # pass returns the proof and the quotient it was made from)
+            lap("device witness map + proof")
             o_out, o_inf, _, o_h = cpu_oracle.groth16_prove(params, inst, z, rm, sm, threads=thr, want_h=True)
+            lap("oracle/cpu proof")
             assert np.array_equal(h_dev, o_h)
             del o_h
             assert not h_dev[-1].any()                          # deg h <= N - 2
@@ -142,13 +156,39 @@ def test_config5_2p24_single_gpu_and_8way_sharded(ctx):
         # then the proof in the exponent (inner products over the full assignment by oracle/cpu)
         from tests.util import spot_check_qap_exponents, trapdoor_proof_exponents
         spot_check_qap_exponents(params, inst)
+        lap("exponent spot check")
         A, B, Cc = trapdoor_proof_exponents(params, inst, z, h_dev, r_, s_)
         del h_dev
+        lap("trapdoor exponents")
         G1, G2 = Group(OC[curve], 1), Group(OC[curve], 2)
         assert proof.a == G1.mul(G1.gen, A)
         assert proof.b == G2.mul(G2.gen, B)
         assert proof.c == G1.mul(G1.gen, Cc)
-        out2, inf2 = _device_sharded_proof(ctx, params, inst, zd, world, r_, s_)
+        import time
+        t0 = time.time()
+        if os.environ.get("ZKP_TEST_2P24_SHARD", "multi") == "step":
+            # one process per GPU style: zkp_groth16_pk_upload_shard x 8 (every rank transforms the H query itself: ~2 min here)
+            out2, inf2 = _device_sharded_proof(ctx, params, inst, zd, world, r_, s_)
+        else:
+            # ONE process, eight ranks: zkp_ctx_create_multi + zkp_groth16_pk_upload_multi(SHARD) + zkp_groth16_prove_multi (the path of
+            # `bench.py --gpus 8 --mode shard`; the H query is transformed once and sliced) — witness on the host and per-rank on the device
+            from ckb_zkp_amd.api import MultiContext
+            m = MultiContext([ctx.device] * world)
+            try:
+                mpk = groth16.MultiProvingKey(m, params, inst, groth16.MULTI_SHARD)
+                try:
+                    out2, inf2 = mpk.prove_raw(z, rm, sm)
+                    zds = [m.member(k_).to_device(z) for k_ in range(world)]
+                    out3, inf3 = mpk.prove_raw(zds, rm, sm, z_on_device=True)
+                    for k_, d_ in enumerate(zds):
+                        m.member(k_).dev_free(d_)
+                    assert np.array_equal(out1, out3) and np.array_equal(inf1, inf3)
+                    assert mpk.info()["devices"] == world
+                finally:
+                    mpk.free()
+            finally:
+                m.close()
+        print(f"8-way sharded leg: {time.time() - t0:.1f} s")
         assert np.array_equal(out1, out2) and np.array_equal(inf1, inf2)
     finally:
         ctx.dev_free(zd)
