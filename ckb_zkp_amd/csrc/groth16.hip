@@ -1322,8 +1322,10 @@ struct RcclApi {
     std::string why;
   };
   Fns f;
-  std::vector<void*> comms;
-  std::vector<int> devices;
+  std::mutex mu;                    // the communicators are process-wide: one bring-up, and one group of collective calls, at a time
+  // one set of communicators per device set, kept for the life of the process (a second root over other devices must not tear
+  // down the communicators a first root is about to use)
+  std::map<std::vector<int>, std::vector<void*>> comms_of;
   bool unusable = false, watchdog_fired = false;
   std::string why;
 
@@ -1407,16 +1409,15 @@ struct RcclApi {
     at->cv.notify_all();
   }
 
-  bool ready(const std::vector<zkp_ctx*>& devs, int timeout_ms) {
-    if (unusable) return false;
+  // -> the communicators of this device set (rank order), or nullptr
+  const std::vector<void*>* ready(const std::vector<zkp_ctx*>& devs, int timeout_ms) {
+    if (unusable) return nullptr;
     std::vector<int> ids;
     for (zkp_ctx* d : devs) ids.push_back(d->device);
-    if (!comms.empty() && ids == devices) return true;
+    if (auto it = comms_of.find(ids); it != comms_of.end()) return &it->second;
     for (size_t i = 0; i < ids.size(); i++)
       for (size_t j = i + 1; j < ids.size(); j++)
-        if (ids[i] == ids[j]) { why = "duplicate device ids"; return false; }             // RCCL refuses duplicate devices (not sticky)
-    for (void* c : comms) (void)f.CommDestroy(c);                                          // another device set: new communicators
-    comms.clear();
+        if (ids[i] == ids[j]) { why = "duplicate device ids"; return nullptr; }           // RCCL refuses duplicate devices (not sticky)
     timeout_ms = std::max(1, timeout_ms);
     auto at = std::make_shared<Attempt>();
     std::thread(bring_up, at, ids, timeout_ms).detach();
@@ -1427,7 +1428,7 @@ struct RcclApi {
       at->abandoned = true;
       unusable = watchdog_fired = true;
       why = "RCCL bring-up (ncclCommInitAll + probe all-gather) did not return within " + std::to_string(2 * (long long)timeout_ms + 2000) + " ms";
-      return false;
+      return nullptr;
     }
     f = at->f;
     if (!at->ok) {
@@ -1435,11 +1436,9 @@ struct RcclApi {
       // a missing library is an ordinary "unavailable"; a failed init or probe is what the watchdog exists for
       unusable = true;
       watchdog_fired = f.lib != nullptr && at->why != "librccl.so lacks a symbol";
-      return false;
+      return nullptr;
     }
-    comms = at->comms;
-    devices = ids;
-    return true;
+    return &(comms_of[ids] = at->comms);
   }
 };
 RcclApi& rccl() {
@@ -1520,10 +1519,11 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
   // hand-declared prototypes below get executed on a one-GPU box (tests/test_gpu_multi.py) before any 8-GPU node sees them.
   const int want = root->cfg.multi_exchange;                     // zkp_ctx_config.multi_exchange / ZKP_MULTI_EXCHANGE, per context
   bool use_rccl = false;
+  const std::vector<void*>* rccl_comms = nullptr;
   if ((n > 1 && want != ZKP_EXCHANGE_PEER) || (n == 1 && want == ZKP_EXCHANGE_RCCL)) {
-    static std::mutex rccl_mu;                                   // the communicators are process-wide: one bring-up at a time
-    std::lock_guard<std::mutex> lk(rccl_mu);
-    use_rccl = rccl().ready(root->devs, root->cfg.multi_exchange_timeout_ms);
+    std::lock_guard<std::mutex> lk(rccl().mu);
+    rccl_comms = rccl().ready(root->devs, root->cfg.multi_exchange_timeout_ms);
+    use_rccl = rccl_comms != nullptr;
     static bool told = false;
     if (!use_rccl && !told) {
       told = true;
@@ -1621,10 +1621,13 @@ void prove_multi_t(zkp_ctx* root, zkp_groth16_pk_multi* M, const uint64_t* const
   const void* gathered = M->gathered;
   if (use_rccl) {
     RcclApi& R = rccl();
+    // two roots over the same devices share these communicators (two prover threads of one process): their groups are enqueued one
+    // after the other, in the same order on every rank
+    std::lock_guard<std::mutex> lk(R.mu);
     ZKP_REQUIRE(R.f.GroupStart() == 0, ZKP_ERR_DEVICE);
     for (int k = 0; k < n; k++) {
       ZKP_HIP(hipSetDevice(root->devs[k]->device));
-      ZKP_REQUIRE(R.f.AllGather(M->partial[k], M->gathered_all[k], pb, /*ncclUint8*/ 1, R.comms[k], root->devs[k]->cur->stream) == 0,
+      ZKP_REQUIRE(R.f.AllGather(M->partial[k], M->gathered_all[k], pb, /*ncclUint8*/ 1, (*rccl_comms)[k], root->devs[k]->cur->stream) == 0,
                   ZKP_ERR_DEVICE);
     }
     ZKP_REQUIRE(R.f.GroupEnd() == 0, ZKP_ERR_DEVICE);
