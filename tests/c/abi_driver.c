@@ -162,6 +162,34 @@ static int groth16_mode(const char* in, const char* out) {
     CHECK(zkp_ctx_destroy(root));
   }
 
+  /* per-context configuration from C (ABI 0.6): a second context with two lanes, the key kept in coefficient form and the proof
+   * points normalised on the device reads its configuration back and proves the same (r0, s0) and the same batch */
+  {
+    zkp_ctx_config cfg, got;
+    zkp_ctx* c2 = NULL;
+    zkp_groth16_pk* pk2 = NULL;
+    uint64_t* p2 = (uint64_t*)calloc(n_proofs * pw, 8);
+    uint8_t* p2_inf = (uint8_t*)malloc(n_proofs * 3);
+    memset(&cfg, 0, sizeof cfg);
+    if (zkp_ctx_create_ex(&c2, 0, &cfg) != ZKP_ERR_BAD_ARG) return 3;      /* struct_size == 0 */
+    cfg.struct_size = (uint32_t)sizeof cfg;
+    cfg.lanes = 2;
+    cfg.h_evaluation_form = ZKP_OFF;
+    cfg.host_affine = ZKP_OFF;
+    CHECK(zkp_ctx_create_ex(&c2, 0, &cfg));
+    CHECK(zkp_ctx_get_config(c2, &got));
+    if (got.struct_size != sizeof got || got.lanes != 2 || got.h_evaluation_form != ZKP_OFF || got.host_affine != ZKP_OFF) return 3;
+    CHECK(zkp_groth16_pk_upload(c2, &d, &pk2));
+    CHECK(zkp_groth16_prove(c2, pk2, z, r, s, p2, p2_inf));
+    if (memcmp(p2, one, pw * 8) != 0 || memcmp(p2_inf, one_inf, 3) != 0) { fprintf(stderr, "proof of the configured context differs\n"); return 5; }
+    CHECK(zkp_groth16_prove_batch(c2, pk2, n_proofs, zs, r, s, p2, p2_inf));
+    if (memcmp(p2, batch, n_proofs * pw * 8) != 0 || memcmp(p2_inf, batch_inf, n_proofs * 3) != 0) { fprintf(stderr, "batch of the configured context differs\n"); return 5; }
+    CHECK(zkp_groth16_pk_free(c2, pk2));
+    CHECK(zkp_ctx_destroy(c2));
+    free(p2);
+    free(p2_inf);
+  }
+
   f = fopen(out, "wb");
   if (!f) return 1;
   fwrite(&N, 8, 1, f);

@@ -66,7 +66,9 @@ def _run_driver(mode, blob, tmp_path):
 
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 def test_c_program_groth16_seam_reproduces_the_golden_proofs(tmp_path, curve):
-    """zkp_groth16_pk_upload -> zkp_groth16_witness_map -> zkp_groth16_prove -> zkp_groth16_prove_batch from a plain C99
+    """(Since round 6 the program also creates a second context with zkp_ctx_create_ex — two lanes, coefficient-form key, device-side
+    into_affine — reads the configuration back and requires the same proof and the same batch: compared in C.)
+    zkp_groth16_pk_upload -> zkp_groth16_witness_map -> zkp_groth16_prove -> zkp_groth16_prove_batch from a plain C99
     program (what the Rust `create_proof` seam of rust/patches binds, groth16/src/prover.rs:124) on the golden Mini / MiMC
     instances: h and the proof of the golden (r, s) equal tests/golden/golden.json, the other proofs of the batch equal the
     oracle prover's.  The key arrays are built from the ORACLE's key on the host: no ctypes call touches the library here."""
