@@ -30,8 +30,14 @@ sys.exit(pytest.main(["-x", "-q", "-p", "no:cacheprovider", "tests/test_fs_rng.p
 
 
 def test_oracle_cpu_and_fs_rng_are_clean_under_asan_and_ubsan(tmp_path):
+    import pytest
     from oracle import cpu_oracle
-    rt = cpu_oracle.asan_runtime()
+    if not os.path.exists(cpu_oracle.CLANGXX):
+        pytest.skip(f"{cpu_oracle.CLANGXX} not present: no sanitizer toolchain on this host")
+    try:
+        rt = cpu_oracle.asan_runtime()
+    except RuntimeError as e:
+        pytest.skip(str(e))
     fs_so = tmp_path / "libfs_rng_asan.so"
     r = subprocess.run([cpu_oracle.CLANGXX, "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libasan",
                         "-fno-omit-frame-pointer", str(ROOT / "ckb_zkp_amd" / "csrc" / "fs_rng.cpp"), "-o", str(fs_so)],
