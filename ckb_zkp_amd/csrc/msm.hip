@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <type_traits>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -433,8 +434,10 @@ constexpr uint32_t SORT_BIN_TARGET = 16384;   // entries per level-1 bin the lev
 constexpr int SORT_L_MAX = 13;         // level-2 keys per bin <= 8192 (dynamic LDS)
 constexpr int SORT_SCALARS = 2048;    // default; larger MSMs use larger tiles (runtime `tile`) to keep the tile count ~1200
 constexpr int SORT_SCALARS_UNUSED_ = 0;     // scalars per workgroup in the level-1 passes (8 per lane): larger tiles = smaller (bin x tile) count matrix and longer contiguous runs per bin in the scatter (512 -> 2048: +2 % proofs/s)
-template <class FrP>
-__global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restrict__ scalars, size_t n, size_t offset,
+// NT = threads per workgroup.  Round 6: all workgroups of the level-1 passes are resident at once, so a pass lasts as long as ONE
+// workgroup; a tile's scalars are spread over more lanes (profiles/r06_sort_stage_ab.txt).
+template <class FrP, int NT>
+__global__ __launch_bounds__(NT) void sort_hist_kernel(const uint32_t* __restrict__ scalars, size_t n, size_t offset,
                                                         const uint8_t* __restrict__ inf, int montgomery, int c, int W, int wide,
                                                         uint32_t nb, int L, uint32_t nbins1,
                                                         uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t tile,
@@ -442,10 +445,10 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restri
   ZKP_SORT_PRIO();
   const uint32_t gmask = (1u << lgk) - 1;                          // window w -> bucket set w & gmask, table copy w >> lgk
   __shared__ uint32_t cnt[(1 << SORT_H1_MAX) + 1];
-  for (uint32_t i = threadIdx.x; i <= nbins1; i += 256) cnt[i] = 0;
+  for (uint32_t i = threadIdx.x; i <= nbins1; i += NT) cnt[i] = 0;
   __syncthreads();
-  for (uint32_t rep = 0; rep < tile / 256; rep++) {
-    size_t i = (size_t)blockIdx.x * tile + rep * 256 + threadIdx.x;
+  for (uint32_t j = threadIdx.x; j < tile; j += NT) {          // (tile is a multiple of 256, not necessarily of NT)
+    size_t i = (size_t)blockIdx.x * tile + j;
     if (i < n && !(inf && inf[offset + i])) {
       DigitIter it = load_scalar<FrP>(scalars, i, montgomery);
       for (int w = 0; w < W; w++) {
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restri
     }
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < nbins1; i += 256) hist[(size_t)i * nblocks + blockIdx.x] = cnt[i];
+  for (uint32_t i = threadIdx.x; i < nbins1; i += NT) hist[(size_t)i * nblocks + blockIdx.x] = cnt[i];
 }
 template <class FrP>
 __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __restrict__ scalars, size_t n,
@@ -527,8 +530,8 @@ __device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* cnt, uint32_t idx, bo
 #define ZKP_SORT_STAGE_BYTES (56 * 1024)
 #endif
 constexpr uint32_t SORT_STAGE_BYTES = ZKP_SORT_STAGE_BYTES;
-template <class FrP>
-__global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t* __restrict__ scalars, size_t n,
+template <class FrP, int NT>
+__global__ __launch_bounds__(NT) void sort_scatter_staged_kernel(const uint32_t* __restrict__ scalars, size_t n,
                                                                   size_t offset, const uint8_t* __restrict__ inf,
                                                                   int montgomery, size_t ntab, int c, int W, int wide, uint32_t nb,
                                                                   int L, uint32_t nbins1, const uint32_t* __restrict__ offs,
@@ -537,21 +540,22 @@ __global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t
   ZKP_SORT_PRIO();
   const uint32_t gmask = (1u << lgk) - 1;
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
-  __shared__ uint32_t pre[256];
+  __shared__ uint32_t pre[NT];
   uint32_t* cur = sm;                                     // [nbins1] next free slot of (bin, this tile) in kv
   uint32_t* cnt = cur + nbins1;                           // [nbins1] counts -> cursors inside the stage
   uint64_t* stage = reinterpret_cast<uint64_t*>(cnt + ((nbins1 + 3) & ~3u));
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < nbins1; i += 256) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
+  for (uint32_t i = tid; i < nbins1; i += NT) cur[i] = offs[(size_t)i * nblocks + blockIdx.x];
   const uint32_t lmask = (1u << L) - 1;
-  const uint32_t per = (nbins1 + 255) / 256;
+  const uint32_t per = (nbins1 + NT - 1) / NT;
   for (uint32_t s0 = 0; s0 < tile; s0 += sub) {
-    for (uint32_t i = tid; i < nbins1; i += 256) cnt[i] = 0;
+    for (uint32_t i = tid; i < nbins1; i += NT) cnt[i] = 0;
     __syncthreads();
     // phase A: counts per bin
-    for (uint32_t rep = 0; rep < sub / 256; rep++) {
-      const size_t i = (size_t)blockIdx.x * tile + s0 + rep * 256 + tid;
-      const bool live = s0 + rep * 256 + tid < tile && i < n && !(inf && inf[offset + i]);
+    for (uint32_t rep = 0; rep * NT < sub; rep++) {               // every lane of a wave runs the loop (wave_agg_inc): `live` masks
+      const uint32_t j = rep * NT + tid;
+      const size_t i = (size_t)blockIdx.x * tile + s0 + j;
+      const bool live = j < sub && s0 + j < tile && i < n && !(inf && inf[offset + i]);
       DigitIter it = load_scalar<FrP>(scalars, live ? i : 0, montgomery);
       for (int w = 0; w < W; w++) {
         uint32_t key, neg;
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t
       }
       pre[tid] = acc;
       __syncthreads();
-      for (uint32_t d = 1; d < 256; d <<= 1) {
+      for (uint32_t d = 1; d < NT; d <<= 1) {
         const uint32_t add = tid >= d ? pre[tid - d] : 0;
         __syncthreads();
         pre[tid] += add;
@@ -587,11 +591,12 @@ __global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t
       }
     }
     __syncthreads();
-    const uint32_t total = pre[255];
+    const uint32_t total = pre[NT - 1];
     // phase B: entries into the stage, bin by bin
-    for (uint32_t rep = 0; rep < sub / 256; rep++) {
-      const size_t i = (size_t)blockIdx.x * tile + s0 + rep * 256 + tid;
-      const bool live = s0 + rep * 256 + tid < tile && i < n && !(inf && inf[offset + i]);
+    for (uint32_t rep = 0; rep * NT < sub; rep++) {               // every lane of a wave runs the loop (wave_agg_inc): `live` masks
+      const uint32_t j = rep * NT + tid;
+      const size_t i = (size_t)blockIdx.x * tile + s0 + j;
+      const bool live = j < sub && s0 + j < tile && i < n && !(inf && inf[offset + i]);
       DigitIter it = load_scalar<FrP>(scalars, live ? i : 0, montgomery);
       const uint64_t gbits = live && group_flags ? (uint64_t)(group_flags[offset + i] & 7u) << 61 : 0;
       for (int w = 0; w < W; w++) {
@@ -608,14 +613,14 @@ __global__ __launch_bounds__(256) void sort_scatter_staged_kernel(const uint32_t
     }
     __syncthreads();
     // copy out: cnt[b] is now the END of bin b inside the stage, i.e. the start of bin b + 1
-    for (uint32_t j = tid; j < total; j += 256) {
+    for (uint32_t j = tid; j < total; j += NT) {
       const uint64_t e = stage[j];
       const uint32_t b = (uint32_t)(e >> 45) & 0x1fffu;
       const uint32_t lo = b ? cnt[b - 1] : 0;
       kv[cur[b] + (j - lo)] = e;
     }
     __syncthreads();
-    for (uint32_t b = tid; b < nbins1; b += 256) cur[b] += cnt[b] - (b ? cnt[b - 1] : 0);
+    for (uint32_t b = tid; b < nbins1; b += NT) cur[b] += cnt[b] - (b ? cnt[b - 1] : 0);
     __syncthreads();
   }
 }
@@ -1002,26 +1007,37 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     const bool timed_scan = ms_scan && ctx->profiling && !reuse && !l1_reuse;      // K5 "scalar scan": histogram pass + count scan + scatter pass
     if (timed_scan) ZKP_HIP(hipEventRecord(ctx->ev2, st));
     if (reuse || l1_reuse) {
-    } else if (be->curve == ZKP_BN254) {
-      hipLaunchKernelGGL(sort_hist_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
-                         wide, nb_w, LB, nbins1, hist, nblocks, tile, lgk);
-      exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-      if (staged_sub)
-        hipLaunchKernelGGL(sort_scatter_staged_kernel<Bn254Fr>, dim3(nblocks), dim3(256), staged_lds, st, sc, n, offset, scan_inf,
-                           mont, be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, lgk, grp, staged_sub);
-      else
-        hipLaunchKernelGGL(sort_scatter_kernel<Bn254Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
-                           be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, lgk, grp);
     } else {
-      hipLaunchKernelGGL(sort_hist_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, c, W,
-                         wide, nb_w, LB, nbins1, hist, nblocks, tile, lgk);
-      exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
-      if (staged_sub)
-        hipLaunchKernelGGL(sort_scatter_staged_kernel<Bls381Fr>, dim3(nblocks), dim3(256), staged_lds, st, sc, n, offset, scan_inf,
-                           mont, be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, lgk, grp, staged_sub);
-      else
-        hipLaunchKernelGGL(sort_scatter_kernel<Bls381Fr>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont,
-                           be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, lgk, grp);
+      // threads per workgroup of the two level-1 passes (A/B: ZKP_SORT_NT_HIST / ZKP_SORT_NT_SCATTER = 256 restores rounds 3-5)
+      static const int nt_hist = [] { const char* e = getenv("ZKP_SORT_NT_HIST"); return e ? atoi(e) : 1024; }();
+      static const int nt_scat = [] { const char* e = getenv("ZKP_SORT_NT_SCATTER"); return e ? atoi(e) : 512; }();
+      auto level1 = [&](auto tag) {
+        using FrP = decltype(tag);
+        auto hist_l = [&](auto nt) {
+          constexpr int NT = decltype(nt)::value;
+          hipLaunchKernelGGL((sort_hist_kernel<FrP, NT>), dim3(nblocks), dim3(NT), 0, st, sc, n, offset, scan_inf, mont, c, W, wide, nb_w,
+                             LB, nbins1, hist, nblocks, tile, lgk);
+        };
+        if (nt_hist >= 1024) hist_l(std::integral_constant<int, 1024>{});
+        else if (nt_hist >= 512) hist_l(std::integral_constant<int, 512>{});
+        else hist_l(std::integral_constant<int, 256>{});
+        exclusive_scan_u32(st, hist, offs, hist_n, ws.scan_tmp);
+        if (staged_sub) {
+          auto scat_l = [&](auto nt) {
+            constexpr int NT = decltype(nt)::value;
+            hipLaunchKernelGGL((sort_scatter_staged_kernel<FrP, NT>), dim3(nblocks), dim3(NT), staged_lds, st, sc, n, offset,
+                               scan_inf, mont, be->n, c, W, wide, nb_w, LB, nbins1, offs, nblocks, tile, kv, lgk, grp, staged_sub);
+          };
+          if (nt_scat >= 1024) scat_l(std::integral_constant<int, 1024>{});
+          else if (nt_scat >= 512) scat_l(std::integral_constant<int, 512>{});
+          else scat_l(std::integral_constant<int, 256>{});
+        } else {
+          hipLaunchKernelGGL(sort_scatter_kernel<FrP>, dim3(nblocks), dim3(256), 0, st, sc, n, offset, scan_inf, mont, be->n, c, W, wide,
+                             nb_w, LB, nbins1, offs, nblocks, tile, kv, lgk, grp);
+        }
+      };
+      if (be->curve == ZKP_BN254) level1(Bn254Fr{});
+      else level1(Bls381Fr{});
     }
     if (timed_scan) {
       ZKP_HIP(hipEventRecord(ctx->ev3, st));
