@@ -631,7 +631,10 @@ __global__ __launch_bounds__(NT) void sort_scatter_staged_kernel(const uint32_t*
 //  reading 1200 short runs per bin: A-query MSM 2.66 vs 2.37 ms, 106-108 vs 113 proofs/s.  Reverted; commit 'Level-1 bucket
 //  sort as ONE kernel per tile' holds the code.)
 constexpr uint32_t SORT_BIN_THREADS = 1024;
-constexpr uint32_t SORT_BIN_STAGE = 20480;      // values staged in LDS (80 KiB) so the output is written fully coalesced
+#ifndef ZKP_SORT_BIN_STAGE                      // A/B builds: 18432 (72 KiB) lets two workgroups share a CU
+#define ZKP_SORT_BIN_STAGE 20480
+#endif
+constexpr uint32_t SORT_BIN_STAGE = ZKP_SORT_BIN_STAGE;      // values staged in LDS (80 KiB) so the output is written fully coalesced
 __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64_t* __restrict__ kv,
                                                                     const uint32_t* __restrict__ offs,
                                                                     uint32_t nblocks, int L,
