@@ -494,6 +494,36 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
     }
   }
 }
+// Exclusive prefix sum of one value per thread over a workgroup of NT threads: wave scan by lane shuffles, the NT / 64 wave totals
+// through LDS (tmp: >= NT / 64 + 1 words), three barriers instead of the 2 log2(NT) of a Hillis-Steele pass over LDS (round 6: the
+// level-1 / level-2 sort kernels are latency chains of such phases).  Returns the exclusive prefix; *total = the sum over the workgroup.
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, uint32_t* total) {
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+    if (lane >= (uint32_t)d) incl += up;
+  }
+  if (lane == 63u) tmp[wave] = incl;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < NT / 64; w++) {
+      const uint32_t x = tmp[w];
+      tmp[w] = run;
+      run += x;
+    }
+    tmp[NT / 64] = run;
+  }
+  __syncthreads();
+  const uint32_t res = tmp[wave] + incl - v;
+  *total = tmp[NT / 64];
+  __syncthreads();                                              // tmp may be reused by the caller's next scan
+  return res;
+}
+
 // ------------------------------------------------------------------------------------------- staged level-1 scatter (round 3)
 // Counter increment for a wave in which many lanes may hit the SAME counter (skewed scalars: a boolean witness sends every
 // non-zero digit of window 0 to bucket 0, equal scalars collide in every window): the lanes that share the first active lane's
@@ -566,21 +596,14 @@ __global__ __launch_bounds__(NT) void sort_scatter_staged_kernel(const uint32_t*
     }
     __syncthreads();
     // exclusive scan of the counts, in place
+    uint32_t total;
     {
       uint32_t acc = 0;
       for (uint32_t k = 0; k < per; k++) {
         const uint32_t idx = tid * per + k;
         if (idx < nbins1) acc += cnt[idx];
       }
-      pre[tid] = acc;
-      __syncthreads();
-      for (uint32_t d = 1; d < NT; d <<= 1) {
-        const uint32_t add = tid >= d ? pre[tid - d] : 0;
-        __syncthreads();
-        pre[tid] += add;
-        __syncthreads();
-      }
-      uint32_t run = pre[tid] - acc;
+      uint32_t run = block_excl_scan<NT>(acc, pre, &total);
       for (uint32_t k = 0; k < per; k++) {
         const uint32_t idx = tid * per + k;
         if (idx < nbins1) {
@@ -591,7 +614,6 @@ __global__ __launch_bounds__(NT) void sort_scatter_staged_kernel(const uint32_t*
       }
     }
     __syncthreads();
-    const uint32_t total = pre[NT - 1];
     // phase B: entries into the stage, bin by bin
     for (uint32_t rep = 0; rep * NT < sub; rep++) {               // every lane of a wave runs the loop (wave_agg_inc): `live` masks
       const uint32_t j = rep * NT + tid;
@@ -661,7 +683,7 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
     if (!(x & dmask)) atomicAdd(&cnt[(uint32_t)(x >> 32) & kmask], 1u);
   }
   __syncthreads();
-  // exclusive scan of the nk counters: `per` consecutive counters per thread + Hillis-Steele over the partials
+  // exclusive scan of the nk counters: `per` consecutive counters per thread + a workgroup scan of the partials
   {
     const uint32_t per = (nk + T - 1) / T;
     uint32_t acc = 0;
@@ -669,16 +691,8 @@ __global__ __launch_bounds__(SORT_BIN_THREADS) void sort_bin_kernel(const uint64
       uint32_t idx = t * per + k;
       if (idx < nk) acc += cnt[idx];
     }
-    pre[t] = acc;
-    __syncthreads();
-    const uint32_t live = (nk + per - 1) / per;          // threads with a non-zero partial: distances >= live add nothing
-    for (uint32_t d = 1; d < live; d <<= 1) {
-      uint32_t add = t >= d ? pre[t - d] : 0;
-      __syncthreads();
-      pre[t] += add;
-      __syncthreads();
-    }
-    uint32_t run = pre[t] - acc;
+    uint32_t total_unused;
+    uint32_t run = block_excl_scan<(int)SORT_BIN_THREADS>(acc, pre, &total_unused);
     for (uint32_t k = 0; k < per; k++) {
       uint32_t idx = t * per + k;
       if (idx < nk) {
