@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void zero_empty_buckets_kernel(const uint32_t*
   for (uint32_t k = 0; k < xb / 16; k++) p[k] = make_uint4(0, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void task_fill_kernel(const uint32_t* __restrict__ start,
+__global__ __launch_bounds__(1024) void task_fill_kernel(const uint32_t* __restrict__ start,
                                                         const uint32_t* __restrict__ end,
                                                         const uint32_t* __restrict__ toff, uint32_t nb,
                                                         uint32_t* __restrict__ task_start,
@@ -788,7 +788,7 @@ __global__ void task_cursor_kernel(uint32_t* tmeta) {
   }
 }
 
-__global__ __launch_bounds__(256) void task_order_kernel(const uint32_t* __restrict__ task_start,
+__global__ __launch_bounds__(1024) void task_order_kernel(const uint32_t* __restrict__ task_start,
                                                          const uint32_t* __restrict__ task_len,
                                                          const uint32_t* __restrict__ task_dst,
                                                          const uint32_t* __restrict__ n_tasks_dev,
@@ -1082,10 +1082,12 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
       ZKP_HIP(hipMemsetAsync(tmeta, 0, TM_WORDS * 4, st));
       hipLaunchKernelGGL(task_count_kernel, dim3((nb + 256) / 256), dim3(256), 0, st, start, end, nb, tcount, be->cap);
       exclusive_scan_u32(st, tcount, toff, (size_t)nb + 1, ws.scan_tmp2);
-      hipLaunchKernelGGL(task_fill_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, start, end, toff, nb, task_start,
+      // (1024 threads per workgroup since round 6: a quarter of the per-(block, length) global atomics on the 129 length counters)
+      static const uint32_t tnt = [] { const char* e = getenv("ZKP_TASK_NT"); const int v = e ? atoi(e) : 1024; return (uint32_t)(v >= 1024 ? 1024 : v >= 512 ? 512 : 256); }();
+      hipLaunchKernelGGL(task_fill_kernel, dim3((nb + tnt - 1) / tnt), dim3(tnt), 0, st, start, end, toff, nb, task_start,
                          task_len, task_dst, long_list, tmeta, be->cap);
       hipLaunchKernelGGL(task_cursor_kernel, dim3(1), dim3(64), 0, st, tmeta);
-      hipLaunchKernelGGL(task_order_kernel, dim3((max_tasks + 255) / 256), dim3(256), 0, st, task_start, task_len, task_dst,
+      hipLaunchKernelGGL(task_order_kernel, dim3((max_tasks + tnt - 1) / tnt), dim3(tnt), 0, st, task_start, task_len, task_dst,
                          toff + nb, tmeta, desc);
       ZKP_HIP(hipEventRecord(ws.sorted, st));
       ctx->mark(st, ":sorted");
