@@ -1194,6 +1194,13 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     const uint32_t chunk = ctx->batch_mode ? SEG_CHUNK_BATCH : SEG_CHUNK;
     plan.chunk = chunk;
     uint32_t lvl_off = 0, cnt = nb, blocks = 0;
+    // Round 6: the one-workgroup top of the pyramid and the segmented sums of the levels below it run in ONE launch (msm_group.hip
+    // pair_top_segsum_kernel); the second stage then sums the partials of the low levels and, directly from the pyramid, the odd
+    // entries of the top's levels (<= PAIR_TOP_MAX / 2 = one block each).  ZKP_PAIR_TOP_FUSE_SEG=0: pair_top, then both stages (rounds 3-5).
+    static const bool fuse_seg = !(getenv("ZKP_PAIR_TOP_FUSE_SEG") && atoi(getenv("ZKP_PAIR_TOP_FUSE_SEG")) == 0);
+    int l_top = -1;                                // first level the fused top produces the successor of
+    char* top_base = nullptr;
+    uint32_t top_cnt = 0;
     for (int l = 0; l < L; l++) {
       uint32_t next_off = lvl_off + cnt;
       static const bool top_fused = !(getenv("ZKP_PAIR_TOP") && atoi(getenv("ZKP_PAIR_TOP")) == 0);
@@ -1206,7 +1213,15 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
         return v;
       }();
       if (!top_fused || cnt > top_max) vt->pair(st, buckets + (size_t)lvl_off * XB, buckets + (size_t)next_off * XB, cnt / 2);
-      else if (cnt == top_max || l == 0) vt->pair_top(st, buckets + (size_t)lvl_off * XB, cnt);   // this level and all above it
+      else if (cnt == top_max || l == 0) {         // this level and all above it
+        if (fuse_seg && cnt / 2 <= chunk) {
+          l_top = l;
+          top_base = buckets + (size_t)lvl_off * XB;
+          top_cnt = cnt;
+        } else {
+          vt->pair_top(st, buckets + (size_t)lvl_off * XB, cnt);
+        }
+      }
       plan.first_block[l] = blocks;
       plan.off[l] = lvl_off + 1;
       plan.stride[l] = 2;
@@ -1219,8 +1234,31 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
     const char* root = buckets + (size_t)lvl_off * XB;      // cnt == 1
     char* partial = reinterpret_cast<char*>(ws.tmp.get(((size_t)blocks + 64) * XB));
     char* Obuf = partial + (size_t)blocks * XB;
-    if (L > 0) {
-      vt->segsum(st, buckets, &plan, partial, blocks);
+    if (L > 0 && l_top >= 0) {
+      SegPlan low = plan;                                    // levels 0 .. l_top - 1: complete before this launch
+      low.L = l_top;
+      const uint32_t blocks_low = plan.first_block[l_top];
+      vt->pair_top_segsum(st, top_base, top_cnt, buckets, &low, partial, blocks_low);
+      SegPlan p2{};
+      p2.L = L;
+      p2.chunk = chunk;
+      for (int l = 0; l < L; l++) {
+        p2.first_block[l] = l;
+        if (l < l_top) {                                     // the level's partials
+          p2.off[l] = plan.first_block[l];
+          p2.stride[l] = 1;
+          p2.count[l] = plan.first_block[l + 1] - plan.first_block[l];
+        } else {                                             // the level's odd entries themselves
+          p2.off[l] = plan.off[l];
+          p2.stride[l] = plan.stride[l];
+          p2.count[l] = plan.count[l];
+        }
+        ZKP_REQUIRE(p2.count[l] <= chunk, ZKP_ERR_BAD_ARG);
+      }
+      p2.first_block[L] = L;
+      vt->segsum(st, partial, &p2, Obuf, L, buckets, l_top);
+    } else if (L > 0) {
+      vt->segsum(st, buckets, &plan, partial, blocks, nullptr, 1 << 30);
       SegPlan p2{};
       p2.L = L;
       p2.chunk = chunk;
@@ -1232,7 +1270,7 @@ static void msm_run_entry(zkp_ctx* ctx, const BasesEntry* be, size_t offset, con
         ZKP_REQUIRE(p2.count[l] <= chunk, ZKP_ERR_BAD_ARG);
       }
       p2.first_block[L] = L;
-      vt->segsum(st, partial, &p2, Obuf, L);
+      vt->segsum(st, partial, &p2, Obuf, L, nullptr, 1 << 30);
     }
     vt->final(st, Obuf, L, root, (char*)out_dev_xyzz, out_jac);
     ctx->mark(st, ":reduced");

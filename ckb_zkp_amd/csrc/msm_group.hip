@@ -73,8 +73,7 @@ __global__ __launch_bounds__(256) void pair_kernel(const char* __restrict__ in, 
 // the hardware queue instead of ten (streams that share the queue wait behind every packet).
 constexpr int PAIR_TOP_THREADS = 512;
 template <class F>
-__global__ __launch_bounds__(PAIR_TOP_THREADS) void pair_top_kernel(char* __restrict__ base, uint32_t cnt) {
-  __builtin_amdgcn_s_setprio(3);
+__device__ __forceinline__ void pair_top_body(char* __restrict__ base, uint32_t cnt) {
   char* in = base;
   for (; cnt > 1; cnt >>= 1) {
     char* out = in + (size_t)cnt * BkPoint<F>::BYTES;
@@ -97,57 +96,90 @@ __global__ __launch_bounds__(PAIR_TOP_THREADS) void pair_top_kernel(char* __rest
     in = out;
   }
 }
-
-// block -> (segment l, chunk): sums <= plan.chunk entries into partial[block]
 template <class F>
-__global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ base, SegPlan plan,
-                                                     char* __restrict__ partial) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
+__global__ __launch_bounds__(PAIR_TOP_THREADS) void pair_top_kernel(char* __restrict__ base, uint32_t cnt) {
+  __builtin_amdgcn_s_setprio(3);
+  pair_top_body<F>(base, cnt);
+}
+
+// One block of a segmented sum: block -> (segment l, chunk); sums <= plan.chunk entries into partial[block].  Segments l >= l_hi read
+// from base_hi instead of base (round 6: the second stage sums the partials of the low levels and, directly, the odd entries of the
+// levels the fused top produced).  Written for workgroups of >= 256 threads: threads >= 256 only take part in the barriers.
+template <class F>
+__device__ __forceinline__ void segsum_body(const char* __restrict__ base, const SegPlan& plan, char* __restrict__ partial, uint32_t block,
+                                            const char* __restrict__ base_hi, int l_hi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t t = threadIdx.x;
+  const bool act = t < 256;
   int l = 0;
-  while (l + 1 < plan.L && blockIdx.x >= plan.first_block[l + 1]) l++;
-  uint32_t chunk = blockIdx.x - plan.first_block[l];
+  while (l + 1 < plan.L && block >= plan.first_block[l + 1]) l++;
+  if (l >= l_hi) base = base_hi;
+  uint32_t chunk = block - plan.first_block[l];
   uint32_t lo = chunk * plan.chunk;
   uint32_t hi = min(plan.count[l], lo + plan.chunk);
   if constexpr (BkPoint<F>::MEM_ADD) {
-    // G2: the running sum lives in this thread's LDS slot and every addition streams its operands (BkPoint::add_mem)
-    char* my = smem + threadIdx.x * BkPoint<F>::BYTES;
-    BkPoint<F>::inf().store(my);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
-      BkPoint<F>::add_mem(my, base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * BkPoint<F>::BYTES, my);
+    // the running sum lives in this thread's LDS slot and every addition streams its operands (BkPoint::add_mem)
+    char* my = smem + (act ? t : 0) * BkPoint<F>::BYTES;
+    if (act) {
+      BkPoint<F>::inf().store(my);
+      for (uint32_t i = lo + t; i < hi; i += 256)
+        BkPoint<F>::add_mem(my, base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * BkPoint<F>::BYTES, my);
+    }
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
       bool coop = false;
       if constexpr (QuadCoop<F>::ON) {
         coop = s <= 64;                                                         // 64 quads: four lanes per addition from here on
-        if (coop && (int)(threadIdx.x >> 2) < s) {
-          char* mine = smem + (threadIdx.x >> 2) * BkPoint<F>::BYTES;
-          quad_add_any<F>(mine, smem + ((threadIdx.x >> 2) + s) * BkPoint<F>::BYTES, mine, threadIdx.x & 3);
+        if (coop && (int)(t >> 2) < s) {
+          char* mine = smem + (t >> 2) * BkPoint<F>::BYTES;
+          quad_add_any<F>(mine, smem + ((t >> 2) + s) * BkPoint<F>::BYTES, mine, t & 3);
         }
       }
-      if (!coop && (int)threadIdx.x < s) BkPoint<F>::add_mem(my, smem + (threadIdx.x + s) * BkPoint<F>::BYTES, my);
+      if (!coop && (int)t < s) BkPoint<F>::add_mem(my, smem + (t + s) * BkPoint<F>::BYTES, my);
       __syncthreads();
     }
-    if (threadIdx.x == 0) BkPoint<F>::copy_point(partial + (size_t)blockIdx.x * BkPoint<F>::BYTES, my);
+    if (t == 0) BkPoint<F>::copy_point(partial + (size_t)block * BkPoint<F>::BYTES, my);
     return;
   }
   BkPoint<F> acc = BkPoint<F>::inf();
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
-    acc.add(BkPoint<F>::load(base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * BkPoint<F>::BYTES));
-  // LDS tree
-  acc.store(smem + threadIdx.x * BkPoint<F>::BYTES);
+  if (act) {
+    for (uint32_t i = lo + t; i < hi; i += 256)
+      acc.add(BkPoint<F>::load(base + ((size_t)plan.off[l] + (size_t)i * plan.stride[l]) * BkPoint<F>::BYTES));
+    // LDS tree
+    acc.store(smem + t * BkPoint<F>::BYTES);
+  }
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      BkPoint<F> o = BkPoint<F>::load(smem + (threadIdx.x + s) * BkPoint<F>::BYTES);
+    if ((int)t < s) {
+      BkPoint<F> o = BkPoint<F>::load(smem + (t + s) * BkPoint<F>::BYTES);
       if (!o.is_inf() || !acc.is_inf()) {
         acc.add(o);
-        acc.store(smem + threadIdx.x * BkPoint<F>::BYTES);
+        acc.store(smem + t * BkPoint<F>::BYTES);
       }
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) acc.store(partial + (size_t)blockIdx.x * BkPoint<F>::BYTES);
+  if (t == 0) acc.store(partial + (size_t)block * BkPoint<F>::BYTES);
+}
+template <class F>
+__global__ __launch_bounds__(256) void segsum_kernel(const char* __restrict__ base, SegPlan plan, char* __restrict__ partial,
+                                                     const char* __restrict__ base_hi, int l_hi) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound tail: win issue arbitration against co-resident accumulate waves
+  segsum_body<F>(base, plan, partial, blockIdx.x, base_hi, l_hi);
+}
+// Round 6: the top of the pyramid (ONE workgroup, ~85 us of dependent additions) and the segmented sums of every level below it
+// (hundreds of workgroups, ~105 us) depend on disjoint data — in ONE launch they run side by side instead of one after the other:
+// block 0 = pair_top, blocks 1.. = segment-sum blocks of the levels the plain pair launches produced.
+template <class F>
+__global__ __launch_bounds__(PAIR_TOP_THREADS) void pair_top_segsum_kernel(char* __restrict__ top_base, uint32_t top_cnt,
+                                                                           const char* __restrict__ base, SegPlan plan,
+                                                                           char* __restrict__ partial) {
+  __builtin_amdgcn_s_setprio(3);
+  if (blockIdx.x == 0) {
+    pair_top_body<F>(top_base, top_cnt);
+    return;
+  }
+  segsum_body<F>(base, plan, partial, blockIdx.x - 1, nullptr, 1 << 30);
 }
 
 // Buckets split into up to COMBINE_SMALL tasks are folded by ONE lane each (64 buckets per wave-addition); only genuinely long
@@ -1008,8 +1040,13 @@ void l_pair(hipStream_t s, const char* in, char* out, uint32_t count) {
 void l_pair_top(hipStream_t s, char* base, uint32_t count) {
   hipLaunchKernelGGL(pair_top_kernel<F>, dim3(1), dim3(PAIR_TOP_THREADS), 0, s, base, count);
 }
-void l_segsum(hipStream_t s, const char* base, const SegPlan* plan, char* partial, uint32_t blocks) {
-  hipLaunchKernelGGL(segsum_kernel<F>, dim3(blocks), dim3(256), 256 * BB, s, base, *plan, partial);
+void l_segsum(hipStream_t s, const char* base, const SegPlan* plan, char* partial, uint32_t blocks, const char* base_hi, int l_hi) {
+  hipLaunchKernelGGL(segsum_kernel<F>, dim3(blocks), dim3(256), 256 * BB, s, base, *plan, partial, base_hi, l_hi);
+}
+void l_pair_top_segsum(hipStream_t s, char* top_base, uint32_t top_cnt, const char* base, const SegPlan* plan, char* partial,
+                       uint32_t blocks) {
+  hipLaunchKernelGGL(pair_top_segsum_kernel<F>, dim3(1 + blocks), dim3(PAIR_TOP_THREADS), 256 * BB, s, top_base, top_cnt, base, *plan,
+                     partial);
 }
 void l_final(hipStream_t s, const char* O, int L, const char* root, char* out_xyzz, uint32_t* out_jac) {
   constexpr int threads = (QuadCoop<F>::ON && QuadCoop<F>::GROUP == 1) ? 128 : 64;            // G1: 32 quads (coop_dev.hpp)
@@ -1104,6 +1141,7 @@ const MsmVtbl* ZKP_CFG_SYM(msm_vtbl)() {
 #else
       nullptr, nullptr,
 #endif
+      l_pair_top_segsum,
   };
   return &v;
 }

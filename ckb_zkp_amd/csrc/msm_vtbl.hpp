@@ -49,7 +49,8 @@ struct MsmVtbl {
   void (*combine)(hipStream_t, const uint32_t* long_list, const uint32_t* n_long_dev, const uint32_t* toff,
                   const char* partial, char* buckets, uint32_t init);   // init: add the bucket's stored value too
   void (*pair)(hipStream_t, const char* in, char* out, uint32_t count);
-  void (*segsum)(hipStream_t, const char* base, const SegPlan* plan, char* partial, uint32_t blocks);
+  // segments l >= l_hi read from base_hi instead of base (pass nullptr, 1 << 30 for a plain segmented sum)
+  void (*segsum)(hipStream_t, const char* base, const SegPlan* plan, char* partial, uint32_t blocks, const char* base_hi, int l_hi);
   void (*final)(hipStream_t, const char* O, int L, const char* root, char* out_xyzz, uint32_t* out_jac);
   void (*write_identity)(hipStream_t, char* out_xyzz, uint32_t* out_jac);
   void (*fold)(hipStream_t, const uint32_t* pts, int k, uint32_t* out_jac);
@@ -90,6 +91,9 @@ struct MsmVtbl {
   // out_m = L_m - sum over column m of a sparse matrix (CSC: col_ptr / rows / kind / coeff) of coeff * G_row, m < n_vars
   void (*lfold)(hipStream_t, const char* L_xy, const uint8_t* L_inf, size_t n_vars, const uint32_t* col_ptr, const uint32_t* rows,
                 const uint8_t* kind, const uint32_t* coeff, const char* G_xy, const uint8_t* G_inf, char* out_xy, uint8_t* out_inf);
+  // pair_top on (top_base, top_cnt) and the segmented sums of `plan` over `base` in ONE launch (block 0 | blocks 1..blocks)
+  void (*pair_top_segsum)(hipStream_t, char* top_base, uint32_t top_cnt, const char* base, const SegPlan* plan, char* partial,
+                          uint32_t blocks);
 };
 constexpr uint32_t PAIR_TOP_MAX = 2048;
 

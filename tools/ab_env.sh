@@ -1,19 +1,14 @@
 #!/bin/bash
-# A/B of an environment switch on the GPU box: tools/ab_env.sh <outdir> <rounds> "<env A>" "<env B>" [bench args...]
-# (e.g. tools/ab_env.sh gpurun_out/ab 3 "ZKP_CHAIN_LH=0" "ZKP_CHAIN_LH=1"); alternates A, B, A, B ... and prints proofs/s per run.
-OUT=$1; R=$2; A=$3; B=$4; shift 4
-mkdir -p $OUT
-for i in $(seq 1 $R); do
-  for V in A B; do
-    if [ $V = A ]; then E=$A; else E=$B; fi
-    env $E python bench.py --no-cpu-baseline --no-marlin "$@" > $OUT/$V.$i.json 2> $OUT/$V.$i.err
-    python - "$V[$E]" $OUT/$V.$i.json <<'PY'
-import json, sys
-try:
-    r = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-    print(sys.argv[1], r["value"], "lat", r.get("latency", {}).get("ms_per_proof"), "acc_ms", r["roofline"].get("avg_launch_ms"))
-except Exception as e:
-    print(sys.argv[1], "failed", e)
-PY
+# same-box A/B of ONE environment switch: bash tools/ab_env.sh VAR "v0 v1 ..." [passes=2]   (lone 2^20 / 2^22 MSM, Marlin, Groth16 2^20, single-proof latency)
+cd "$(dirname "$0")/.."
+VAR=$1; VALS=$2; P=${3:-2}
+val() { python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'], d.get('summary',{}).get('latency_ms'))"; }
+for pass in $(seq 1 $P); do
+  for v in $VALS; do
+    export $VAR=$v
+    s=$(SWEEP_ONLY_DEFAULT=1 python tools/msm_window_sweep.py bn254 20 2>/dev/null | awk '$1=="default"{print $3, $5}')
+    m=$(python bench.py --workload marlin --no-cpu-baseline --steps 8 2>/dev/null | val)
+    g=$(python bench.py --no-cpu-baseline --no-marlin --no-extra-configs --steps 64 --warmup 10 2>/dev/null | val)
+    echo "pass $pass $VAR=$v  lone MSM 2^20 (median ms, Mop/s): $s   marlin (proofs/s ms -): $m   groth16 2^20 (proofs/s ms latency_ms): $g"
   done
 done
